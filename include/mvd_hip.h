@@ -1,0 +1,211 @@
+/* mvd_hip.h -- C ABI of the MI355X-native (gfx950) MVD-Fusion denoising hot path.
+ *
+ * The reference (zhizdev/mvdfusion) is pure Python/PyTorch and has no FFI of its own; this ABI is the new
+ * boundary *below* the reference's config-driven classes.  Each entry point replaces a
+ * cluster of torch ops on the per-DDIM-step path; the reference site is cited next to it (paths relative to the
+ * reference root).  The Python mirror classes in mvdfusion_amd/ (GridAttn, UNetModel, ViewFusion, DDIMSampler)
+ * bind these symbols with ctypes -- see INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr()); the library never
+ *     allocates, frees or retains memory beyond a call;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t); no host synchronisation => calls are capturable
+ *     in a hipGraph (mvd_graph_*);
+ *   - return 0 on success, <0 on error; the message is available from mvd_last_error(); nothing throws;
+ *   - activations are fp32, channels-last: an image tensor is (B, H, W, C) == a row-major (B*H*W, C) matrix;
+ *   - GEMM-shaped math runs on bf16 MFMA.  `prec` selects MVD_PREC_BF16 (one product) or MVD_PREC_BF16X3
+ *     (operands split x = hi + lo, three products hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2^-17 relative
+ *     operand error, which is what keeps the 50-step trajectory within the 1e-3 latent-RMSE budget).
+ *   - one host thread per process / GPU (matches the reference's mp.spawn model, demo.py:208).
+ */
+#ifndef MVD_HIP_H
+#define MVD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mvd_stream_t; /* hipStream_t */
+
+#define MVD_VERSION 100
+#define MVD_PREC_BF16 1
+#define MVD_PREC_BF16X3 3
+
+int mvd_version(void);
+const char* mvd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight packing (once per model load).  Packed image: [K/32][N/16][2 planes: hi, lo][16 n][32 k] bf16,
+ * K padded to 32, N padded to 16 with zeros.  Bytes = mvd_packed_weight_bytes(N, K).
+ * Replaces nothing in the reference (its weights stay fp32 nn.Parameters); the Python mirrors keep the
+ * fp32 parameters under the reference's state_dict keys and pack on first use. */
+size_t mvd_packed_weight_bytes(int N, int K);
+/* w: (N, K) row-major fp32 with leading dimension ldw.  geglu != 0 interleaves value/gate row blocks of 16
+ * (rows [0,N/2) = value, [N/2,N) = gate, attention.py:43-44) so a GEMM tile holds matching value/gate columns. */
+int mvd_pack_linear_weight(const float* w, int N, int K, int ldw, int geglu, void* packed, mvd_stream_t stream);
+/* w: (Cout, Cin, 3, 3) fp32 (nn.Conv2d layout).  Packed K index = (ky*3+kx)*cin_pad + ci. */
+int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, void* packed, mvd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM convolution with fused epilogue.
+ *   nn.Linear                      external/sd1/ldm/modules/attention.py:161-168, 41, 60; mvdfusion/attention.py:100,114;
+ *                                  view_attn_efficient2.py:52-61,83,158,167 (timm Attention/Mlp linears)
+ *   nn.Conv2d 1x1                  attention.py:245,259; openaimodel.py:241
+ *   nn.Conv2d 3x3 (s1, s2, after nearest-2x upsample)   openaimodel.py:107,116,151,204,229-231; unet.py:323,499 */
+#define MVD_A_DENSE 0   /* A: (M, K) row-major fp32, leading dim lda */
+#define MVD_A_CONV3X3 1 /* A: NHWC (B, Hin, Win, Cin) fp32, pad 1; M = B*Hout*Wout, K = 9*Cin */
+
+#define MVD_EPI_STORE 0 /* out[m,n] = res[m,n] + colscale[n] * act(acc + bias[n] + bias_b[m / rows_per_batch, n]) */
+#define MVD_EPI_GEGLU 1 /* out[m,j] = (acc_v + bias[j]) * gelu(acc_g + bias[N/2 + j]);  out has N/2 columns */
+#define MVD_EPI_QKV 2   /* route N = 3*heads*dhead columns to the attention operand planes (see mvd_attention) */
+
+#define MVD_ACT_NONE 0
+#define MVD_ACT_GELU 1 /* exact erf GELU (nn.GELU(), F.gelu) */
+#define MVD_ACT_SILU 2
+
+typedef struct mvd_gemm_desc {
+  int M, N, K;      /* logical sizes; N % 16 == 0 after padding of the packed weight, K as packed (multiple of 32) */
+  const float* A;
+  int lda;
+  int a_mode;       /* MVD_A_* */
+  /* conv geometry (a_mode == MVD_A_CONV3X3) */
+  int B, Hin, Win, Cin, Hout, Wout, stride, upsample; /* upsample: input is nearest-2x upsampled before the conv */
+  const void* Wp;   /* packed weight (mvd_pack_*) */
+  int prec;         /* MVD_PREC_* */
+  /* epilogue */
+  int epi;          /* MVD_EPI_* */
+  int act;          /* MVD_ACT_* */
+  float* out;
+  int ldo;
+  int n_store;      /* columns actually stored (<= N; lets N be padded to 16, e.g. the 5-channel UNet head) */
+  const float* bias;     /* [N] or NULL */
+  const float* bias_b;   /* [M / rows_per_batch][N] or NULL (per-view vector, e.g. the kv_len==1 cross-attention) */
+  int rows_per_batch;
+  const float* colscale; /* [N] or NULL (adaLN gate) */
+  const float* res;      /* [M][ldr] or NULL */
+  int ldr;
+  /* MVD_EPI_QKV */
+  void *q_hi, *q_lo, *k_hi, *k_lo, *vt_hi, *vt_lo;
+  int heads, dhead, L, Lpad; /* rows m = b*L + token */
+  float qscale;              /* dhead^-0.5, applied to q in fp32 before the split */
+  /* split-K: 1 = none; >1 = that many K slices; 0 = choose automatically (fills the 256 CUs when the tile grid
+   * is small, i.e. the weight-bandwidth-bound low-resolution layers).  Partial fp32 slabs (splitk*M*N) go to
+   * `workspace` and are reduced by a second kernel that applies the epilogue; without a workspace (or when it is
+   * too small: workspace_elems) the GEMM runs unsplit. */
+  int splitk;
+  float* workspace;
+  size_t workspace_elems;
+} mvd_gemm_desc;
+
+int mvd_gemm(const mvd_gemm_desc* d, mvd_stream_t stream);
+
+/* fp32 matrix-vector products for the M<=16 cases (exact fp32 FMA):
+ *   y[m, n] = act_out( sum_k W[n,k] * act_in(x[m,k]) + bias[n] ),  W (N,K) row-major fp32.
+ * time_embed / emb_layers / adaLN / cc_projection / kv_len==1 cross-attention vectors:
+ *   unet.py:309-314,537-538; openaimodel.py:218-224,264; view_attn_efficient2.py:58-61,64;
+ *   viewfusion_zero_depth_rgb.py:110,126-132,276-279,322; attention.py:221 (context length 1). */
+int mvd_gemv(const float* W, const float* bias, const float* x, float* y, int M, int N, int K, int ldx, int ldy,
+             int act_in, int act_out, mvd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation.
+ * GroupNorm(32 groups) on channels-last data, optional fused SiLU (openaimodel.py:201-203,225-227 eps 1e-5;
+ * attention.py:76,243,274 and mvdfusion/attention.py:92,132 eps 1e-6; unet.py:496-498).
+ * ws: B * chunks * groups * 2 doubles with chunks = mvd_groupnorm_chunks(HW). */
+int mvd_groupnorm_chunks(int HW);
+int mvd_groupnorm_nhwc(const float* x, float* y, const float* gamma, const float* beta, int B, int HW, int C,
+                       int groups, float eps, int silu, double* ws, mvd_stream_t stream);
+/* LayerNorm over the last dim.  w/b may be NULL (no affine).  w_plus_one: y = norm * (1 + w) + b
+ * (adaLN "modulate", view_attn_efficient2.py:15-16,51,53,65-66); attention.py:211-213, mvdfusion/attention.py:35-37. */
+int mvd_layernorm(const float* x, float* y, const float* w, const float* b, int rows, int C, float eps,
+                  int w_plus_one, mvd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-attention over the tokens of one view (CrossAttention with context=None, attention.py:170-193).
+ * Operand planes are written by mvd_gemm(MVD_EPI_QKV):
+ *   q/k : [B][heads][Lpad][dq]   bf16, dq  = roundup(dhead, 32), zero padded, q pre-scaled by dhead^-0.5
+ *   vt  : [B][heads][dv][Lpad]   bf16, dv  = roundup(dhead, 16)   (V transposed: keys contiguous)
+ * out : (B*L, heads*dhead) fp32 row-major (leading dim ldo), head-major channels ('b n (h d)'). */
+size_t mvd_attn_qk_plane_elems(int B, int heads, int L, int dhead);
+size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead);
+int mvd_attn_lpad(int L);
+int mvd_attention(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                  const void* vt_lo, float* out, int ldo, int B, int heads, int L, int dhead, int prec,
+                  mvd_stream_t stream);
+
+/* Per-pixel cross attention of one query token against D context tokens (DualAttnetionBlock attn2,
+ * mvdfusion/attention.py:56-62; D = n_pts_per_ray).  q (P, C), k/v (P*D, C), out (P, C), C = heads*dhead. */
+int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, float* out, int P, int D, int heads,
+                         int dhead, mvd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout / data-movement kernels. */
+/* UNet input (unet.py:167-187): x (V,5,S,S) NCHW, input_latents (1,5,S,S) NCHW ->
+ * out (2V, S, S, cpad) NHWC: rows [0,V) = [x, il[:4]/0.18215, il[4]] , rows [V,2V) = [x, 0]; channels >= 10 zero.
+ * With cfg == 0 only the first V rows are produced. */
+int mvd_unet_input(const float* x, const float* input_latents, float* out, int V, int S, int cpad, int cfg,
+                   mvd_stream_t stream);
+/* out[r, 0:Ca] = a[r], out[r, Ca:Ca+Cb] = b[r]  (torch.cat([h, hs.pop()], dim=1), unet.py:550) */
+int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, int rows, mvd_stream_t stream);
+/* area pooling by `factor` of vol (B, S, S, D, C) -> (B, S/f, S/f, D, C)  (unet.py:198-209) */
+int mvd_area_pool(const float* vol, float* out, int B, int S, int D, int C, int factor, mvd_stream_t stream);
+/* out[i] = 0 (memset as a kernel so it is graph-capturable on any stream) */
+int mvd_fill_zero(float* p, size_t n, mvd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-step scalars.  A device table `steps` of nsteps x MVD_STEP_STRIDE floats, indexed by a device-resident
+ * iteration counter *iter (so a captured graph needs no per-step host input):
+ *   [0] t  [1] sqrt(alpha_bar_t)  [2] depth_std = sqrt(1-ab)/sqrt(ab)/10  [3] a_t  [4] a_prev  [5] sigma_t
+ *   [6] sqrt(1-a_t)  [7] 1 if noise is added at this step (sampler.py:63-65) */
+#define MVD_STEP_STRIDE 8
+/* sinusoidal embedding, cos first (diffusionmodules/util.py:152-172; mvdfusion/embedder.py:114-134): out (dim) */
+int mvd_timestep_embedding(const float* steps, const int* iter, float* out, int dim, mvd_stream_t stream);
+int mvd_advance_iter(int* iter, mvd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GridAttn: depth-conditioned cross-view aggregation (mvdfusion/view_attn_efficient2.py).
+ * Camera record (20 floats): R row-major (9), T (3), focal (2), principal point (2), centre C = -T R^T (3), pad. */
+#define MVD_CAM_RECORD 20
+#define MVD_TOKEN_DIM 723
+#define MVD_TOKEN_LD 736
+/* z_embedder: Linear(5->256)+GELU per pixel (:152,434-437).  lat (N,5,S,S) NCHW -> feat (N,S,S,256) NHWC. */
+int mvd_zembed(const float* lat, const float* w, const float* b, float* feat, int N, int S, mvd_stream_t stream);
+/* G1-G3 (:269-370, :418-432; utils/ray_utils.py:128-212,263-269,367-369; utils/common_utils.py:229-244):
+ * depth sample -> unproject -> reproject into every view and the input view -> bilinear gather (border,
+ * align_corners) -> Plucker / harmonic embeddings.  Writes the (T, MVD_TOKEN_LD) token matrix, row
+ * ((b*S*S + pix)*D + d)*V + v_ref, T = V*S*S*D*V; columns >= 723 are zero.
+ * x (V,5,S,S) NCHW noisy latents; depth_noise (nsteps, V, D, S, S) standard normal (host-ordered, trap T2). */
+int mvd_gridattn_tokens(const float* x, const float* depth_noise, const float* steps, const int* iter,
+                        const float* feat, const float* in_feat, const float* cams, const float* in_cam,
+                        float* tokens, int V, int S, int D, float depth_scale, float depth_shift,
+                        mvd_stream_t stream);
+/* timm Attention core over the V reference views (:52): qkv (Nseq*V, 3*heads*dhead) -> out (Nseq*V, heads*dhead) */
+int mvd_view_mha(const float* qkv, float* out, int Nseq, int V, int heads, int dhead, mvd_stream_t stream);
+/* weight_layer + softmax over V + weighted sum (:83,396-397): x (Nseq*V, C) -> out (Nseq, C) */
+int mvd_view_pool(const float* x, const float* w, const float* b, float* out, int Nseq, int V, int C,
+                  mvd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CFG combine + DDIM update (unet.py:195; sampler.py:43-66), fused elementwise.
+ * eps_nhwc (2V or V, S, S, ldc) UNet head output; x (V,5,S,S) NCHW updated IN PLACE; x0 (V,5,S,S) out.
+ * ddim_noise (nsteps, V, 5, S, S).  eps_out (V,5,S,S) NCHW or NULL receives the guided prediction. */
+int mvd_cfg_ddim_update(const float* eps_nhwc, int ldc, float* x, float* x0, float* eps_out,
+                        const float* ddim_noise, const float* steps, const int* iter, int V, int S, int cfg,
+                        float cfg_scale, int do_update, mvd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * hipGraph capture of a whole denoising step and HIP-event timing on the caller's stream. */
+int mvd_graph_begin(mvd_stream_t stream);
+int mvd_graph_end(mvd_stream_t stream, void** graph_exec);
+int mvd_graph_launch(void* graph_exec, mvd_stream_t stream);
+int mvd_graph_destroy(void* graph_exec);
+int mvd_event_create(void** ev);
+int mvd_event_record(void* ev, mvd_stream_t stream);
+int mvd_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int mvd_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVD_HIP_H */

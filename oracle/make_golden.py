@@ -1,0 +1,360 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference through
+oracle/shims.py) -- TEST INFRASTRUCTURE, container-only (the reference does not exist on the GPU box).
+
+For every fixture the same inputs are also pushed through the restatement in oracle/ref_torch.py and the
+two are required to agree (this is what pins the oracle).  Only inputs that cannot be re-derived from seeds
+and the outputs are stored; weights come from mvdfusion_amd.synthetic.det_fill (name-keyed, no weight files).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden [--only NAME]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import shims  # noqa: E402
+
+shims.install()
+
+from oracle import ref_torch as O  # noqa: E402
+from mvdfusion_amd import synthetic as syn  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+UNET_PARAMS = dict(image_size=32, in_channels=10, out_channels=5, model_channels=320,
+                   attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8,
+                   use_spatial_transformer=True, use_view_aligned_transformer=True, transformer_depth=1,
+                   context_dim=768, use_checkpoint=True, legacy=False)
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def fill_ref(module, prefix=""):
+    return syn.fill_module_(module, prefix)
+
+
+def sd_of(module, prefix=""):
+    return {prefix + k: v.detach().clone() for k, v in module.state_dict().items()}
+
+
+def ref_cams(c):
+    from pytorch3d.renderer import PerspectiveCameras
+    return PerspectiveCameras(R=c.R, T=c.T, focal_length=c.focal_length, principal_point=c.principal_point)
+
+
+def cam_dict(c):
+    return {"R": c.R, "T": c.T, "f": c.focal_length, "p": c.principal_point}
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    kb = os.path.getsize(os.path.join(GOLD, name + ".npz")) / 1024
+    print(f"  wrote tests/golden/{name}.npz ({kb:.0f} KB)")
+
+
+# ---------------------------------------------------------------------------------------------
+def gold_schedule():
+    from mvdfusion.scheduler import DDPMScheduler
+    from mvdfusion.sampler import DDIMSampler
+
+    class M:
+        pass
+    m = M()
+    m.scheduler = DDPMScheduler(1000)
+    s = DDIMSampler(m, ddim_num_steps=50, ddim_discretize="uniform", ddim_eta=1.0, latent_size=32, z_dim=4)
+    tab = O.ddpm_tables()
+    dd = O.ddim_schedule(tab)
+    assert torch.equal(tab["alphas_cumprod"], m.scheduler.alphas_cumprod)
+    assert torch.equal(tab["sqrt_alphas_cumprod"], m.scheduler.sqrt_alphas_cumprod)
+    assert torch.equal(tab["sqrt_one_minus_alphas_cumprod"], m.scheduler.sqrt_one_minus_alphas_cumprod)
+    assert np.array_equal(dd["timesteps"].numpy(), s.ddim_timesteps)
+    for a, b in (("alphas", s.ddim_alphas), ("alphas_prev", s.ddim_alphas_prev), ("sigmas", s.ddim_sigmas),
+                 ("sqrt_one_minus_alphas", s.ddim_sqrt_one_minus_alphas)):
+        assert torch.equal(dd[a], b), a
+    # DDIM update with injected noise
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 5, 8, 8, generator=g)
+    eps = torch.randn(2, 5, 8, 8, generator=g)
+    outs = {}
+    for index in (49, 25, 1, 0):
+        torch.manual_seed(77)
+        xp, x0 = s.denoise_apply_impl(x, index, eps, is_step0=index == 0)
+        torch.manual_seed(77)
+        noise = torch.randn_like(x) if index > 0 else None
+        oxp, ox0 = O.ddim_update(x, eps, dd, index, noise)
+        assert torch.equal(oxp, xp) and torch.equal(ox0, x0), index
+        outs[f"x_prev_{index}"] = xp
+        outs[f"x0_{index}"] = x0
+    save("schedule", alphas_cumprod=tab["alphas_cumprod"], ddim_timesteps=dd["timesteps"], ddim_alphas=dd["alphas"],
+         ddim_alphas_prev=dd["alphas_prev"], ddim_sigmas=dd["sigmas"],
+         ddim_sqrt_one_minus_alphas=dd["sqrt_one_minus_alphas"], x=x, eps=eps,
+         noise=torch.randn(2, 5, 8, 8, generator=torch.Generator().manual_seed(77)), **outs)
+    print("  schedule: oracle == reference (bit-exact)")
+
+
+def gold_cameras():
+    """Known-answer fixtures for the camera algebra (rig, re-basing, projection round trip)."""
+    from pytorch3d.renderer import look_at_view_transform, PerspectiveCameras
+    from utils.camera_utils import _get_relative_camera, _get_camera_slice
+    az = torch.tensor(syn.GSO_AZIMUTHS)
+    el = torch.full((16,), syn.GSO_ELEVATION)
+    R, T = look_at_view_transform(dist=1.5, azim=az * 180 / torch.pi + 90, elev=el * 180 / torch.pi,
+                                  up=((0, 1, 0),))
+    cams = PerspectiveCameras(R=R, T=T, focal_length=((2.1875, 2.1875),), principal_point=((0, 0),))
+    rel = _get_relative_camera(cams, query_idx=torch.tensor([0]))
+    mine = syn.gso_rig()
+    from mvdfusion_amd.cameras import get_relative_camera
+    mrel = get_relative_camera(mine, [0])
+    assert rel_err(mine.R, R) < 1e-6 and rel_err(mine.T, T) < 1e-6
+    assert rel_err(mrel.R, rel.R) < 1e-6 and rel_err(mrel.T, rel.T) < 1e-6
+    g = torch.Generator().manual_seed(3)
+    pts = torch.randn(1, 64, 3, generator=g) * 0.3
+    ndc = rel.transform_points_ndc(pts)
+    o_ndc = O.project_ndc(rel.R, rel.T, rel.focal_length, rel.principal_point, pts[0])
+    assert rel_err(o_ndc, ndc) < 1e-5
+    xy_d = torch.cat([torch.rand(16, 64, 2, generator=g) * 2 - 1, torch.rand(16, 64, 1, generator=g) * 2 + 0.5], -1)
+    unp = rel.unproject_points(xy_d, from_ndc=True)
+    o_unp = O.unproject_ndc(rel.R, rel.T, rel.focal_length, rel.principal_point, xy_d[..., :2], xy_d[..., 2])
+    assert rel_err(o_unp, unp) < 1e-5
+    assert rel_err(O.camera_center(rel.R, rel.T), rel.get_camera_center()) < 1e-6
+    save("cameras", R=R, T=T, rel_R=rel.R, rel_T=rel.T, pts=pts[0], ndc=ndc, xy_d=xy_d, unproj=unp,
+         centers=rel.get_camera_center())
+    print("  cameras: rig / re-basing / project / unproject agree with the reference call sites")
+
+
+def _gridattn_case(V, D, S, seed, t_val):
+    from mvdfusion.view_attn_efficient2 import GridAttn
+    from mvdfusion.scheduler import DDPMScheduler
+    ga = GridAttn(in_channels=5, input_size=S, output_dim=768, num_layers=3, z_near_far_scale=0.8, n_pts_per_ray=D)
+    fill_ref(ga, "view_attn.")
+    ga.eval()
+    sd = sd_of(ga, "view_attn.")
+    inp = syn.make_inputs(V, S, seed)
+    g = torch.Generator().manual_seed(100 + seed)
+    x = torch.randn(V, 5, S, S, generator=g)
+    t_embed = torch.randn(V, 256, generator=g) * 0.5
+    t = torch.full((V,), t_val, dtype=torch.long)
+    sched = DDPMScheduler(1000)
+    torch.manual_seed(4242 + seed)
+    with torch.no_grad():
+        ref = ga(x, ref_cams(inp["batch_cameras"]), torch.ones(V), t_embed, t, sched,
+                 input_latents=inp["input_latents"], input_cameras=ref_cams(inp["input_cameras"]))
+    torch.manual_seed(4242 + seed)
+    depth_noise = torch.randn(V, D, S, S)
+    tab = O.ddpm_tables()
+    with torch.no_grad():
+        mine = O.gridattn_forward(sd, "view_attn.", x, cam_dict(inp["batch_cameras"]), t_embed, t, tab, depth_noise,
+                                  inp["input_latents"], cam_dict(inp["input_cameras"]), n_pts_per_ray=D)
+        tokens = O.gridattn_forward(sd, "view_attn.", x, cam_dict(inp["batch_cameras"]), t_embed, t, tab, depth_noise,
+                                    inp["input_latents"], cam_dict(inp["input_cameras"]), n_pts_per_ray=D,
+                                    return_tokens=True)
+    e = rel_err(mine, ref)
+    print(f"  gridattn V={V} D={D} S={S} t={t_val}: oracle vs reference rel-max err {e:.2e}")
+    assert e < 2e-5, e
+    return dict(x=x, t_embed=t_embed, t=t, depth_noise=depth_noise, out=ref, seed=np.int64(seed),
+                tokens_sample=tokens[::97][:, :, :].contiguous(), tokens_stride=np.int64(97))
+
+
+def gold_gridattn():
+    c = _gridattn_case(4, 1, 32, 0, 981)
+    # keep the fixture small: fp16-free, but subsample the (V,S,S,D,768) output on a strided lattice + full stats
+    out = c.pop("out")
+    save("gridattn_v4_d1", out_full_view0=out[0, ::2, ::2], out_strided=out[:, ::5, ::7, :, ::3],
+         out_mean=out.mean(), out_std=out.std(), out_l2=out.norm(), **c)
+    c = _gridattn_case(3, 3, 32, 1, 501)
+    out = c.pop("out")
+    save("gridattn_v3_d3", out_strided=out[:, ::5, ::7, :, ::3], out_mean=out.mean(), out_std=out.std(),
+         out_l2=out.norm(), **c)
+    c = _gridattn_case(8, 1, 32, 2, 21)
+    out = c.pop("out")
+    c.pop("tokens_sample")
+    save("gridattn_v8_d1", out_strided=out[:, ::5, ::7, :, ::3], out_mean=out.mean(), out_std=out.std(),
+         out_l2=out.norm(), **c)
+
+
+def _unet(model_channels):
+    from mvdfusion.unet import UNetModel
+    p = dict(UNET_PARAMS)
+    p["model_channels"] = model_channels
+    net = UNetModel(**p)
+    fill_ref(net, "unet_model.unet_model.")
+    net.eval()
+    return net
+
+
+def _unet_inputs(V, D, S, seed):
+    g = torch.Generator().manual_seed(200 + seed)
+    x = torch.randn(V, 10, S, S, generator=g)
+    ctx = torch.randn(V, 1, 768, generator=g)
+    vol = torch.randn(V, S, S, D, 768, generator=g) * 0.5
+    return x, ctx, vol
+
+
+def gold_unet(model_channels, V, D, tag, t_val=981, S=32):
+    from mvdfusion.unet import UNetWrapper
+    net = _unet(model_channels)
+    sd = sd_of(net, "unet_model.unet_model.")
+    x, ctx, vol = _unet_inputs(V, D, S, model_channels + V + D)
+    t1 = torch.tensor([t_val], dtype=torch.long)
+    levels = UNetWrapper.get_volume_feats_pyramid(type("W", (), {"unet_model": net})(), vol)
+    t0 = time.time()
+    with torch.no_grad():
+        ref = net(x, t1, ctx, volume_feats=levels)
+    dt = time.time() - t0
+    with torch.no_grad():
+        mine = O.unet_forward(sd, "unet_model.unet_model.", x, t1, ctx, O.volume_pyramid(vol),
+                              model_channels=model_channels)
+    e = rel_err(mine, ref)
+    print(f"  unet mc={model_channels} V={V} D={D}: ref {dt:.1f}s, oracle vs reference rel-max err {e:.2e}, "
+          f"out std {float(ref.std()):.3f}")
+    assert e < 2e-5, e
+    save(tag, x=x, ctx=ctx, vol_seed=np.int64(model_channels + V + D), t=t1, out=ref,
+         spec=json.dumps([[k, list(v.shape)] for k, v in net.state_dict().items()]))
+    return net
+
+
+def gold_step(model_channels, V, D, tag, indices=(49, 1, 0), S=32):
+    """One DDIMSampler.denoise_apply through a ViewFusion-shaped stand-in (no VAE / CLIP: not on the path)."""
+    import torch.nn as nn
+    from mvdfusion.view_attn_efficient2 import GridAttn
+    from mvdfusion.scheduler import DDPMScheduler
+    from mvdfusion.sampler import DDIMSampler
+    from mvdfusion.unet import UNetWrapper
+    from mvdfusion.viewfusion_zero_depth_rgb import ViewFusion
+
+    class Facade(nn.Module):
+        """The exact ViewFusion members that apply_model touches (viewfusion_zero_depth_rgb.py:282-345)."""
+        embed_time = ViewFusion.embed_time
+        apply_model = ViewFusion.apply_model
+
+        def __init__(self):
+            super().__init__()
+            self.view_attn = GridAttn(in_channels=5, input_size=S, output_dim=768, num_layers=3,
+                                      z_near_far_scale=0.8, n_pts_per_ray=D)
+            w = UNetWrapper.__new__(UNetWrapper)
+            nn.Module.__init__(w)
+            w.unet_model = _unet(model_channels)
+            w.drop_conditions, w.use_zero_123 = False, True
+            self.unet_model = w
+            self.scheduler = DDPMScheduler(1000)
+            self.cc_projection = nn.Sequential(nn.Linear(796, 768), nn.SiLU(True), nn.Linear(768, 768),
+                                               nn.SiLU(True), nn.Linear(768, 768))
+            self.time_embed_dim = 256
+            self.time_embed = nn.Sequential(nn.Linear(256, 256), nn.SiLU(True), nn.Linear(256, 256))
+            self.register_buffer("_device", torch.tensor([0.0]), persistent=False)
+
+    m = Facade()
+    for name in ("view_attn", "cc_projection", "time_embed"):
+        fill_ref(getattr(m, name), name + ".")
+    m.eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sampler = DDIMSampler(m, ddim_num_steps=50, ddim_discretize="uniform", ddim_eta=1.0, latent_size=S, z_dim=4)
+    inp = syn.make_inputs(V, S, seed=7)
+    tab, dd = O.ddpm_tables(), O.ddim_schedule(O.ddpm_tables())
+    bc, ic = ref_cams(inp["batch_cameras"]), ref_cams(inp["input_cameras"])
+    res = {}
+    x = inp["x_T"]
+    for index in indices:
+        tval = int(dd["timesteps"][index])
+        ts = torch.full((V,), tval, dtype=torch.long)
+        torch.manual_seed(900 + index)
+        t0 = time.time()
+        with torch.no_grad():
+            xp, x0 = sampler.denoise_apply(x, bc, inp["input_latents"], ic, inp["clip_v_embed"], ts, index,
+                                           is_step0=index == 0, cfg_scale=2.5)
+        dt = time.time() - t0
+        torch.manual_seed(900 + index)
+        dn = torch.randn(V, D, S, S)
+        sn = torch.randn(V, 5, S, S) if index > 0 else None
+        with torch.no_grad():
+            oxp, ox0 = O.denoise_step(sd, x, cam_dict(inp["batch_cameras"]), inp["input_latents"],
+                                      cam_dict(inp["input_cameras"]), inp["clip_v_embed"], tab, dd, index, dn, sn,
+                                      cfg_scale=2.5, n_pts_per_ray=D, unet_kw=dict(model_channels=model_channels))
+        e = max(rel_err(oxp, xp), rel_err(ox0, x0))
+        print(f"  step mc={model_channels} V={V} D={D} index={index}: ref {dt:.1f}s, oracle vs reference {e:.2e}")
+        assert e < 5e-5, e
+        res[f"depth_noise_{index}"] = dn
+        res[f"step_noise_{index}"] = sn if sn is not None else torch.zeros(V, 5, S, S)
+        res[f"x_prev_{index}"] = xp
+        res[f"x0_{index}"] = x0
+    save(tag, x=x, indices=np.asarray(indices), **res)
+
+
+def gold_trajectory(model_channels, V, D, tag, steps=5, S=32):
+    """A short stochastic DDIM trajectory (first `steps` iterations of sampler.sample's loop, sampler.py:119-142)."""
+    sd, _ = synth_state_dict(model_channels, D, S)
+    inp = syn.make_inputs(V, S, seed=11)
+    tab, dd = O.ddpm_tables(), O.ddim_schedule(O.ddpm_tables())
+    dn, sn = syn.step_noise(V, S, D, 50, seed=11)
+    x = inp["x_T"]
+    xs = []
+    for i in range(steps):
+        index = 50 - i - 1
+        with torch.no_grad():
+            x, x0 = O.denoise_step(sd, x, cam_dict(inp["batch_cameras"]), inp["input_latents"],
+                                   cam_dict(inp["input_cameras"]), inp["clip_v_embed"], tab, dd, index, dn[i], sn[i],
+                                   cfg_scale=2.5, n_pts_per_ray=D, unet_kw=dict(model_channels=model_channels))
+        xs.append(x)
+    save(tag, xs=torch.stack(xs))
+
+
+def synth_state_dict(model_channels, D, S=32):
+    """The flat state_dict of the hot-path parameters from shapes alone (spec fixture) + det_fill."""
+    spec = json.load(open(os.path.join(GOLD, f"state_dict_spec_mc{model_channels}.json")))
+    return syn.det_fill_state_dict(spec), spec
+
+
+def gold_spec(model_channels):
+    import torch.nn as nn
+    from mvdfusion.view_attn_efficient2 import GridAttn
+    net = _unet(model_channels)
+    ga = GridAttn(in_channels=5, input_size=32, output_dim=768, num_layers=3, z_near_far_scale=0.8, n_pts_per_ray=1)
+    spec = [["view_attn." + k, list(v.shape)] for k, v in ga.state_dict().items()]
+    spec += [["unet_model.unet_model." + k, list(v.shape)] for k, v in net.state_dict().items()]
+    cc = nn.Sequential(nn.Linear(796, 768), nn.SiLU(True), nn.Linear(768, 768), nn.SiLU(True), nn.Linear(768, 768))
+    spec += [["cc_projection." + k, list(v.shape)] for k, v in cc.state_dict().items()]
+    te = nn.Sequential(nn.Linear(256, 256), nn.SiLU(True), nn.Linear(256, 256))
+    spec += [["time_embed." + k, list(v.shape)] for k, v in te.state_dict().items()]
+    os.makedirs(GOLD, exist_ok=True)
+    with open(os.path.join(GOLD, f"state_dict_spec_mc{model_channels}.json"), "w") as f:
+        json.dump(spec, f)
+    print(f"  wrote state_dict_spec_mc{model_channels}.json ({len(spec)} keys, "
+          f"{sum(int(np.prod(s)) for _, s in spec) / 1e6:.1f} M params)")
+
+
+ALL = {
+    "schedule": gold_schedule,
+    "cameras": gold_cameras,
+    "spec32": lambda: gold_spec(32),
+    "spec320": lambda: gold_spec(320),
+    "gridattn": gold_gridattn,
+    "unet32": lambda: gold_unet(32, 4, 1, "unet_mc32_v4_d1"),
+    "unet32_d3": lambda: gold_unet(32, 2, 3, "unet_mc32_v2_d3", t_val=501),
+    "unet64": lambda: gold_unet(64, 2, 1, "unet_mc64_v2_d1", t_val=21),
+    "unet320": lambda: gold_unet(320, 2, 1, "unet_mc320_v2_d1"),
+    "step32": lambda: gold_step(32, 4, 1, "step_mc32_v4_d1"),
+    "step32_d3": lambda: gold_step(32, 2, 3, "step_mc32_v2_d3", indices=(30,)),
+    "step320": lambda: gold_step(320, 4, 1, "step_mc320_v4_d1", indices=(49, 0)),
+    "traj32": lambda: gold_trajectory(32, 4, 1, "traj_mc32_v4_d1", steps=5),
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    for k, fn in ALL.items():
+        if a.only and k not in a.only:
+            continue
+        print(f"[{k}]")
+        fn()
