@@ -159,8 +159,10 @@ int mvd_fill_zero(float* p, size_t n, mvd_stream_t stream);
  *   [0] t  [1] sqrt(alpha_bar_t)  [2] depth_std = sqrt(1-ab)/sqrt(ab)/10  [3] a_t  [4] a_prev  [5] sigma_t
  *   [6] sqrt(1-a_t)  [7] 1 if noise is added at this step (sampler.py:63-65) */
 #define MVD_STEP_STRIDE 8
-/* sinusoidal embedding, cos first (diffusionmodules/util.py:152-172; mvdfusion/embedder.py:114-134): out (dim) */
-int mvd_timestep_embedding(const float* steps, const int* iter, float* out, int dim, mvd_stream_t stream);
+/* sinusoidal embedding, cos first (diffusionmodules/util.py:152-172; mvdfusion/embedder.py:114-134): out (dim).
+ * freqs (dim/2) = exp(-ln(1e4) * i / (dim/2)) is computed once on the host exactly as the reference does. */
+int mvd_timestep_embedding(const float* steps, const int* iter, const float* freqs, float* out, int dim,
+                           mvd_stream_t stream);
 int mvd_advance_iter(int* iter, mvd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -177,8 +179,9 @@ int mvd_zembed(const float* lat, const float* w, const float* b, float* feat, in
  * ((b*S*S + pix)*D + d)*V + v_ref, T = V*S*S*D*V; columns >= 723 are zero.
  * x (V,5,S,S) NCHW noisy latents; depth_noise (nsteps, V, D, S, S) standard normal (host-ordered, trap T2). */
 int mvd_gridattn_tokens(const float* x, const float* depth_noise, const float* steps, const int* iter,
+                        const float* grid_lin /* (S) = linspace(1-1/S, -1+1/S, S), ray_utils.py:263-267 */,
                         const float* feat, const float* in_feat, const float* cams, const float* in_cam,
-                        float* tokens, int V, int S, int D, float depth_scale, float depth_shift,
+                        float* tokens, int V, int q0, int Vq, int S, int D, float depth_scale, float depth_shift,
                         mvd_stream_t stream);
 /* timm Attention core over the V reference views (:52): qkv (Nseq*V, 3*heads*dhead) -> out (Nseq*V, heads*dhead) */
 int mvd_view_mha(const float* qkv, float* out, int Nseq, int V, int heads, int dhead, mvd_stream_t stream);
@@ -191,8 +194,9 @@ int mvd_view_pool(const float* x, const float* w, const float* b, float* out, in
  * eps_nhwc (2V or V, S, S, ldc) UNet head output; x (V,5,S,S) NCHW updated IN PLACE; x0 (V,5,S,S) out.
  * ddim_noise (nsteps, V, 5, S, S).  eps_out (V,5,S,S) NCHW or NULL receives the guided prediction. */
 int mvd_cfg_ddim_update(const float* eps_nhwc, int ldc, float* x, float* x0, float* eps_out,
-                        const float* ddim_noise, const float* steps, const int* iter, int V, int S, int cfg,
-                        float cfg_scale, int do_update, mvd_stream_t stream);
+                        const float* ddim_noise, size_t noise_stride /* floats between consecutive steps */,
+                        const float* steps, const int* iter, int V, int S, int cfg, float cfg_scale, int do_update,
+                        mvd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * hipGraph capture of a whole denoising step and HIP-event timing on the caller's stream. */

@@ -1,0 +1,221 @@
+"""Transformer blocks of the view-conditioned UNet, executed by HIP kernels.
+
+Mirrors (same attribute names => same state_dict keys):
+  * ``CrossAttention``, ``FeedForward``/``GEGLU``, ``BasicTransformerBlock``, ``SpatialTransformer``
+    (external/sd1/ldm/modules/attention.py:37-64, 152-287)
+  * ``DualAttnetionBlock`` [sic], ``ViewAlignedFeatureTransformer`` (mvdfusion/attention.py:16-145)
+
+The nn.Linear / nn.Conv2d / nn.LayerNorm / nn.GroupNorm members only HOLD the fp32 parameters under the reference's
+names; ``run(ctx, x, H, W)`` is the forward pass on channels-last activations (a (B*H*W, C) fp32 matrix):
+
+  GroupNorm -> proj_in GEMM -> LN -> fused QKV GEMM (epilogue writes the split-bf16 attention operands) ->
+  flash attention (MFMA) -> to_out GEMM (+bias +residual [+ per-view cross-attention vector]) -> LN ->
+  GEGLU GEMM (gate fused in the epilogue) -> ff-out GEMM (+residual) -> proj_out GEMM (+residual).
+
+Cross-attention against a length-1 context (the CLIP vector; the D==1 depth sample) is softmax over one key == 1, so
+it reduces exactly to to_out(to_v(ctx)); to_q / to_k / norm2 are dead there and are skipped.
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+
+
+def _normalize(c):
+    return nn.GroupNorm(num_groups=32, num_channels=c, eps=1e-6, affine=True)
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner = dim_head * heads
+        context_dim = query_dim if context_dim is None else context_dim
+        self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+        self._p = {}
+
+    def packed(self, key):
+        """Lazily packed MFMA operand images: 'qkv' (fused), 'q', 'k', 'v', 'out'."""
+        if key not in self._p:
+            if key == "qkv":
+                self._p[key] = hip.pack_linear_cat([self.to_q.weight, self.to_k.weight, self.to_v.weight])
+            elif key == "out":
+                self._p[key] = hip.pack_linear(self.to_out[0].weight, self.to_out[0].bias)
+            else:
+                self._p[key] = hip.pack_linear(getattr(self, "to_" + key).weight)
+        return self._p[key]
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4, dropout=0.0):
+        super().__init__()
+        inner = int(dim * mult)
+        self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim))
+        self._p = None
+
+    def packed(self):
+        if self._p is None:
+            self._p = (hip.pack_linear(self.net[0].proj.weight, self.net[0].proj.bias, geglu=True),
+                       hip.pack_linear(self.net[2].weight, self.net[2].bias))
+        return self._p
+
+
+class _TransformerCore(nn.Module):
+    """attn1 / attn2 / ff / norm1-3 holder shared by BasicTransformerBlock and DualAttnetionBlock."""
+
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None):
+        super().__init__()
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout, context_dim=None)
+        self.ff = FeedForward(dim, dropout=dropout)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head,
+                                    dropout=dropout)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.dim, self.n_heads, self.d_head = dim, n_heads, d_head
+
+    def self_attn(self, ctx, t, B, L, tag):
+        """returns t + attn1(norm1(t)) pieces: the attention output `o` (pre to_out)."""
+        C, M = self.dim, B * L
+        ln = ctx.ws.get(tag + ".ln", (M, C))
+        ctx.layernorm(t, ln, self.norm1, M, C)
+        planes = ctx.ws.attn_planes(B, self.n_heads, L, self.d_head)
+        ctx.gemm(ln, self.attn1.packed("qkv"), None, epi=hip.EPI_QKV,
+                 qkv=dict(planes=planes, heads=self.n_heads, dhead=self.d_head, L=L))
+        o = ctx.ws.get(tag + ".o", (M, C))
+        hip.attention(planes, o, B, self.n_heads, L, self.d_head, prec=ctx.prec)
+        return o
+
+    def feed_forward(self, ctx, t2, M, tag):
+        C = self.dim
+        ln = ctx.ws.get(tag + ".ln", (M, C))
+        ctx.layernorm(t2, ln, self.norm3, M, C)
+        w1, w2 = self.ff.packed()
+        g = ctx.ws.get(tag + ".g", (M, 4 * C))
+        ctx.gemm(ln, w1, g, epi=hip.EPI_GEGLU)
+        t3 = ctx.ws.get(tag + ".t3", (M, C))
+        ctx.gemm(g, w2, t3, res=t2)
+        return t3
+
+
+class BasicTransformerBlock(_TransformerCore):
+    pass
+
+
+class DualAttnetionBlock(_TransformerCore):
+    pass
+
+
+class SpatialTransformer(nn.Module):
+    """external/sd1/ldm/modules/attention.py:225-287 (use_linear=False: proj_in/out are 1x1 convs)."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None):
+        super().__init__()
+        assert depth == 1
+        inner = n_heads * d_head
+        self.in_channels = in_channels
+        self.norm = _normalize(in_channels)
+        self.proj_in = nn.Conv2d(in_channels, inner, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, dropout, context_dim)])
+        self.proj_out = nn.Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0)
+        self._p = None
+
+    def packed(self):
+        if self._p is None:
+            self._p = (hip.pack_linear(self.proj_in.weight, self.proj_in.bias),
+                       hip.pack_linear(self.proj_out.weight, self.proj_out.bias))
+        return self._p
+
+    def run(self, ctx, x, H, W, out=None):
+        B, C, L = ctx.B, self.in_channels, H * W
+        M = B * L
+        tb = self.transformer_blocks[0]
+        w_in, w_out = self.packed()
+        n = ctx.ws.get("tf.n", (M, C))
+        ctx.groupnorm(x, n, self.norm, B, L, C, silu=False)
+        t = ctx.ws.get("tf.t", (M, C))
+        ctx.gemm(n, w_in, t)
+        o = tb.self_attn(ctx, t, B, L, "tf")
+        # attn2 on the length-1 CLIP context: per-view vector to_out(to_v(ctx_b)), broadcast over the pixels
+        a2 = tb.attn2
+        v1 = ctx.ws.get("tf.v1", (B, C))
+        ctx.gemv_rows(a2.to_v.weight, None, ctx.context, v1)
+        vec = ctx.ws.get("tf.vec", (B, C))
+        ctx.gemv_rows(a2.to_out[0].weight, a2.to_out[0].bias, v1, vec)
+        t2 = ctx.ws.get("tf.t2", (M, C))
+        ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L)
+        t3 = tb.feed_forward(ctx, t2, M, "tf")
+        if out is None:
+            out = ctx.act((M, C))
+        ctx.gemm(t3, w_out, out, res=x)
+        return out
+
+
+class ViewAlignedFeatureTransformer(nn.Module):
+    """mvdfusion/attention.py:72-145 (use_linear=True).  Parameters are prefixed ``aligned_attn_``."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None, image_size=None):
+        super().__init__()
+        assert depth == 1
+        inner = n_heads * d_head
+        self.in_channels, self.image_size = in_channels, image_size
+        self.aligned_attn_norm = _normalize(in_channels)
+        self.aligned_attn_proj_in = nn.Linear(in_channels, inner)
+        self.aligned_attn_transformer_blocks = nn.ModuleList(
+            [DualAttnetionBlock(inner, n_heads, d_head, dropout, context_dim)])
+        self.aligned_attn_proj_out = nn.Linear(in_channels, inner)
+        self.level_mapper = {image_size: 0, image_size // 2: 1, image_size // 4: 2, image_size // 8: 3}
+        self._p = None
+
+    def packed(self):
+        if self._p is None:
+            self._p = (hip.pack_linear(self.aligned_attn_proj_in.weight, self.aligned_attn_proj_in.bias),
+                       hip.pack_linear(self.aligned_attn_proj_out.weight, self.aligned_attn_proj_out.bias))
+        return self._p
+
+    def run(self, ctx, x, H, W, out=None):
+        B, C, L, D = ctx.B, self.in_channels, H * W, ctx.D
+        M = B * L
+        tb = self.aligned_attn_transformer_blocks[0]
+        w_in, w_out = self.packed()
+        vol = ctx.vol_levels[self.level_mapper[H]]            # (M*D, 768): this view's own depth samples
+        n = ctx.ws.get("tf.n", (M, C))
+        ctx.groupnorm(x, n, self.aligned_attn_norm, B, L, C, silu=False)
+        t = ctx.ws.get("tf.t", (M, C))
+        ctx.gemm(n, w_in, t)
+        o = tb.self_attn(ctx, t, B, L, "tf")
+        t2 = ctx.ws.get("tf.t2", (M, C))
+        ctx.gemm(o, tb.attn1.packed("out"), t2, res=t)
+        a2 = tb.attn2.packed
+        t2b = ctx.ws.get("tf.t2b", (M, C))
+        if D == 1:
+            vv = ctx.ws.get("tf.vv", (M, C))
+            ctx.gemm(vol, a2("v"), vv)
+            ctx.gemm(vv, a2("out"), t2b, res=t2)
+        else:
+            ln2 = ctx.ws.get("tf.ln", (M, C))
+            ctx.layernorm(t2, ln2, tb.norm2, M, C)
+            q = ctx.ws.get("tf.q2", (M, C))
+            ctx.gemm(ln2, a2("q"), q)
+            k = ctx.ws.get("tf.k2", (M * D, C))
+            v = ctx.ws.get("tf.v2", (M * D, C))
+            ctx.gemm(vol, a2("k"), k)
+            ctx.gemm(vol, a2("v"), v)
+            o2 = ctx.ws.get("tf.o2", (M, C))
+            hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o2), M, D,
+                                                     tb.n_heads, tb.d_head, hip.stream()))
+            ctx.gemm(o2, a2("out"), t2b, res=t2)
+        t3 = tb.feed_forward(ctx, t2b, M, "tf")
+        if out is None:
+            out = ctx.act((M, C))
+        ctx.gemm(t3, w_out, out, res=x)
+        return out

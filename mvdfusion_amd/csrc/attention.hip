@@ -1,0 +1,333 @@
+// Attention kernels.
+//  * attn_kernel      : flash-style self-attention over the tokens of one view on bf16 MFMA (16x16x32), operands are
+//                       the pre-split bf16 planes written by the QKV GEMM epilogue (gemm.hip, MVD_EPI_QKV).
+//                       Computes S^T = K Q^T so that every lane owns ONE query column: the online-softmax row
+//                       statistics need only two cross-lane shuffles, and P^T feeds the PV MFMA's B operand straight
+//                       from registers (the MFMA k-slot order is permuted identically on the V^T side).
+//  * pixel_xattn_kernel : 1 query x D context tokens per pixel (DualAttnetionBlock attn2), VALU.
+//  * view_mha_kernel  : timm Attention core over the V reference views of GridAttn (sequence length V <= 16), VALU.
+//  * view_pool_kernel : weight_layer + softmax over V + weighted sum.
+#include "common.hpp"
+#include "../../include/mvd_hip.h"
+
+namespace {
+
+constexpr int KV_TILE = 64;
+
+template <int DQ, int DV, int NS>
+__global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
+                                                   const u16* __restrict__ k_hi, const u16* __restrict__ k_lo,
+                                                   const u16* __restrict__ vt_hi, const u16* __restrict__ vt_lo,
+                                                   float* __restrict__ out, int ldo, int H, int L, int Lpad, int dhead) {
+  constexpr int NPL = NS == 3 ? 2 : 1;
+  constexpr int KP = DQ + 8;       // LDS pitch of a K row (bf16 elements)
+  constexpr int VP = KV_TILE + 8;  // LDS pitch of a V^T row
+  constexpr int QS = DQ / 32;      // MFMA k-steps over the head dim
+  constexpr int DT = DV / 16;      // output d-tiles
+  __shared__ __attribute__((aligned(16))) u16 sK[NPL][KV_TILE][KP];
+  __shared__ __attribute__((aligned(16))) u16 sV[NPL][DV][VP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bool active = q0 < L;
+  const size_t bh = (size_t)b * H + h;
+  const u16* kp[2] = {k_hi + bh * Lpad * DQ, k_lo + bh * Lpad * DQ};
+  const u16* vp[2] = {vt_hi + bh * DV * Lpad, vt_lo + bh * DV * Lpad};
+
+  bf16x8 qh[QS], ql[QS];
+  {
+    const size_t qoff = (bh * Lpad + q0 + c) * DQ + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < QS; ++ks) {
+      qh[ks] = *(const bf16x8*)(q_hi + qoff + ks * 32);
+      if (NS == 3) ql[ks] = *(const bf16x8*)(q_lo + qoff + ks * 32);
+    }
+  }
+  f32x4 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (L + KV_TILE - 1) / KV_TILE;
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * KV_TILE;
+    __syncthreads();
+    // ---- stage K tile (contiguous 64*DQ bf16 per plane) and V^T tile (DV rows x 64 keys) into LDS
+    constexpr int KCH = KV_TILE * DQ / 8;
+    constexpr int VCH = DV * 8;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      for (int ch = tid; ch < KCH; ch += 256) {
+        const int row = ch / (DQ / 8), kc = ch - row * (DQ / 8);
+        *(uint4*)&sK[pl][row][kc * 8] = *(const uint4*)(kp[pl] + ((size_t)(kv0 + row)) * DQ + kc * 8);
+      }
+      for (int ch = tid; ch < VCH; ch += 256) {
+        const int row = ch >> 3, kc = ch & 7;
+        *(uint4*)&sV[pl][row][kc * 8] = *(const uint4*)(vp[pl] + (size_t)row * Lpad + kv0 + kc * 8);
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+
+    // ---- S^T = K Q^T : s[kt][r] = S[q = c][key = kv0 + kt*16 + g*4 + r]
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < QS; ++ks) {
+        const bf16x8 kh = *(const bf16x8*)&sK[0][kt * 16 + c][ks * 32 + g * 8];
+        if (NS == 3) {
+          const bf16x8 kl = *(const bf16x8*)&sK[NPL - 1][kt * 16 + c][ks * 32 + g * 8];
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], s[kt], 0, 0, 0);
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], s[kt], 0, 0, 0);
+        }
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], s[kt], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (per query column c; keys are spread over registers and the 4 lane groups)
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kv0 + kt * 16 + g * 4 + r;
+        if (key >= L) s[kt][r] = -INFINITY;
+        mt = fmaxf(mt, s[kt][r]);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kt][r] = __expf(s[kt][r] - m_new);
+        psum += s[kt][r];
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] *= alpha;
+    // ---- P^T as MFMA B operand: k-slot (g, j): j<4 -> key 32u + 4g + j ; j>=4 -> key 32u + 16 + 4g + (j-4)
+    bf16x8 ph[2], pl2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      union { bf16x8 v; u16 e[8]; } H8, L8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float pv = j < 4 ? s[2 * u][j] : s[2 * u + 1][j - 4];
+        if (NS == 3) {
+          split_bf16(pv, H8.e[j], L8.e[j]);
+        } else {
+          H8.e[j] = f32_to_bf16_rne(pv);
+        }
+      }
+      ph[u] = H8.v;
+      if (NS == 3) pl2[u] = L8.v;
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        union { bf16x8 v; uint2 h2[2]; } VH, VL;
+        VH.h2[0] = *(const uint2*)&sV[0][dt * 16 + c][32 * u + 4 * g];
+        VH.h2[1] = *(const uint2*)&sV[0][dt * 16 + c][32 * u + 16 + 4 * g];
+        if (NS == 3) {
+          VL.h2[0] = *(const uint2*)&sV[NPL - 1][dt * 16 + c][32 * u + 4 * g];
+          VL.h2[1] = *(const uint2*)&sV[NPL - 1][dt * 16 + c][32 * u + 16 + 4 * g];
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VL.v, ph[u], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VH.v, pl2[u], o[dt], 0, 0, 0);
+        }
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VH.v, ph[u], o[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + c;
+  if (q < L) {
+    float* orow = out + ((size_t)b * L + q) * ldo + h * dhead;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d0 = dt * 16 + g * 4;
+      if (d0 < dhead) *(float4*)(orow + d0) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+  }
+}
+
+// one wave per pixel; lanes stride over channels of a head. q (P,C), k/v (P*D, C), D <= 8.
+__global__ __launch_bounds__(256) void pixel_xattn_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, float* __restrict__ out, int P, int D,
+                                                          int heads, int dhead) {
+  const int lane = threadIdx.x & 63;
+  const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= P) return;
+  const int C = heads * dhead;
+  const float scale = rsqrtf((float)dhead);
+  for (int h = 0; h < heads; ++h) {
+    float sc[8];
+    for (int j = 0; j < D; ++j) {
+      float part = 0.f;
+      for (int e = lane; e < dhead; e += 64)
+        part += q[(size_t)pix * C + h * dhead + e] * k[((size_t)pix * D + j) * C + h * dhead + e];
+      sc[j] = wave_sum(part) * scale;
+    }
+    float mx = sc[0];
+    for (int j = 1; j < D; ++j) mx = fmaxf(mx, sc[j]);
+    float den = 0.f;
+    for (int j = 0; j < D; ++j) {
+      sc[j] = expf(sc[j] - mx);
+      den += sc[j];
+    }
+    for (int e = lane; e < dhead; e += 64) {
+      float acc = 0.f;
+      for (int j = 0; j < D; ++j) acc += (sc[j] / den) * v[((size_t)pix * D + j) * C + h * dhead + e];
+      out[(size_t)pix * C + h * dhead + e] = acc;
+    }
+  }
+}
+
+// one thread per (sequence, head, query view); qkv row layout [3][heads][dhead] (timm reshape B,N,3,H,hd).
+__global__ __launch_bounds__(256) void view_mha_kernel(const float* __restrict__ qkv, float* __restrict__ out, int Nseq, int V,
+                                                       int heads, int dhead) {
+  const size_t total = (size_t)Nseq * heads * V;
+  const int C = heads * dhead;
+  const float scale = rsqrtf((float)dhead);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int vq = (int)(e % V);
+    const int h = (int)((e / V) % heads);
+    const size_t n = e / ((size_t)V * heads);
+    const float* qrow = qkv + (n * V + vq) * 3 * C + h * dhead;
+    float sc[16];
+    float mx = -INFINITY;
+    for (int j = 0; j < V; ++j) {
+      const float* krow = qkv + (n * V + j) * 3 * C + C + h * dhead;
+      float a = 0.f;
+      for (int d = 0; d < dhead; ++d) a += (qrow[d] * scale) * krow[d];
+      sc[j] = a;
+      mx = fmaxf(mx, a);
+    }
+    float den = 0.f;
+    for (int j = 0; j < V; ++j) {
+      sc[j] = expf(sc[j] - mx);
+      den += sc[j];
+    }
+    float* orow = out + (n * V + vq) * C + h * dhead;
+    for (int d = 0; d < dhead; ++d) {
+      float a = 0.f;
+      for (int j = 0; j < V; ++j) a += (sc[j] / den) * qkv[(n * V + j) * 3 * C + 2 * C + h * dhead + d];
+      orow[d] = a;
+    }
+  }
+}
+
+// one wave per sequence: logits w.x_v + b, softmax over V, out = sum_v p_v x_v.  C % 64 == 0, C <= 512.
+__global__ __launch_bounds__(256) void view_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int Nseq, int V,
+                                                        int C) {
+  const int lane = threadIdx.x & 63;
+  const size_t n = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= (size_t)Nseq) return;
+  float lg[16];
+  float mx = -INFINITY;
+  for (int v = 0; v < V; ++v) {
+    float part = 0.f;
+    for (int e = lane; e < C; e += 64) part += x[(n * V + v) * C + e] * w[e];
+    lg[v] = wave_sum(part) + bias[0];
+    mx = fmaxf(mx, lg[v]);
+  }
+  float den = 0.f;
+  for (int v = 0; v < V; ++v) {
+    lg[v] = expf(lg[v] - mx);
+    den += lg[v];
+  }
+  for (int e = lane; e < C; e += 64) {
+    float a = 0.f;
+    for (int v = 0; v < V; ++v) a += x[(n * V + v) * C + e] * (lg[v] / den);
+    out[n * C + e] = a;
+  }
+}
+
+template <int NS>
+int launch_attn(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi, const void* vt_lo,
+                float* out, int ldo, int B, int H, int L, int Lpad, int dhead, hipStream_t s) {
+  const int dq = (dhead + 31) & ~31, dv = (dhead + 15) & ~15;
+  dim3 grid(Lpad / 64, H, B), block(256);
+#define MVD_ATTN_CASE(DQ, DV)                                                                                          \
+  if (dq == DQ && dv == DV) {                                                                                          \
+    hipLaunchKernelGGL((attn_kernel<DQ, DV, NS>), grid, block, 0, s, (const u16*)q_hi, (const u16*)q_lo,               \
+                       (const u16*)k_hi, (const u16*)k_lo, (const u16*)vt_hi, (const u16*)vt_lo, out, ldo, H, L, Lpad, \
+                       dhead);                                                                                         \
+    return 0;                                                                                                          \
+  }
+  MVD_ATTN_CASE(32, 16)
+  MVD_ATTN_CASE(32, 32)
+  MVD_ATTN_CASE(64, 48)
+  MVD_ATTN_CASE(64, 64)
+  MVD_ATTN_CASE(96, 80)
+  MVD_ATTN_CASE(160, 160)
+#undef MVD_ATTN_CASE
+  return -1;
+}
+
+}  // namespace
+
+extern "C" int mvd_attn_lpad(int L) { return (L + 63) & ~63; }
+extern "C" size_t mvd_attn_qk_plane_elems(int B, int heads, int L, int dhead) {
+  return (size_t)B * heads * mvd_attn_lpad(L) * ((dhead + 31) & ~31);
+}
+extern "C" size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead) {
+  return (size_t)B * heads * mvd_attn_lpad(L) * ((dhead + 15) & ~15);
+}
+
+extern "C" int mvd_attention(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                             const void* vt_lo, float* out, int ldo, int B, int heads, int L, int dhead, int prec,
+                             mvd_stream_t stream) {
+  MVD_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out, "mvd_attention: null pointer");
+  MVD_CHECK_ARG(B > 0 && heads > 0 && L > 0 && dhead > 0 && dhead % 4 == 0, "mvd_attention: bad shape (dhead %% 4 == 0)");
+  MVD_CHECK_ARG(ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, "mvd_attention: out must be 16-byte aligned, ldo %% 4 == 0");
+  MVD_CHECK_ARG(prec == MVD_PREC_BF16 || prec == MVD_PREC_BF16X3, "mvd_attention: bad prec");
+  const int Lpad = mvd_attn_lpad(L);
+  int rc;
+  if (prec == MVD_PREC_BF16X3)
+    rc = launch_attn<3>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+  else
+    rc = launch_attn<1>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+  MVD_CHECK_ARG(rc == 0, "mvd_attention: unsupported head dim %d (supported: <=32, 33..64, 65..96 with dv 80, 160)", dhead);
+  MVD_CHECK_LAUNCH("mvd_attention");
+  return 0;
+}
+
+extern "C" int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, float* out, int P, int D, int heads,
+                                    int dhead, mvd_stream_t stream) {
+  MVD_CHECK_ARG(q && k && v && out && P > 0 && D > 0 && D <= 8 && heads > 0 && dhead > 0, "mvd_pixel_cross_attn: bad arguments (D <= 8)");
+  hipLaunchKernelGGL(pixel_xattn_kernel, dim3(cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, out, P, D, heads, dhead);
+  MVD_CHECK_LAUNCH("mvd_pixel_cross_attn");
+  return 0;
+}
+
+extern "C" int mvd_view_mha(const float* qkv, float* out, int Nseq, int V, int heads, int dhead, mvd_stream_t stream) {
+  MVD_CHECK_ARG(qkv && out && Nseq > 0 && V > 0 && V <= 16 && heads > 0 && dhead > 0, "mvd_view_mha: bad arguments (V <= 16)");
+  const size_t total = (size_t)Nseq * heads * V;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(view_mha_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, out, Nseq, V, heads, dhead);
+  MVD_CHECK_LAUNCH("mvd_view_mha");
+  return 0;
+}
+
+extern "C" int mvd_view_pool(const float* x, const float* w, const float* b, float* out, int Nseq, int V, int C,
+                             mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && w && b && out && Nseq > 0 && V > 0 && V <= 16 && C > 0, "mvd_view_pool: bad arguments (V <= 16)");
+  hipLaunchKernelGGL(view_pool_kernel, dim3(cdiv(Nseq, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, out, Nseq, V, C);
+  MVD_CHECK_LAUNCH("mvd_view_pool");
+  return 0;
+}

@@ -1,0 +1,263 @@
+// Small HBM/latency-bound kernels: fp32 GEMV (M <= 16), layout conversion, concat, area pooling, per-step scalars,
+// CFG combine + DDIM update.  All exact fp32 VALU math.
+#include "common.hpp"
+#include "../../include/mvd_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == MVD_ACT_GELU) return gelu_erf(v);
+  if (act == MVD_ACT_SILU) return silu_f(v);
+  return v;
+}
+
+// one wave per output feature n; lanes stride over K (float4); up to 16 rows of x share one sweep of W.
+template <int MR>
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                   const float* __restrict__ x, float* __restrict__ y, int M, int N, int K, int ldx,
+                                                   int ldy, int act_in, int act_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  const float* wr = W + (size_t)n * K;
+  if ((K & 3) == 0) {
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 w4 = *(const float4*)(wr + k);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        if (m < M) {
+          float4 x4 = *(const float4*)(x + (size_t)m * ldx + k);
+          if (act_in) {
+            x4.x = act_apply(x4.x, act_in);
+            x4.y = act_apply(x4.y, act_in);
+            x4.z = act_apply(x4.z, act_in);
+            x4.w = act_apply(x4.w, act_in);
+          }
+          acc[m] += w4.x * x4.x + w4.y * x4.y + w4.z * x4.z + w4.w * x4.w;
+        }
+      }
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) {
+      const float w1 = wr[k];
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+        if (m < M) acc[m] += w1 * act_apply(x[(size_t)m * ldx + k], act_in);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    if (m < M) {
+      float v = wave_sum(acc[m]);
+      if (lane == 0) {
+        if (bias) v += bias[n];
+        y[(size_t)m * ldy + n] = act_apply(v, act_out);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict__ x, const float* __restrict__ il,
+                                                         float* __restrict__ out, int V, int S, int cpad, int nb) {
+  const int SS = S * S;
+  const size_t total = (size_t)nb * SS * cpad;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % cpad);
+    const int pix = (int)((e / cpad) % SS);
+    const int b = (int)(e / ((size_t)cpad * SS));
+    const int v = b < V ? b : b - V;
+    float o = 0.f;
+    if (c < 5) {
+      o = x[((size_t)v * 5 + c) * SS + pix];
+    } else if (c < 10 && b < V) {
+      const float t = il[(size_t)(c - 5) * SS + pix];
+      o = (c < 9) ? t / 0.18215f : t;
+    }
+    out[e] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ a, int ca4, const float4* __restrict__ b, int cb4,
+                                                     float4* __restrict__ out, size_t rows) {
+  const int c4 = ca4 + cb4;
+  const size_t total = rows * c4;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t r = e / c4;
+    const int c = (int)(e - r * c4);
+    out[e] = c < ca4 ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
+  }
+}
+
+// vol (B,S,S,D,C) -> out (B,S/f,S/f,D,C), mean over f x f windows (F.interpolate(mode='area') with integer ratio)
+__global__ __launch_bounds__(256) void area_pool_kernel(const float4* __restrict__ vol, float4* __restrict__ out, int B, int S, int D,
+                                                        int C4, int f) {
+  const int So = S / f;
+  const size_t total = (size_t)B * So * So * D * C4;
+  const float inv = 1.0f / (float)(f * f);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C4);
+    size_t r = e / C4;
+    const int d = (int)(r % D);
+    r /= D;
+    const int ox = (int)(r % So);
+    r /= So;
+    const int oy = (int)(r % So);
+    const int b = (int)(r / So);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) {
+        const float4 v = vol[((((size_t)b * S + oy * f + dy) * S + ox * f + dx) * D + d) * C4 + c];
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+      }
+    out[e] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_zero_kernel(float* p, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) p[e] = 0.f;
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ steps, const int* __restrict__ iter,
+                                          const float* __restrict__ freqs, float* __restrict__ out, int dim) {
+  const float t = steps[(size_t)iter[0] * MVD_STEP_STRIDE + 0];
+  const int half = dim / 2;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float a = t * freqs[i];
+    out[i] = cosf(a);
+    out[half + i] = sinf(a);
+  }
+}
+
+__global__ void advance_iter_kernel(int* iter) {
+  if (threadIdx.x == 0) iter[0] += 1;
+}
+
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__ eps_nhwc, int ldc, float* __restrict__ x,
+                                                       float* __restrict__ x0, float* __restrict__ eps_out,
+                                                       const float* __restrict__ noise, const float* __restrict__ steps,
+                                                       const int* __restrict__ iter, int V, int S, int cfg, float cfg_scale,
+                                                       int do_update, size_t noise_stride) {
+  const int it = iter[0];
+  const float* st = steps + (size_t)it * MVD_STEP_STRIDE;
+  const float a_t = st[3], a_prev = st[4], sigma = st[5], s1m = st[6], has_noise = st[7];
+  const int SS = S * S;
+  const size_t total = (size_t)V * 5 * SS;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int pix = (int)(e % SS);
+    const int c = (int)((e / SS) % 5);
+    const int b = (int)(e / ((size_t)5 * SS));
+    float ep = eps_nhwc[((size_t)b * SS + pix) * ldc + c];
+    if (cfg) {
+      const float eu = eps_nhwc[((size_t)(V + b) * SS + pix) * ldc + c];
+      ep = eu + cfg_scale * (ep - eu);
+    }
+    if (eps_out) eps_out[e] = ep;
+    if (do_update) {
+      const float xv = x[e];
+      const float px0 = (xv - s1m * ep) / sqrtf(a_t);
+      const float dir = sqrtf(fmaxf(1.0f - a_prev - sigma * sigma, 1e-7f)) * ep;
+      float xp = sqrtf(a_prev) * px0 + dir;
+      if (has_noise != 0.f) xp = xp + sigma * noise[(size_t)it * noise_stride + e];
+      x0[e] = px0;
+      x[e] = xp;
+    }
+  }
+}
+
+inline int grid_for(size_t total, int cap = 2048) {
+  size_t b = (total + 255) / 256;
+  if (b > (size_t)cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int mvd_gemv(const float* W, const float* bias, const float* x, float* y, int M, int N, int K, int ldx, int ldy,
+                        int act_in, int act_out, mvd_stream_t stream) {
+  MVD_CHECK_ARG(W && x && y && M > 0 && M <= 16 && N > 0 && K > 0, "mvd_gemv: bad arguments (M <= 16)");
+  if ((K & 3) == 0) MVD_CHECK_ARG((ldx & 3) == 0, "mvd_gemv: ldx must be a multiple of 4 when K is");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(N, 4)), block(256);
+  if (M <= 1)
+    hipLaunchKernelGGL(gemv_kernel<1>, grid, block, 0, s, W, bias, x, y, M, N, K, ldx, ldy, act_in, act_out);
+  else if (M <= 4)
+    hipLaunchKernelGGL(gemv_kernel<4>, grid, block, 0, s, W, bias, x, y, M, N, K, ldx, ldy, act_in, act_out);
+  else
+    hipLaunchKernelGGL(gemv_kernel<16>, grid, block, 0, s, W, bias, x, y, M, N, K, ldx, ldy, act_in, act_out);
+  MVD_CHECK_LAUNCH("mvd_gemv");
+  return 0;
+}
+
+extern "C" int mvd_unet_input(const float* x, const float* input_latents, float* out, int V, int S, int cpad, int cfg,
+                              mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && input_latents && out && V > 0 && S > 0 && cpad >= 10, "mvd_unet_input: bad arguments");
+  const int nb = cfg ? 2 * V : V;
+  const size_t total = (size_t)nb * S * S * cpad;
+  hipLaunchKernelGGL(unet_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, input_latents, out, V, S,
+                     cpad, nb);
+  MVD_CHECK_LAUNCH("mvd_unet_input");
+  return 0;
+}
+
+extern "C" int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, int rows, mvd_stream_t stream) {
+  MVD_CHECK_ARG(a && b && out && rows > 0 && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0,
+                "mvd_concat_channels: bad arguments (channel counts must be multiples of 4)");
+  const size_t total = (size_t)rows * (Ca + Cb) / 4;
+  hipLaunchKernelGGL(concat_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, Ca / 4,
+                     (const float4*)b, Cb / 4, (float4*)out, (size_t)rows);
+  MVD_CHECK_LAUNCH("mvd_concat_channels");
+  return 0;
+}
+
+extern "C" int mvd_area_pool(const float* vol, float* out, int B, int S, int D, int C, int factor, mvd_stream_t stream) {
+  MVD_CHECK_ARG(vol && out && B > 0 && S > 0 && D > 0 && C % 4 == 0 && factor >= 1 && S % factor == 0,
+                "mvd_area_pool: bad arguments");
+  const int So = S / factor;
+  const size_t total = (size_t)B * So * So * D * (C / 4);
+  hipLaunchKernelGGL(area_pool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)vol,
+                     (float4*)out, B, S, D, C / 4, factor);
+  MVD_CHECK_LAUNCH("mvd_area_pool");
+  return 0;
+}
+
+extern "C" int mvd_fill_zero(float* p, size_t n, mvd_stream_t stream) {
+  MVD_CHECK_ARG(p != nullptr, "mvd_fill_zero: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n);
+  MVD_CHECK_LAUNCH("mvd_fill_zero");
+  return 0;
+}
+
+extern "C" int mvd_timestep_embedding(const float* steps, const int* iter, const float* freqs, float* out, int dim,
+                                      mvd_stream_t stream) {
+  MVD_CHECK_ARG(steps && iter && freqs && out && dim > 0 && dim % 2 == 0, "mvd_timestep_embedding: bad arguments");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, steps, iter, freqs, out, dim);
+  MVD_CHECK_LAUNCH("mvd_timestep_embedding");
+  return 0;
+}
+
+extern "C" int mvd_advance_iter(int* iter, mvd_stream_t stream) {
+  MVD_CHECK_ARG(iter != nullptr, "mvd_advance_iter: null pointer");
+  hipLaunchKernelGGL(advance_iter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, iter);
+  MVD_CHECK_LAUNCH("mvd_advance_iter");
+  return 0;
+}
+
+extern "C" int mvd_cfg_ddim_update(const float* eps_nhwc, int ldc, float* x, float* x0, float* eps_out,
+                                   const float* ddim_noise, size_t noise_stride, const float* steps, const int* iter, int V,
+                                   int S, int cfg, float cfg_scale, int do_update, mvd_stream_t stream) {
+  MVD_CHECK_ARG(eps_nhwc && steps && iter && V > 0 && S > 0 && ldc >= 5, "mvd_cfg_ddim_update: bad arguments");
+  if (do_update) MVD_CHECK_ARG(x && x0 && ddim_noise, "mvd_cfg_ddim_update: update needs x, x0, ddim_noise");
+  const size_t total = (size_t)V * 5 * S * S;
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, eps_nhwc, ldc, x, x0, eps_out,
+                     ddim_noise, steps, iter, V, S, cfg, cfg_scale, do_update, noise_stride);
+  MVD_CHECK_LAUNCH("mvd_cfg_ddim_update");
+  return 0;
+}

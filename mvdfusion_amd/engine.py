@@ -1,0 +1,103 @@
+"""Execution context shared by the HIP-backed module mirrors: static workspace arena, per-step device tables.
+
+Design (MI355X-first): every intermediate of a denoising step lives in a buffer that is allocated ONCE (first eager
+run) and re-used with a fixed address afterwards, so a whole step -- GridAttn + the classifier-free-guidance pair of
+UNet passes (batched as 2V views: one sweep of the 4 GB of weights) + the DDIM update -- is allocation-free and can be
+captured in a single hipGraph and replayed 50 times with no host work in between.  Scratch buffers are shared between
+layers of the same shape (keeps the working set inside the 256 MB Infinity Cache); 288 GB of HBM makes the arena size
+a non-issue.
+"""
+import torch
+
+from . import hip
+
+
+class Workspace:
+    """Named static buffers.  get(tag, shape) returns the same tensor (same address) on every call."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.bufs = {}
+
+    def get(self, tag, shape, dtype=torch.float32, zero=False):
+        key = (tag, tuple(int(s) for s in shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        return t
+
+    def attn_planes(self, B, heads, L, dhead):
+        key = ("attn_planes", B, heads, L, dhead)
+        t = self.bufs.get(key)
+        if t is None:
+            t = hip.alloc_attn_planes(B, heads, L, dhead, self.device)
+            self.bufs[key] = t
+        return t
+
+    def nbytes(self):
+        n = 0
+        for v in self.bufs.values():
+            for t in (v if isinstance(v, tuple) else (v,)):
+                n += t.numel() * t.element_size()
+        return n
+
+
+class Ctx:
+    """Per-model execution context handed down the module tree."""
+
+    def __init__(self, device, prec=hip.PREC_BF16X3):
+        self.device = torch.device(device)
+        self.ws = Workspace(device)
+        self.prec = prec
+        self.B = 0                  # views in the UNet batch (2V with classifier-free guidance)
+        self.D = 1                  # depth samples per ray
+        self.context = None         # (B, 768) projected CLIP context
+        self.vol_levels = None      # list of (B*h*w*D, 768)
+        self.emb_bias = None        # dict: ResBlock -> (Cout,) slice of the per-step time-embedding biases
+        self._rot = {}
+        self.gn_ws = torch.empty(64 * 64 * 32 * 2, dtype=torch.float64, device=self.device)
+        self.gemm_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 256 MB split-K slabs
+
+    def act(self, shape):
+        """Rotating layer-output buffers (3 per shape): a layer's input stays valid while it writes its output."""
+        key = tuple(int(s) for s in shape)
+        i = self._rot.get(key, 0)
+        self._rot[key] = (i + 1) % 3
+        return self.ws.get(f"act{i}", key)
+
+    # -- op helpers bound to this context
+    def gemm(self, A, W, out, **kw):
+        kw.setdefault("prec", self.prec)
+        kw.setdefault("workspace", self.gemm_ws)
+        return hip.gemm(A, W, out, **kw)
+
+    def groupnorm(self, x, y, norm, B, HW, C, silu):
+        return hip.groupnorm(x, y, norm.weight, norm.bias, B, HW, C, norm.eps, silu, self.gn_ws)
+
+    def layernorm(self, x, y, norm, rows, C):
+        return hip.layernorm(x, y, norm.weight, norm.bias, rows, C, norm.eps)
+
+    def gemv_rows(self, W, bias, x, y, act_in=hip.ACT_NONE, act_out=hip.ACT_NONE):
+        """gemv for any number of rows (the kernel takes <= 16 at a time)."""
+        for r in range(0, x.shape[0], 16):
+            hip.gemv(W, bias, x[r:r + 16], y[r:r + 16], act_in, act_out)
+        return y
+
+
+def ddim_step_table(scheduler_tables, ddim, iters):
+    """(len(iters), 8) fp32 table for the device kernels (include/mvd_hip.h, MVD_STEP_STRIDE).
+
+    ``iters`` is the list of DDIM indices in execution order (49, 48, ..., 0 for a full sample).
+    """
+    rows = []
+    for index in iters:
+        t = int(ddim["timesteps"][index])
+        sac = float(scheduler_tables["sqrt_alphas_cumprod"][t])
+        s1m = float(scheduler_tables["sqrt_one_minus_alphas_cumprod"][t])
+        dstd = (scheduler_tables["sqrt_one_minus_alphas_cumprod"][t] / scheduler_tables["sqrt_alphas_cumprod"][t] / 10.0)
+        rows.append([float(t), sac, float(dstd), float(ddim["alphas"][index]), float(ddim["alphas_prev"][index]),
+                     float(ddim["sigmas"][index]), float(ddim["sqrt_one_minus_alphas"][index]),
+                     1.0 if index > 0 else 0.0])
+        del s1m
+    return torch.tensor(rows, dtype=torch.float32)

@@ -1,0 +1,294 @@
+"""ctypes binding of the C ABI in include/mvd_hip.h (mvdfusion_amd/csrc/libmvd_hip.so).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised (the product path must
+never silently run on something other than the HIP kernels).  Everything is enqueued on torch's current stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvd_hip.so")
+
+PREC_BF16, PREC_BF16X3 = 1, 3
+A_DENSE, A_CONV3X3 = 0, 1
+EPI_STORE, EPI_GEGLU, EPI_QKV = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+STEP_STRIDE = 8
+CAM_RECORD = 20
+TOKEN_DIM, TOKEN_LD = 723, 736
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    """struct mvd_gemm_desc (field order must match include/mvd_hip.h)."""
+    _fields_ = [
+        ("M", _i), ("N", _i), ("K", _i),
+        ("A", _vp), ("lda", _i), ("a_mode", _i),
+        ("B", _i), ("Hin", _i), ("Win", _i), ("Cin", _i), ("Hout", _i), ("Wout", _i), ("stride", _i), ("upsample", _i),
+        ("Wp", _vp), ("prec", _i),
+        ("epi", _i), ("act", _i), ("out", _vp), ("ldo", _i), ("n_store", _i),
+        ("bias", _vp), ("bias_b", _vp), ("rows_per_batch", _i), ("colscale", _vp), ("res", _vp), ("ldr", _i),
+        ("q_hi", _vp), ("q_lo", _vp), ("k_hi", _vp), ("k_lo", _vp), ("vt_hi", _vp), ("vt_lo", _vp),
+        ("heads", _i), ("dhead", _i), ("L", _i), ("Lpad", _i), ("qscale", _f),
+        ("splitk", _i), ("workspace", _vp), ("workspace_elems", _sz),
+    ]
+
+
+# name -> (restype, argtypes): every symbol declared in include/mvd_hip.h
+SIGNATURES = {
+    "mvd_version": (_i, []),
+    "mvd_last_error": (C.c_char_p, []),
+    "mvd_packed_weight_bytes": (_sz, [_i, _i]),
+    "mvd_pack_linear_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mvd_pack_conv3x3_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mvd_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "mvd_gemv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mvd_groupnorm_chunks": (_i, [_i]),
+    "mvd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "mvd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "mvd_attn_qk_plane_elems": (_sz, [_i, _i, _i, _i]),
+    "mvd_attn_vt_plane_elems": (_sz, [_i, _i, _i, _i]),
+    "mvd_attn_lpad": (_i, [_i]),
+    "mvd_attention": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _vp]),
+    "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvd_unet_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp]),
+    "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvd_fill_zero": (_i, [_vp, _sz, _vp]),
+    "mvd_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "mvd_advance_iter": (_i, [_vp, _vp]),
+    "mvd_zembed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mvd_gridattn_tokens": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _f, _f, _vp]),
+    "mvd_view_mha": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvd_view_pool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mvd_cfg_ddim_update": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "mvd_graph_begin": (_i, [_vp]),
+    "mvd_graph_end": (_i, [_vp, C.POINTER(_vp)]),
+    "mvd_graph_launch": (_i, [_vp, _vp]),
+    "mvd_graph_destroy": (_i, [_vp]),
+    "mvd_event_create": (_i, [C.POINTER(_vp)]),
+    "mvd_event_record": (_i, [_vp, _vp]),
+    "mvd_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),
+    "mvd_event_destroy": (_i, [_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libmvd_hip.so (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m mvdfusion_amd.csrc.build` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). mvdfusion_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"mvd_hip error {rc}: {lib().mvd_last_error().decode()}")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.shape, t.stride())
+    return t
+
+
+# ---------------------------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------------------------
+class PackedWeight:
+    """A weight in the MFMA operand image (split bf16, [K/32][N/16][hi,lo][16][32]) plus its fp32 bias."""
+
+    __slots__ = ("data", "N", "K", "n_real", "bias", "geglu", "conv_cin")
+
+    def __init__(self, data, N, K, n_real, bias, geglu=False, conv_cin=0):
+        self.data, self.N, self.K, self.n_real, self.bias, self.geglu, self.conv_cin = data, N, K, n_real, bias, geglu, conv_cin
+
+
+def pack_linear(weight, bias=None, geglu=False):
+    """weight (N, K) fp32 on the GPU (nn.Linear / 1x1 nn.Conv2d weight)."""
+    w = weight.detach().reshape(weight.shape[0], -1).contiguous().float()
+    N, K = w.shape
+    Np, Kp = (N + 15) // 16 * 16, (K + 31) // 32 * 32
+    data = torch.empty(lib().mvd_packed_weight_bytes(N, K), dtype=torch.uint8, device=w.device)
+    check(lib().mvd_pack_linear_weight(ptr(w), N, K, K, int(geglu), ptr(data), stream()))
+    b = None
+    if bias is not None:
+        b = torch.zeros(Np, dtype=torch.float32, device=w.device)
+        b[:N] = bias.detach().float()
+    torch.cuda.current_stream().synchronize()  # w may be a temporary
+    return PackedWeight(data, Np, Kp, N, b, geglu)
+
+
+def pack_linear_cat(weights):
+    """Row-concatenate several (N_i, K) weights (e.g. to_q/to_k/to_v -> one QKV GEMM)."""
+    return pack_linear(torch.cat([w.detach().float() for w in weights], dim=0))
+
+
+def pack_conv3x3(weight, bias=None):
+    w = weight.detach().contiguous().float()
+    Cout, Cin = w.shape[0], w.shape[1]
+    cin_pad = (Cin + 31) // 32 * 32
+    Np = (Cout + 15) // 16 * 16
+    data = torch.empty(Np * 9 * cin_pad * 4, dtype=torch.uint8, device=w.device)
+    check(lib().mvd_pack_conv3x3_weight(ptr(w), Cout, Cin, cin_pad, ptr(data), stream()))
+    b = None
+    if bias is not None:
+        b = torch.zeros(Np, dtype=torch.float32, device=w.device)
+        b[:Cout] = bias.detach().float()
+    torch.cuda.current_stream().synchronize()
+    return PackedWeight(data, Np, 9 * cin_pad, Cout, b, conv_cin=cin_pad)
+
+
+# ---------------------------------------------------------------------------------------------
+# ops (thin wrappers; all outputs are caller-provided tensors)
+# ---------------------------------------------------------------------------------------------
+def gemm(A, W, out=None, *, prec=PREC_BF16X3, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
+         bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None):
+    """out = epilogue(A @ W^T).  A: (M, K) fp32 (dense) or NHWC (B,H,W,C) with conv=dict(...).
+
+    conv = dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
+    """
+    d = GemmDesc()
+    d.N, d.K = W.N, W.K
+    d.A = A.data_ptr()
+    d.Wp = W.data.data_ptr()
+    d.prec = prec
+    if conv is not None:
+        d.a_mode = A_CONV3X3
+        for k in ("B", "Hin", "Win", "Cin", "Hout", "Wout", "stride", "upsample"):
+            setattr(d, k, int(conv[k]))
+        d.M = conv["B"] * conv["Hout"] * conv["Wout"]
+        assert conv["Cin"] * 9 == W.K, (conv["Cin"], W.K)
+    else:
+        d.a_mode = A_DENSE
+        d.M = int(M if M is not None else A.numel() // A.shape[-1])
+        d.lda = int(lda if lda is not None else A.shape[-1])
+        assert d.lda >= W.K, f"A has {d.lda} columns, packed K is {W.K} (pad A)"
+    d.epi, d.act = epi, act
+    if out is not None:
+        d.out = out.data_ptr()
+        d.ldo = int(ldo if ldo is not None else out.shape[-1])
+    d.n_store = W.n_real
+    if bias and W.bias is not None:
+        d.bias = W.bias.data_ptr()
+    if bias_b is not None:
+        d.bias_b = bias_b.data_ptr()
+        d.rows_per_batch = int(rows_per_batch)
+    if colscale is not None:
+        d.colscale = colscale.data_ptr()
+    if res is not None:
+        d.res = res.data_ptr()
+        d.ldr = int(res.shape[-1])
+    if qkv is not None:
+        qh, ql, kh, kl, vh, vl = qkv["planes"]
+        d.q_hi, d.q_lo, d.k_hi, d.k_lo, d.vt_hi, d.vt_lo = (t.data_ptr() for t in (qh, ql, kh, kl, vh, vl))
+        d.heads, d.dhead, d.L = qkv["heads"], qkv["dhead"], qkv["L"]
+        d.Lpad = lib().mvd_attn_lpad(qkv["L"])
+        d.qscale = float(qkv["dhead"]) ** -0.5
+    d.splitk = splitk
+    if workspace is not None:
+        d.workspace = workspace.data_ptr()
+        d.workspace_elems = workspace.numel()
+    check(lib().mvd_gemm(C.byref(d), stream()))
+    return out
+
+
+def gemv(W, bias, x, y, act_in=ACT_NONE, act_out=ACT_NONE):
+    """y (M,N) = act_out(act_in(x) (M,K) @ W^T (N,K) + bias), fp32 exact, M <= 16."""
+    M, K = x.shape
+    N = W.shape[0]
+    check(lib().mvd_gemv(ptr(W), ptr(bias), ptr(x), ptr(y), M, N, K, x.stride(0), y.stride(0), act_in, act_out, stream()))
+    return y
+
+
+def groupnorm(x, y, gamma, beta, B, HW, Cc, eps, silu, ws):
+    check(lib().mvd_groupnorm_nhwc(ptr(x), ptr(y), ptr(gamma), ptr(beta), B, HW, Cc, 32, eps, int(silu), ptr(ws), stream()))
+    return y
+
+
+def layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False):
+    check(lib().mvd_layernorm(ptr(x), ptr(y), ptr(w), ptr(b), rows, Cc, eps, int(w_plus_one), stream()))
+    return y
+
+
+def attention(planes, out, B, heads, L, dhead, prec=PREC_BF16X3):
+    qh, ql, kh, kl, vh, vl = planes
+    check(lib().mvd_attention(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(out), out.shape[-1], B, heads, L,
+                              dhead, prec, stream()))
+    return out
+
+
+def alloc_attn_planes(B, heads, L, dhead, device):
+    nqk = lib().mvd_attn_qk_plane_elems(B, heads, L, dhead)
+    nvt = lib().mvd_attn_vt_plane_elems(B, heads, L, dhead)
+    mk = lambda n: torch.zeros(n, dtype=torch.int16, device=device)  # zero padding is part of the contract
+    return (mk(nqk), mk(nqk), mk(nqk), mk(nqk), mk(nvt), mk(nvt))
+
+
+class Graph:
+    """A captured hipGraph of everything enqueued on the current stream inside the `with` block."""
+
+    def __init__(self):
+        self.exec = C.c_void_p()
+
+    def __enter__(self):
+        self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(self._side)
+        self._ctx.__enter__()
+        check(lib().mvd_graph_begin(stream()))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = lib().mvd_graph_end(stream(), C.byref(self.exec))
+        self._ctx.__exit__(et, ev, tb)
+        torch.cuda.current_stream().wait_stream(self._side)
+        if et is None:
+            check(rc)
+        return False
+
+    def launch(self):
+        check(lib().mvd_graph_launch(self.exec, stream()))
+
+    def __del__(self):
+        try:
+            if self.exec:
+                lib().mvd_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.h = C.c_void_p()
+        check(lib().mvd_event_create(C.byref(self.h)))
+
+    def record(self):
+        check(lib().mvd_event_record(self.h, stream()))
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float()
+        check(lib().mvd_event_elapsed_ms(self.h, stop.h, C.byref(ms)))
+        return ms.value

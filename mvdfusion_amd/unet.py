@@ -1,0 +1,316 @@
+"""View-conditioned SD1.x UNet executed by HIP kernels -- mirror of ``mvdfusion/unet.py``.
+
+Classes keep the reference's names, constructor kwargs and state_dict keys:
+  ``ResBlock`` / ``Downsample`` / ``Upsample``   external/sd1/ldm/modules/diffusionmodules/openaimodel.py:91-275
+  ``TimestepEmbedSequential``                    mvdfusion/unet.py:36-52
+  ``UNetModel``                                  mvdfusion/unet.py:215-576
+  ``UNetWrapper``                                mvdfusion/unet.py:56-209
+
+Data layout in HBM: activations are fp32 channels-last, (B, H, W, C) == a (B*H*W, C) row-major matrix, so the conv
+path (implicit GEMM, K = 9*C contiguous per tap) and the transformer path ((hw, C) tokens) share buffers with no
+transposes.  The classifier-free-guidance pair is ONE batch of 2V views (rows [0,V) conditional, [V,2V) null), so the
+4 GB of weights stream once per step instead of twice.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .attention import SpatialTransformer, ViewAlignedFeatureTransformer
+from .engine import Ctx
+
+
+class GroupNorm32(nn.GroupNorm):
+    pass
+
+
+def normalization(channels):
+    return GroupNorm32(32, channels)  # eps 1e-5 (diffusionmodules/util.py:200-217)
+
+
+class TimestepBlock(nn.Module):
+    pass
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=padding)
+        self._p = None
+
+    def run(self, ctx, x, H, W, out=None):
+        if self._p is None:
+            self._p = hip.pack_conv3x3(self.conv.weight, self.conv.bias)
+        if out is None:
+            out = ctx.act((ctx.B * 4 * H * W, self.out_channels))
+        ctx.gemm(x, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=2 * H, Wout=2 * W,
+                                            stride=1, upsample=1))
+        return out, 2 * H, 2 * W
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.op = nn.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
+        self._p = None
+
+    def run(self, ctx, x, H, W, out=None):
+        if self._p is None:
+            self._p = hip.pack_conv3x3(self.op.weight, self.op.bias)
+        Ho, Wo = H // 2, W // 2
+        if out is None:
+            out = ctx.act((ctx.B * Ho * Wo, self.out_channels))
+        ctx.gemm(x, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=Ho, Wout=Wo, stride=2,
+                                            upsample=0))
+        return out, Ho, Wo
+
+
+class ResBlock(TimestepBlock):
+    """GN+SiLU -> conv3x3 (+bias +time-embedding) -> GN+SiLU -> conv3x3 (+bias +skip)  (openaimodel.py:255-275)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, dims=2, use_checkpoint=False,
+                 use_scale_shift_norm=False):
+        super().__init__()
+        assert not use_scale_shift_norm
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(),
+                                       nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1))
+        self.skip_connection = nn.Identity() if self.out_channels == channels else \
+            nn.Conv2d(channels, self.out_channels, 1)
+        self._p = None
+
+    def packed(self):
+        if self._p is None:
+            c1, c2 = self.in_layers[2], self.out_layers[3]
+            sk = None if isinstance(self.skip_connection, nn.Identity) else \
+                hip.pack_linear(self.skip_connection.weight, self.skip_connection.bias)
+            self._p = (hip.pack_conv3x3(c1.weight, None), hip.pack_conv3x3(c2.weight, c2.bias), sk)
+        return self._p
+
+    def run(self, ctx, x, H, W, out=None):
+        B, Ci, Co = ctx.B, self.channels, self.out_channels
+        M = B * H * W
+        w1, w2, wsk = self.packed()
+        geo = dict(B=B, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
+        a = ctx.ws.get("res.a", (M, Ci))
+        ctx.groupnorm(x, a, self.in_layers[0], B, H * W, Ci, silu=True)
+        h = ctx.ws.get("res.h", (M, Co))
+        # conv bias + Linear(SiLU(emb)) are folded into one per-step bias vector (UNetModel._time_biases)
+        hip.gemm(a, w1, h, prec=ctx.prec, conv=dict(Cin=Ci, **geo), bias=False, colscale=None,
+                 res=None, workspace=ctx.gemm_ws, bias_b=ctx.emb_bias[self], rows_per_batch=M)
+        a2 = ctx.ws.get("res.a2", (M, Co))
+        ctx.groupnorm(h, a2, self.out_layers[0], B, H * W, Co, silu=True)
+        skip = x
+        if wsk is not None:
+            skip = ctx.ws.get("res.skip", (M, Co))
+            ctx.gemm(x, wsk, skip)
+        if out is None:
+            out = ctx.act((M, Co))
+        ctx.gemm(a2, w2, out, conv=dict(Cin=Co, **geo), res=skip)
+        return out
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    def run(self, ctx, x, H, W, out=None):
+        """Run the layers in order; `out` (optional) is the buffer the LAST layer must write (skip tensors)."""
+        n = len(self)
+        for i, layer in enumerate(self):
+            dst = out if i == n - 1 else None
+            if isinstance(layer, (Upsample, Downsample)):
+                x, H, W = layer.run(ctx, x, H, W, out=dst)
+            else:
+                x = layer.run(ctx, x, H, W, out=dst)
+        return x, H, W
+
+
+class _StemConv(nn.Conv2d):
+    """input_blocks.0.0: Conv2d(in_channels -> model_channels); input is zero-padded to 32 channels."""
+    _p = None
+
+    def run(self, ctx, x, H, W, out):
+        if self._p is None:
+            self._p = hip.pack_conv3x3(self.weight, self.bias)
+        ctx.gemm(x, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self._p.conv_cin, Hout=H, Wout=W, stride=1,
+                                            upsample=0))
+        return out
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None,
+                 use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=True, use_view_aligned_transformer=True, transformer_depth=1,
+                 context_dim=None, n_embed=None, legacy=True):
+        super().__init__()
+        assert use_view_aligned_transformer and use_spatial_transformer and context_dim is not None
+        assert dims == 2 and num_classes is None and not resblock_updown and n_embed is None and conv_resample
+        assert num_heads != -1 and num_head_channels == -1, "this build supports the num_heads form (configs/*.yaml)"
+        if isinstance(context_dim, (list, tuple)) or type(context_dim).__name__ == "ListConfig":
+            context_dim = list(context_dim)[0]
+        channel_mult = tuple(channel_mult)
+        attention_resolutions = tuple(attention_resolutions)
+        self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
+        self.out_channels, self.num_res_blocks, self.channel_mult = out_channels, num_res_blocks, channel_mult
+        self.attention_resolutions, self.num_heads, self.context_dim = attention_resolutions, num_heads, context_dim
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+
+        def res(cin, cout):
+            return ResBlock(cin, ted, dropout, out_channels=cout, use_checkpoint=use_checkpoint)
+
+        def st(c):
+            return SpatialTransformer(c, num_heads, c // num_heads, depth=transformer_depth, context_dim=context_dim)
+
+        def vaft(c):
+            return ViewAlignedFeatureTransformer(c, num_heads, c // num_heads, depth=transformer_depth,
+                                                 context_dim=context_dim, image_size=image_size)
+
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(_StemConv(in_channels, model_channels, 3, padding=1))])
+        skip_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [res(ch, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(st(ch))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                skip_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, True, out_channels=ch)))
+                skip_chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(res(ch, ch), st(ch), vaft(ch), res(ch, ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                layers = [res(ch + skip_chans.pop(), model_channels * mult)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers += [st(ch), vaft(ch)]
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, True, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(normalization(ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
+        self._head = None
+        self._temb = None
+
+    # ------------------------------------------------------------------ reference API (unet.py:558-576)
+    def get_cross_attn_parameters(self, finetune_cross_attn, finetune_view_attn):
+        out = []
+        for name, p in self.named_parameters():
+            if finetune_cross_attn and any(k in name for k in (".norm.", ".proj_in.", ".transformer_blocks.", ".proj_out.")):
+                out.append(p)
+            if finetune_view_attn and ".aligned_attn_" in name:
+                out.append(p)
+        return out
+
+    def disable_unet_grad(self):
+        for name, p in self.named_parameters():
+            if ".aligned_attn_" not in name:
+                p.requires_grad_(False)
+
+    # ------------------------------------------------------------------ HIP execution
+    def _resblocks(self):
+        return [m for m in self.modules() if isinstance(m, ResBlock)]
+
+    def time_biases(self, ctx, t_sin):
+        """emb = time_embed(t_sin); per ResBlock bias = in_layers.2.bias + emb_layers.1(SiLU(emb))  -- one GEMV
+        over the row-concatenated emb_layers weights (unet.py:537-538; openaimodel.py:264-273)."""
+        if self._temb is None:
+            blocks = self._resblocks()
+            w = torch.cat([b.emb_layers[1].weight.detach() for b in blocks], 0).contiguous()
+            bias = torch.cat([b.emb_layers[1].bias.detach() + b.in_layers[2].bias.detach() for b in blocks], 0).contiguous()
+            offs, o = {}, 0
+            for b in blocks:
+                offs[b] = (o, o + b.out_channels)
+                o += b.out_channels
+            self._temb = (w, bias, offs, torch.empty(1, o, dtype=torch.float32, device=w.device))
+        w, bias, offs, out = self._temb
+        ted = self.model_channels * 4
+        e1 = ctx.ws.get("temb.e1", (1, ted))
+        hip.gemv(self.time_embed[0].weight, self.time_embed[0].bias, t_sin, e1, act_out=hip.ACT_SILU)
+        emb = ctx.ws.get("temb.emb", (1, ted))
+        hip.gemv(self.time_embed[2].weight, self.time_embed[2].bias, e1, emb)
+        hip.gemv(w, bias, emb, out, act_in=hip.ACT_SILU)
+        ctx.emb_bias = {b: out[0, lo:hi] for b, (lo, hi) in offs.items()}
+
+    def run(self, ctx, x_in, t_sin, S):
+        """x_in: (B, S, S, 32) channels-last zero-padded input; t_sin: (1, model_channels) sinusoid; returns the
+        (B*S*S, 8) head output (first out_channels columns valid)."""
+        B = ctx.B
+        self.time_biases(ctx, t_sin)
+        hs = []
+        H = W = S
+        h = x_in
+        for bi, blk in enumerate(self.input_blocks):
+            if bi == 0:
+                o = ctx.ws.get("hs0", (B * H * W, self.model_channels))
+                h = blk[0].run(ctx, h, H, W, o)
+            else:
+                last = blk[-1]
+                Ho, Wo = (H // 2, W // 2) if isinstance(last, Downsample) else (H, W)
+                co = last.out_channels if isinstance(last, (ResBlock, Downsample)) else last.in_channels
+                o = ctx.ws.get(f"hs{bi}", (B * Ho * Wo, co))      # skip tensors get their own static buffers
+                h, H, W = blk.run(ctx, h, H, W, out=o)
+            hs.append((h, H, W))
+        h, H, W = self.middle_block.run(ctx, h, H, W)
+        for blk in self.output_blocks:
+            sk, _, _ = hs.pop()
+            M = B * H * W
+            ca, cb = h.shape[-1], sk.shape[-1]
+            cat = ctx.ws.get("cat", (M, ca + cb))
+            hip.check(hip.lib().mvd_concat_channels(hip.ptr(h), ca, hip.ptr(sk), cb, hip.ptr(cat), M, hip.stream()))
+            h, H, W = blk.run(ctx, cat, H, W)
+        if self._head is None:
+            self._head = hip.pack_conv3x3(self.out[2].weight, self.out[2].bias)
+        M = B * H * W
+        a = ctx.ws.get("res.a", (M, self.model_channels))
+        ctx.groupnorm(h, a, self.out[0], B, H * W, self.model_channels, silu=True)
+        y = ctx.ws.get("head", (M, 8))
+        ctx.gemm(a, self._head, y, conv=dict(B=B, Hin=H, Win=W, Cin=self.model_channels, Hout=H, Wout=W, stride=1,
+                                             upsample=0), ldo=8)
+        return y
+
+
+class UNetWrapper(nn.Module):
+    """mvdfusion/unet.py:56-209.  ``unet_config`` is the yaml node {target, params} (or a params dict)."""
+
+    def __init__(self, unet_config, unet_path=None, drop_conditions=False, drop_scheme="default", use_zero_123=False,
+                 finetune_unet=False, finetune_cross_attn=False, finetune_view_attn=True, remove_keys=()):
+        super().__init__()
+        params = unet_config.get("params", unet_config) if hasattr(unet_config, "get") else unet_config
+        self.unet_model = UNetModel(**dict(params))
+        if unet_path:
+            from .load_model import load_unet_checkpoint
+            load_unet_checkpoint(self.unet_model, unet_path, remove_keys=remove_keys)
+        if not finetune_unet:
+            self.unet_model.disable_unet_grad()
+        self.drop_conditions, self.drop_scheme, self.use_zero_123 = drop_conditions, drop_scheme, use_zero_123
+        self.finetune_unet, self.finetune_cross_attn, self.finetune_view_attn = \
+            finetune_unet, finetune_cross_attn, finetune_view_attn
+
+    def get_trainable_parameters(self):
+        if self.finetune_unet:
+            return self.unet_model.parameters()
+        return self.unet_model.get_cross_attn_parameters(finetune_cross_attn=self.finetune_cross_attn,
+                                                         finetune_view_attn=self.finetune_view_attn)
+
+    def volume_pyramid(self, ctx, vol, B, S, D):
+        """get_volume_feats_pyramid (unet.py:198-209): area pooling at x{1, 1/2, 1/4, 1/8}; vol (B,S,S,D,768)."""
+        levels = [vol.view(B * S * S * D, -1)]
+        Cc = vol.shape[-1]
+        for i in range(1, len(self.unet_model.channel_mult)):
+            f = 2 ** i
+            o = ctx.ws.get(f"vol{i}", (B * (S // f) * (S // f) * D, Cc))
+            hip.check(hip.lib().mvd_area_pool(hip.ptr(vol), hip.ptr(o), B, S, D, Cc, f, hip.stream()))
+            levels.append(o)
+        return levels

@@ -1,0 +1,160 @@
+"""Depth-conditioned cross-view aggregation, executed by HIP kernels -- mirror of
+``mvdfusion.view_attn_efficient2.GridAttn`` (mvdfusion/view_attn_efficient2.py:96-442).
+
+Same constructor kwargs and state_dict keys (``z_embedder.0``, ``t_embedder.mlp.{0,2}`` [present but unused, as in the
+reference], ``pre_layer_b.0``, ``aggregation_transformer.layer_list.{i}.{attn.qkv,attn.proj,mlp.fc1,mlp.fc2,
+adaLN_modulation.1}``, ``aggregation_transformer.weight_layer``, ``final_layer_b``).
+
+Per step (one launch each unless noted):
+  z_embed (x2) -> fused depth-sample/unproject/reproject/gather/embed token kernel -> pre_layer GEMM(+GELU)
+  -> 3 x [adaLN GEMV, LN+modulate, QKV GEMM, attention over the V views, proj GEMM (+gate +residual),
+          LN+modulate, fc1 GEMM(+GELU), fc2 GEMM (+gate +residual)]
+  -> weight-softmax pooling over V -> final GEMM -> (V, S, S, D, 768) feature frustum.
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .cameras import pack_cameras
+
+
+class _TimmAttention(nn.Module):      # parameter holder: timm.models.vision_transformer.Attention(qkv_bias=True)
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _TimmMlp(nn.Module):            # parameter holder: timm Mlp(fc1, GELU, fc2)
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class DiTBlock(nn.Module):
+    """adaLN-Zero block (view_attn_efficient2.py:42-67); LN eps 1e-6 without affine."""
+
+    def __init__(self, hidden_size, num_heads, cond_dim=None, mlp_ratio=4.0):
+        super().__init__()
+        cond_dim = hidden_size if cond_dim is None else cond_dim
+        self.attn = _TimmAttention(hidden_size, num_heads)
+        self.mlp = _TimmMlp(hidden_size, int(hidden_size * mlp_ratio))
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(cond_dim, 6 * hidden_size, bias=True))
+        self.hidden_size, self.num_heads = hidden_size, num_heads
+        self._p = None
+
+    def packed(self):
+        if self._p is None:
+            self._p = (hip.pack_linear(self.attn.qkv.weight, self.attn.qkv.bias),
+                       hip.pack_linear(self.attn.proj.weight, self.attn.proj.bias),
+                       hip.pack_linear(self.mlp.fc1.weight, self.mlp.fc1.bias),
+                       hip.pack_linear(self.mlp.fc2.weight, self.mlp.fc2.bias))
+        return self._p
+
+    def run(self, ctx, h, h_alt, c, T, V):
+        """h (T, C) -> returns the updated stream (written back into h); h_alt is the ping-pong partner."""
+        C = self.hidden_size
+        wqkv, wproj, wfc1, wfc2 = self.packed()
+        lin = self.adaLN_modulation[1]
+        mod = ctx.ws.get("ga.mod", (1, 6 * C))
+        hip.gemv(lin.weight, lin.bias, c, mod, act_in=hip.ACT_SILU)
+        sh1, sc1, g1, sh2, sc2, g2 = (mod[0, i * C:(i + 1) * C] for i in range(6))
+        ln = ctx.ws.get("ga.ln", (T, C))
+        hip.layernorm(h, ln, sc1, sh1, T, C, eps=1e-6, w_plus_one=True)
+        qkv = ctx.ws.get("ga.qkv", (T, 3 * C))
+        ctx.gemm(ln, wqkv, qkv)
+        att = ctx.ws.get("ga.att", (T, C))
+        hip.check(hip.lib().mvd_view_mha(hip.ptr(qkv), hip.ptr(att), T // V, V, self.num_heads, C // self.num_heads,
+                                         hip.stream()))
+        ctx.gemm(att, wproj, h_alt, res=h, colscale=g1)
+        hip.layernorm(h_alt, ln, sc2, sh2, T, C, eps=1e-6, w_plus_one=True)
+        f1 = ctx.ws.get("ga.f1", (T, wfc1.N))
+        ctx.gemm(ln, wfc1, f1, act=hip.ACT_GELU)
+        ctx.gemm(f1, wfc2, h, res=h_alt, colscale=g2)
+        return h
+
+
+class AggregationTransformer(nn.Module):
+    def __init__(self, hidden_size, num_layers=3, num_heads=8, mlp_ratio=2.0, use_t=False):
+        super().__init__()
+        if not use_t:
+            raise NotImplementedError
+        self.use_t = use_t
+        self.layer_list = nn.ModuleList([DiTBlock(hidden_size, num_heads=num_heads, mlp_ratio=mlp_ratio)
+                                         for _ in range(num_layers)])
+        self.weight_layer = nn.Linear(hidden_size, 1)
+
+
+class _TimestepEmbedder(nn.Module):   # holder for the unused-but-present t_embedder.mlp.{0,2} parameters
+    def __init__(self, hidden_size, frequency_embedding_size=256):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden_size, bias=True), nn.SiLU(),
+                                 nn.Linear(hidden_size, hidden_size, bias=True))
+
+
+class GridAttn(nn.Module):
+    def __init__(self, input_size=32, in_channels=4, hidden_size=256, output_dim=768, num_heads=8, mlp_ratio=2.0,
+                 num_layers=3, side_length=32, world_scale=0.6, z_near_far_scale=0.8, depth_scale=2.0,
+                 depth_shift=0.5, n_pts_per_ray=3, use_t=True, keep_top_k_views=False, top_k=4, device="cpu"):
+        super().__init__()
+        assert not keep_top_k_views, "top-k view selection is dead code in the reference configs"
+        assert hidden_size == 256, "the token kernel is specialised for 256-channel feature maps"
+        self.input_size, self.hidden_size, self.output_dim = input_size, hidden_size, output_dim
+        self.depth_scale, self.depth_shift, self.n_pts_per_ray = depth_scale, depth_shift, n_pts_per_ray
+        self.z_near_far_scale = z_near_far_scale
+        self.z_embedder = nn.Sequential(nn.Linear(in_channels, 256), nn.GELU())
+        self.t_embedder = _TimestepEmbedder(hidden_size)
+        self.use_t = use_t
+        self.pre_layer_b = nn.Sequential(nn.Linear(256 * 2 + 90 * 2 + 15 * 2 + 1, hidden_size), nn.GELU())
+        self.aggregation_transformer = AggregationTransformer(hidden_size, num_layers, num_heads, mlp_ratio, use_t)
+        self.final_layer_b = nn.Linear(hidden_size, output_dim)
+        for blk in self.aggregation_transformer.layer_list:      # adaLN-Zero init (:174-176)
+            nn.init.constant_(blk.adaLN_modulation[-1].weight, 0)
+            nn.init.constant_(blk.adaLN_modulation[-1].bias, 0)
+        self._p = None
+
+    def packed(self):
+        if self._p is None:
+            self._p = (hip.pack_linear(self.pre_layer_b[0].weight, self.pre_layer_b[0].bias),
+                       hip.pack_linear(self.final_layer_b.weight, self.final_layer_b.bias))
+        return self._p
+
+    def run(self, ctx, x, depth_noise, steps, it, cams_rec, in_cam_rec, input_latents, c, vol_out, V, S, D, q0=0, Vq=None):
+        """x (V,5,S,S) noisy latents; c (1,256) time conditioning (t_embed[:1]); vol_out: (>=V*S*S*D, 768) buffer
+        whose first Vq*S*S*D rows receive the feature frustum (row = ((v*S + y)*S + x)*D + d) of the query views
+        [q0, q0+Vq) (all V views by default; a view-parallel rank passes the range it owns)."""
+        Vq = V if Vq is None else Vq
+        L = hip.lib()
+        assert x.shape[1] == 5, "depth wise efficient attention requires 4+1 channels"
+        w_pre, w_fin = self.packed()
+        z = self.z_embedder[0]
+        feat = ctx.ws.get("ga.feat", (V, S, S, 256))
+        in_feat = ctx.ws.get("ga.infeat", (1, S, S, 256))
+        hip.check(L.mvd_zembed(hip.ptr(x), hip.ptr(z.weight), hip.ptr(z.bias), hip.ptr(feat), V, S, hip.stream()))
+        hip.check(L.mvd_zembed(hip.ptr(input_latents), hip.ptr(z.weight), hip.ptr(z.bias), hip.ptr(in_feat), 1, S,
+                               hip.stream()))
+        nseq = Vq * S * S * D
+        T = nseq * V
+        grid_lin = ctx.ws.bufs.get(("ga.lin", S))
+        if grid_lin is None:
+            half = 1.0 / float(S)
+            grid_lin = torch.linspace(1.0 - half, -1.0 + half, S, dtype=torch.float32).to(ctx.device)
+            ctx.ws.bufs[("ga.lin", S)] = grid_lin
+        tokens = ctx.ws.get("ga.tokens", (T, hip.TOKEN_LD))
+        hip.check(L.mvd_gridattn_tokens(hip.ptr(x), hip.ptr(depth_noise), hip.ptr(steps), hip.ptr(it), hip.ptr(grid_lin),
+                                        hip.ptr(feat), hip.ptr(in_feat), hip.ptr(cams_rec), hip.ptr(in_cam_rec),
+                                        hip.ptr(tokens), V, q0, Vq, S, D, float(self.depth_scale), float(self.depth_shift),
+                                        hip.stream()))
+        h = ctx.ws.get("ga.h", (T, self.hidden_size))
+        h_alt = ctx.ws.get("ga.h_alt", (T, self.hidden_size))
+        ctx.gemm(tokens, w_pre, h, act=hip.ACT_GELU)
+        for blk in self.aggregation_transformer.layer_list:
+            h = blk.run(ctx, h, h_alt, c, T, V)
+        wl = self.aggregation_transformer.weight_layer
+        pool = ctx.ws.get("ga.pool", (nseq, self.hidden_size))
+        hip.check(L.mvd_view_pool(hip.ptr(h), hip.ptr(wl.weight), hip.ptr(wl.bias), hip.ptr(pool), nseq, V,
+                                  self.hidden_size, hip.stream()))
+        ctx.gemm(pool, w_fin, vol_out, M=nseq)
+        return vol_out

@@ -1,0 +1,252 @@
+"""CPU-only tests (`-m "not gpu"`): the oracle against the reference-generated golden vectors and analytic
+known answers, the host logic of the product package, and the C-ABI export check (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, ROOT, load_golden, load_spec, model_config, rel_err
+
+from oracle import ref_torch as O
+from mvdfusion_amd import synthetic as syn
+from mvdfusion_amd import cameras as cam
+
+
+def cams(c):
+    return {"R": c.R, "T": c.T, "f": c.focal_length, "p": c.principal_point}
+
+
+# ------------------------------------------------------------------------------------------------ oracle vs golden
+def test_oracle_schedule_bit_exact():
+    gd = load_golden("schedule")
+    tab = O.ddpm_tables()
+    dd = O.ddim_schedule(tab)
+    assert torch.equal(tab["alphas_cumprod"], gd["alphas_cumprod"])
+    assert torch.equal(dd["timesteps"], gd["ddim_timesteps"])
+    for k in ("alphas", "alphas_prev", "sigmas", "sqrt_one_minus_alphas"):
+        assert torch.equal(dd[k], gd["ddim_" + k]), k
+    for index in (49, 25, 1, 0):
+        xp, x0 = O.ddim_update(gd["x"], gd["eps"], dd, index, gd["noise"] if index > 0 else None)
+        assert torch.equal(xp, gd[f"x_prev_{index}"]) and torch.equal(x0, gd[f"x0_{index}"])
+
+
+@pytest.mark.parametrize("name,V,D,seed,tval", [("gridattn_v4_d1", 4, 1, 0, 981), ("gridattn_v3_d3", 3, 3, 1, 501)])
+def test_oracle_gridattn_vs_reference(name, V, D, seed, tval):
+    gd = load_golden(name)
+    sd = {k: v for k, v in syn.det_fill_state_dict(load_spec(32)).items() if k.startswith("view_attn.")}
+    inp = syn.make_inputs(V, 32, seed)
+    with torch.no_grad():
+        out = O.gridattn_forward(sd, "view_attn.", gd["x"], cams(inp["batch_cameras"]), gd["t_embed"],
+                                 torch.full((V,), tval, dtype=torch.long), O.ddpm_tables(), gd["depth_noise"],
+                                 inp["input_latents"], cams(inp["input_cameras"]), n_pts_per_ray=D)
+    assert rel_err(out[:, ::5, ::7, :, ::3], gd["out_strided"]) < 3e-5
+    assert abs(float(out.norm()) - float(gd["out_l2"])) / float(gd["out_l2"]) < 1e-5
+
+
+@pytest.mark.parametrize("name,mc,V,D,tval", [("unet_mc32_v4_d1", 32, 4, 1, 981), ("unet_mc32_v2_d3", 32, 2, 3, 501),
+                                              ("unet_mc64_v2_d1", 64, 2, 1, 21)])
+def test_oracle_unet_vs_reference(name, mc, V, D, tval):
+    import json
+    gd = load_golden(name)
+    spec = [(f"unet_model.unet_model.{k}", tuple(s)) for k, s in json.loads(str(gd["spec"]))]
+    sd = syn.det_fill_state_dict(spec)
+    g = torch.Generator().manual_seed(200 + int(gd["vol_seed"]))
+    x = torch.randn(V, 10, 32, 32, generator=g)
+    ctx = torch.randn(V, 1, 768, generator=g)
+    vol = torch.randn(V, 32, 32, D, 768, generator=g) * 0.5
+    with torch.no_grad():
+        out = O.unet_forward(sd, "unet_model.unet_model.", x, torch.tensor([tval]), ctx, O.volume_pyramid(vol),
+                             model_channels=mc)
+    assert rel_err(out, gd["out"]) < 1e-5
+
+
+def test_oracle_step_vs_reference():
+    gd = load_golden("step_mc32_v4_d1")
+    sd = syn.det_fill_state_dict(load_spec(32))
+    inp = syn.make_inputs(4, 32, seed=7)
+    tab = O.ddpm_tables()
+    dd = O.ddim_schedule(tab)
+    for index in (49, 0):
+        with torch.no_grad():
+            xp, x0 = O.denoise_step(sd, gd["x"], cams(inp["batch_cameras"]), inp["input_latents"],
+                                    cams(inp["input_cameras"]), inp["clip_v_embed"], tab, dd, index,
+                                    gd[f"depth_noise_{index}"], gd[f"step_noise_{index}"], cfg_scale=2.5,
+                                    unet_kw=dict(model_channels=32))
+        assert rel_err(xp, gd[f"x_prev_{index}"]) < 2e-5 and rel_err(x0, gd[f"x0_{index}"]) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ known answers
+def test_kat_camera_rig_and_rebasing():
+    gd = load_golden("cameras")
+    rig = syn.gso_rig()
+    assert rel_err(rig.R, gd["R"]) < 1e-6 and rel_err(rig.T, gd["T"]) < 1e-6
+    rel = cam.get_relative_camera(rig, [0])
+    assert rel_err(rel.R, gd["rel_R"]) < 1e-6 and rel_err(rel.T, gd["rel_T"]) < 1e-6
+    # the input camera becomes R = I, T = (0, 0, 1.5)
+    assert torch.allclose(rel.R[0], torch.eye(3), atol=1e-6)
+    assert torch.allclose(rel.T[0], torch.tensor([0.0, 0.0, 1.5]), atol=1e-6)
+    assert rel_err(rel.get_camera_center(), gd["centers"]) < 1e-6
+    assert rel_err(cam.pack_cameras(rel)[:, 16:19], gd["centers"]) < 1e-6
+
+
+def test_kat_project_unproject_roundtrip():
+    gd = load_golden("cameras")
+    R, T = gd["rel_R"], gd["rel_T"]
+    f, p = torch.full((16, 2), 2.1875), torch.zeros(16, 2)
+    assert rel_err(O.project_ndc(R, T, f, p, gd["pts"]), gd["ndc"]) < 1e-5
+    xy_d = gd["xy_d"]
+    w = O.unproject_ndc(R, T, f, p, xy_d[..., :2], xy_d[..., 2])
+    assert rel_err(w, gd["unproj"]) < 1e-5
+    for i in range(16):   # project(unproject(xy, d)) == (xy, 1/d)
+        back = O.project_ndc(R[i:i + 1], T[i:i + 1], f[i:i + 1], p[i:i + 1], w[i])[0]
+        assert torch.allclose(back[:, :2], xy_d[i, :, :2], atol=2e-5)
+        assert torch.allclose(back[:, 2], 1.0 / xy_d[i, :, 2], atol=2e-5)
+
+
+def test_kat_own_view_gather_coordinates():
+    """Ray grid is half-pixel inset but grid_sample uses align_corners=True: own-view samples land at
+    0.484375 + 0.96875*i pixels (SURVEY trap T4)."""
+    S = 32
+    lin = torch.linspace(1 - 1 / S, -1 + 1 / S, S)
+    ix = ((-lin + 1) / 2) * (S - 1)
+    assert torch.allclose(ix, 0.484375 + 0.96875 * torch.arange(S, dtype=torch.float32), atol=1e-5)
+
+
+def test_kat_harmonic_and_timestep_embedding():
+    e = O.harmonic_embedding(torch.tensor([[2.0]]))
+    w = 0.1 * 2.0 ** torch.arange(7)
+    assert e.shape == (1, 15)
+    assert torch.allclose(e[0, :7], torch.sin(2.0 * w)) and torch.allclose(e[0, 7:14], torch.cos(2.0 * w))
+    assert float(e[0, 14]) == 2.0
+    e6 = O.harmonic_embedding(torch.arange(6, dtype=torch.float32)[None])
+    assert e6.shape == (1, 90) and float(e6[0, 1 * 7 + 2]) == pytest.approx(float(torch.sin(torch.tensor(1.0 * 0.4))))
+    t = O.timestep_embedding(torch.tensor([981.0]), 320)
+    assert float(t[0, 0]) == pytest.approx(float(torch.cos(torch.tensor(981.0)))) and float(t[0, 160]) == pytest.approx(
+        float(torch.sin(torch.tensor(981.0))))
+
+
+def test_kat_ddim_tables():
+    tab = O.ddpm_tables()
+    dd = O.ddim_schedule(tab)
+    assert int(dd["timesteps"][0]) == 1 and int(dd["timesteps"][-1]) == 981
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    assert torch.equal(tab["alphas_cumprod"], torch.cumprod(1 - betas, 0))
+    assert float(dd["alphas_prev"][0]) == float(tab["alphas_cumprod"][0])
+
+
+def test_kat_kvlen1_attention_is_linear():
+    """softmax over one key == 1  =>  CrossAttention(x, ctx of length 1) == to_out(to_v(ctx))."""
+    g = torch.Generator().manual_seed(0)
+    C, H = 64, 8
+    sd = {"a.to_q.weight": torch.randn(C, C, generator=g), "a.to_k.weight": torch.randn(C, 768, generator=g),
+          "a.to_v.weight": torch.randn(C, 768, generator=g), "a.to_out.0.weight": torch.randn(C, C, generator=g),
+          "a.to_out.0.bias": torch.randn(C, generator=g)}
+    x, ctx = torch.randn(2, 10, C, generator=g), torch.randn(2, 1, 768, generator=g)
+    full = O._cross_attention(sd, "a.", x, ctx, H)
+    short = torch.nn.functional.linear(torch.nn.functional.linear(ctx, sd["a.to_v.weight"]), sd["a.to_out.0.weight"],
+                                       sd["a.to_out.0.bias"]).expand(-1, 10, -1)
+    assert torch.allclose(full, short, atol=1e-4)
+
+
+def test_kat_normal_equals_mean_plus_std_randn():
+    """torch.normal(mean, std) consumes the CPU stream exactly like mean + std*randn (SURVEY trap T2)."""
+    mean, std = torch.randn(4, 3, 8, 8), torch.rand(4, 3, 8, 8) + 0.1
+    torch.manual_seed(5)
+    a = torch.normal(mean, std=std)
+    torch.manual_seed(5)
+    b = mean + std * torch.randn(4, 3, 8, 8)
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ host logic of the product
+def test_state_dict_keys_match_reference():
+    from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
+    m = ViewFusion(**model_config(32))
+    want = dict(load_spec(32))
+    have = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("scheduler.")}
+    assert have == want
+    sched = {k for k in m.state_dict() if k.startswith("scheduler.")}
+    assert sched == {"scheduler." + k for k in ("betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod",
+                                                "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+                                                "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                                                "posterior_log_variance_clipped")}
+
+
+def test_product_scheduler_and_sampler_tables():
+    from mvdfusion_amd.scheduler import DDPMScheduler
+    from mvdfusion_amd.sampler import DDIMSampler
+    from mvdfusion_amd.engine import ddim_step_table
+    gd = load_golden("schedule")
+
+    class M:
+        scheduler = DDPMScheduler(1000)
+    s = DDIMSampler(M(), ddim_num_steps=50, ddim_eta=1.0, latent_size=32)
+    assert torch.equal(M.scheduler.alphas_cumprod, gd["alphas_cumprod"])
+    assert np.array_equal(s.ddim_timesteps, gd["ddim_timesteps"].numpy())
+    assert torch.equal(s.ddim_alphas, gd["ddim_alphas"]) and torch.equal(s.ddim_sigmas, gd["ddim_sigmas"])
+    assert torch.equal(s.ddim_alphas_prev, gd["ddim_alphas_prev"])
+    st, dd = s.tables()
+    tab = ddim_step_table(st, dd, [49, 0])
+    assert tab.shape == (2, 8) and float(tab[0, 0]) == 981.0 and float(tab[1, 0]) == 1.0
+    assert float(tab[0, 7]) == 1.0 and float(tab[1, 7]) == 0.0
+    x, eps = gd["x"], gd["eps"]
+    torch.manual_seed(77)
+    xp, x0 = s.denoise_apply_impl(x, 25, eps)
+    assert torch.equal(xp, gd["x_prev_25"]) and torch.equal(x0, gd["x0_25"])
+
+
+def test_factory_resolves_reference_targets():
+    from mvdfusion_amd.load_model import instantiate_from_config, get_obj_from_str
+    from mvdfusion_amd.scheduler import DDPMScheduler
+    from mvdfusion_amd.unet import UNetModel
+    assert get_obj_from_str("mvdfusion.unet.UNetModel") is UNetModel
+    s = instantiate_from_config({"target": "mvdfusion.scheduler.DDPMScheduler", "params": {"timesteps": 1000}})
+    assert isinstance(s, DDPMScheduler)
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
+    m = ViewFusion(**model_config(32))
+    inp = syn.make_inputs(2, 32, 0)
+    with pytest.raises(RuntimeError):
+        m.apply_model(inp["x_T"], inp["batch_cameras"], inp["input_latents"], inp["input_cameras"], inp["clip_v_embed"],
+                      torch.full((2,), 981))
+
+
+def test_det_fill_is_stable_and_nonzero():
+    a = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))
+    b = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))
+    assert torch.equal(a, b) and float(a.abs().min()) > 0
+    assert abs(float(syn.det_fill("x.norm1.weight", (64,)).mean()) - 1.0) < 0.1
+
+
+def test_view_range_partition():
+    from mvdfusion_amd.parallel import view_range
+    for V in (4, 8, 15):
+        for world in (1, 2, 4, 8):
+            rs = [view_range(V, r, world) for r in range(world)]
+            assert sum(n for _, n in rs) == V
+            assert all(rs[i][0] + rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_c_abi_library_exports_every_declared_symbol():
+    from mvdfusion_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "mvd_hip.h")).read()
+    declared = set(re.findall(r"\b(mvd_[a-z0-9_]+)\s*\(", hdr)) - {"mvd_gemm_desc"}
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    if not os.path.exists(hip.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.lib().mvd_version() == 100
+    assert hip.lib().mvd_packed_weight_bytes(320, 2880) == 320 * 2880 * 4
+    assert hip.lib().mvd_attn_lpad(1000) == 1024
+    assert ctypes.sizeof(hip.GemmDesc) > 0

@@ -1,0 +1,278 @@
+"""Per-kernel parity: every HIP op (called through the C ABI) against a plain fp32 PyTorch-CPU statement of the same
+op.  Tolerances (relative to the max magnitude of the reference tensor):
+  exact-fp32 VALU kernels ................ 2e-6
+  bf16x3 MFMA kernels (~16-bit operands) . 3e-5
+  bf16 MFMA kernels ...................... 2e-2
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {1: 2e-2, 3: 3e-5}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mvdfusion_amd import hip as h
+    assert h.lib().mvd_version() == 100
+    return h
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("M,N,K", [(2048, 320, 320), (128, 1280, 2560), (100, 48, 96), (4096, 256, 736), (64, 16, 32)])
+def test_gemm_dense(hip, prec, M, N, K):
+    A = torch.randn(M, K, generator=g(1))
+    W = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(3))
+    R = torch.randn(M, N, generator=g(4))
+    ref = F.linear(A, W, b) + R
+    Wp = hip.pack_linear(W.cuda(), b.cuda())
+    out = torch.empty(M, N, device="cuda")
+    ws = torch.empty(8 * 1024 * 1024, device="cuda")
+    hip.gemm(A.cuda(), Wp, out, prec=prec, res=R.cuda(), workspace=ws)
+    assert rel_err(out, ref) < TOL[prec]
+    # forced split-K and no split must agree with the reference as well
+    for sk in (1, 4):
+        out.zero_()
+        hip.gemm(A.cuda(), Wp, out, prec=prec, res=R.cuda(), workspace=ws, splitk=sk)
+        assert rel_err(out, ref) < TOL[prec], sk
+
+
+def test_gemm_epilogues(hip):
+    M, C = 512, 320
+    A = torch.randn(M, C, generator=g(5))
+    W = torch.randn(C, C, generator=g(6)) / math.sqrt(C)
+    b = torch.randn(C, generator=g(7))
+    gate = torch.randn(C, generator=g(8))
+    R = torch.randn(M, C, generator=g(9))
+    bb = torch.randn(4, C, generator=g(10))
+    Wp = hip.pack_linear(W.cuda(), b.cuda())
+    out = torch.empty(M, C, device="cuda")
+    ws = torch.empty(4 * 1024 * 1024, device="cuda")
+    # gate * (acc + bias) + residual  (adaLN gate)
+    hip.gemm(A.cuda(), Wp, out, res=R.cuda(), colscale=gate.cuda(), workspace=ws)
+    assert rel_err(out, R + gate * F.linear(A, W, b)) < 3e-5
+    # GELU / SiLU
+    hip.gemm(A.cuda(), Wp, out, act=hip.ACT_GELU, workspace=ws)
+    assert rel_err(out, F.gelu(F.linear(A, W, b))) < 3e-5
+    hip.gemm(A.cuda(), Wp, out, act=hip.ACT_SILU, workspace=ws)
+    assert rel_err(out, F.silu(F.linear(A, W, b))) < 3e-5
+    # per-batch bias vector (kv_len == 1 cross attention)
+    hip.gemm(A.cuda(), Wp, out, bias_b=bb.cuda(), rows_per_batch=M // 4, workspace=ws)
+    assert rel_err(out, F.linear(A, W, b) + bb.repeat_interleave(M // 4, 0)) < 3e-5
+
+
+@pytest.mark.parametrize("splitk", [0, 1, 3])
+def test_gemm_geglu(hip, splitk):
+    M, C = 256, 64
+    A = torch.randn(M, C, generator=g(11))
+    W = torch.randn(8 * C, C, generator=g(12)) / math.sqrt(C)
+    b = torch.randn(8 * C, generator=g(13))
+    h = F.linear(A, W, b)
+    a, gt = h.chunk(2, dim=-1)
+    ref = a * F.gelu(gt)
+    Wp = hip.pack_linear(W.cuda(), b.cuda(), geglu=True)
+    out = torch.empty(M, 4 * C, device="cuda")
+    ws = torch.empty(4 * 1024 * 1024, device="cuda")
+    # GEGLU bias is addressed by logical column: pass the unpermuted bias
+    hip.gemm(A.cuda(), Wp, out, epi=hip.EPI_GEGLU, workspace=ws, splitk=splitk)
+    assert rel_err(out, ref) < 3e-5
+
+
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("case", ["s1", "s2", "up", "smallM", "stem", "head"])
+def test_conv3x3(hip, prec, case):
+    B, H, Cin, Cout, stride, up = {"s1": (4, 16, 64, 96, 1, 0), "s2": (2, 16, 64, 64, 2, 0), "up": (2, 8, 64, 64, 1, 1),
+                                   "smallM": (2, 4, 2560, 1280, 1, 0), "stem": (2, 32, 10, 320, 1, 0),
+                                   "head": (2, 32, 320, 5, 1, 0)}[case]
+    x = torch.randn(B, Cin, H, H, generator=g(20))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(21)) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g(22))
+    xi = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xi, w, b, stride=stride, padding=1)
+    Ho = ref.shape[-1]
+    cin_pad = (Cin + 31) // 32 * 32
+    xn = torch.zeros(B, H, H, cin_pad)
+    xn[..., :Cin] = x.permute(0, 2, 3, 1)
+    Wp = hip.pack_conv3x3(w.cuda(), b.cuda())
+    ldo = 8 if Cout < 8 else Cout
+    out = torch.zeros(B * Ho * Ho, ldo, device="cuda")
+    ws = torch.empty(16 * 1024 * 1024, device="cuda")
+    hip.gemm(xn.cuda(), Wp, out, prec=prec, workspace=ws, ldo=ldo,
+             conv=dict(B=B, Hin=H, Win=H, Cin=cin_pad, Hout=Ho, Wout=Ho, stride=stride, upsample=up))
+    got = out[:, :Cout].view(B, Ho, Ho, Cout).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < TOL[prec]
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("B,HW,C,silu,eps", [(4, 1024, 320, True, 1e-5), (2, 256, 1920, True, 1e-5), (3, 64, 1280, False, 1e-6),
+                                             (2, 16, 2560, True, 1e-5), (2, 1024, 32, False, 1e-6)])
+def test_groupnorm(hip, B, HW, C, silu, eps):
+    x = torch.randn(B, HW, C, generator=g(30)) * 2 + 0.5
+    gm, bt = torch.randn(C, generator=g(31)), torch.randn(C, generator=g(32))
+    ref = F.group_norm(x.permute(0, 2, 1), 32, gm, bt, eps=eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    y = torch.empty(B, HW, C, device="cuda")
+    ws = torch.empty(64 * 64 * 32 * 2, dtype=torch.float64, device="cuda")
+    hip.groupnorm(x.cuda(), y, gm.cuda(), bt.cuda(), B, HW, C, eps, silu, ws)
+    assert rel_err(y, ref) < 5e-6
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (64, 1280), (4096, 256), (37, 640), (16, 32)])
+def test_layernorm(hip, rows, C):
+    x = torch.randn(rows, C, generator=g(33)) * 3 + 1
+    w, b = torch.randn(C, generator=g(34)), torch.randn(C, generator=g(35))
+    y = torch.empty(rows, C, device="cuda")
+    hip.layernorm(x.cuda(), y, w.cuda(), b.cuda(), rows, C, eps=1e-5)
+    assert rel_err(y, F.layer_norm(x, (C,), w, b, eps=1e-5)) < 5e-6
+    hip.layernorm(x.cuda(), y, w.cuda(), b.cuda(), rows, C, eps=1e-6, w_plus_one=True)   # adaLN modulate
+    assert rel_err(y, F.layer_norm(x, (C,), eps=1e-6) * (1 + w) + b) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("B,H,L,d", [(2, 8, 1024, 40), (2, 8, 256, 80), (3, 8, 64, 160), (2, 8, 16, 160), (2, 8, 1024, 4),
+                                     (1, 8, 256, 8), (1, 8, 64, 16), (1, 8, 256, 32)])
+def test_qkv_gemm_and_attention(hip, prec, B, H, L, d):
+    """QKV GEMM with the routing epilogue + flash attention == CrossAttention(context=None) core (attention.py:170-193)."""
+    C = H * d
+    x = torch.randn(B * L, C, generator=g(40))
+    wq, wk, wv = (torch.randn(C, C, generator=g(41 + i)) / math.sqrt(C) * 1.5 for i in range(3))
+    q, k, v = (F.linear(x, w).view(B, L, H, d).permute(0, 2, 1, 3) for w in (wq, wk, wv))
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).permute(0, 2, 1, 3).reshape(B * L, C)
+    Wp = hip.pack_linear_cat([wq.cuda(), wk.cuda(), wv.cuda()])
+    planes = hip.alloc_attn_planes(B, H, L, d, "cuda")
+    ws = torch.empty(16 * 1024 * 1024, device="cuda")
+    hip.gemm(x.cuda(), Wp, None, prec=prec, epi=hip.EPI_QKV, qkv=dict(planes=planes, heads=H, dhead=d, L=L), workspace=ws)
+    out = torch.empty(B * L, C, device="cuda")
+    hip.attention(planes, out, B, H, L, d, prec=prec)
+    assert rel_err(out, ref) < (5e-5 if prec == 3 else 3e-2)
+
+
+def test_attention_forced_rescale(hip):
+    """A key whose score dominates late in the sequence forces the online-softmax rescale path."""
+    B, H, L, d = 1, 8, 256, 40
+    C = H * d
+    x = torch.randn(B * L, C, generator=g(50))
+    x[200] *= 12.0
+    wq = torch.eye(C)
+    q, k, v = (x.view(B, L, H, d).permute(0, 2, 1, 3) for _ in range(3))
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).permute(0, 2, 1, 3).reshape(B * L, C)
+    Wp = hip.pack_linear_cat([wq.cuda(), wq.cuda(), wq.cuda()])
+    planes = hip.alloc_attn_planes(B, H, L, d, "cuda")
+    hip.gemm(x.cuda(), Wp, None, epi=hip.EPI_QKV, qkv=dict(planes=planes, heads=H, dhead=d, L=L))
+    out = torch.empty(B * L, C, device="cuda")
+    hip.attention(planes, out, B, H, L, d)
+    assert rel_err(out, ref) < 5e-5
+
+
+@pytest.mark.parametrize("D", [1, 3])
+def test_pixel_cross_attn(hip, D):
+    P, H, d = 300, 8, 40
+    C = H * d
+    q = torch.randn(P, C, generator=g(60))
+    k = torch.randn(P * D, C, generator=g(61))
+    v = torch.randn(P * D, C, generator=g(62))
+    qq = q.view(P, 1, H, d).permute(0, 2, 1, 3)
+    kk, vv = (t.view(P, D, H, d).permute(0, 2, 1, 3) for t in (k, v))
+    sim = torch.einsum("phid,phjd->phij", qq, kk) * d ** -0.5
+    ref = torch.einsum("phij,phjd->phid", sim.softmax(-1), vv).permute(0, 2, 1, 3).reshape(P, C)
+    out = torch.empty(P, C, device="cuda")
+    hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q.cuda()), hip.ptr(k.cuda()), hip.ptr(v.cuda()), hip.ptr(out), P, D, H, d,
+                                             hip.stream()))
+    assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("V", [4, 8, 3])
+def test_view_mha_and_pool(hip, V):
+    N, H, d = 500, 8, 32
+    C = H * d
+    qkv = torch.randn(N * V, 3 * C, generator=g(70))
+    t = qkv.view(N, V, 3, H, d).permute(2, 0, 3, 1, 4)
+    q, k, v = t.unbind(0)
+    ref = (((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(N * V, C)
+    out = torch.empty(N * V, C, device="cuda")
+    hip.check(hip.lib().mvd_view_mha(hip.ptr(qkv.cuda()), hip.ptr(out), N, V, H, d, hip.stream()))
+    assert rel_err(out, ref) < 2e-6
+    x = torch.randn(N, V, C, generator=g(71))
+    w, b = torch.randn(1, C, generator=g(72)) * 0.2, torch.randn(1, generator=g(73))
+    wt = F.linear(x, w, b).softmax(dim=-2)
+    refp = (x * wt).sum(-2)
+    outp = torch.empty(N, C, device="cuda")
+    hip.check(hip.lib().mvd_view_pool(hip.ptr(x.cuda()), hip.ptr(w.cuda()), hip.ptr(b.cuda()), hip.ptr(outp), N, V, C,
+                                      hip.stream()))
+    assert rel_err(outp, refp) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ small kernels
+@pytest.mark.parametrize("M,N,K", [(1, 1280, 320), (8, 768, 796), (16, 1280, 1280), (3, 50, 7)])
+def test_gemv(hip, M, N, K):
+    W, b, x = torch.randn(N, K, generator=g(80)), torch.randn(N, generator=g(81)), torch.randn(M, K, generator=g(82))
+    y = torch.empty(M, N, device="cuda")
+    hip.gemv(W.cuda(), b.cuda(), x.cuda(), y, act_in=hip.ACT_SILU, act_out=hip.ACT_SILU)
+    assert rel_err(y, F.silu(F.linear(F.silu(x), W, b))) < 3e-6
+
+
+def test_area_pool_concat_input(hip):
+    B, S, D, C = 2, 32, 3, 768
+    vol = torch.randn(B, S, S, D, C, generator=g(90))
+    v = vol.permute(0, 3, 4, 1, 2).reshape(B * D, C, S, S)
+    for f in (2, 4, 8):
+        ref = F.interpolate(v, scale_factor=1.0 / f, mode="area").reshape(B, D, C, S // f, S // f).permute(0, 3, 4, 1, 2)
+        out = torch.empty(B, S // f, S // f, D, C, device="cuda")
+        hip.check(hip.lib().mvd_area_pool(hip.ptr(vol.cuda()), hip.ptr(out), B, S, D, C, f, hip.stream()))
+        assert rel_err(out, ref) < 1e-6
+    a, b = torch.randn(100, 320, generator=g(91)), torch.randn(100, 640, generator=g(92))
+    out = torch.empty(100, 960, device="cuda")
+    hip.check(hip.lib().mvd_concat_channels(hip.ptr(a.cuda()), 320, hip.ptr(b.cuda()), 640, hip.ptr(out), 100, hip.stream()))
+    assert torch.equal(out.cpu(), torch.cat([a, b], 1))
+    V, S = 3, 32
+    x, il = torch.randn(V, 5, S, S, generator=g(93)), torch.randn(1, 5, S, S, generator=g(94))
+    xi = torch.empty(2 * V, S, S, 32, device="cuda")
+    hip.check(hip.lib().mvd_unet_input(hip.ptr(x.cuda()), hip.ptr(il.cuda()), hip.ptr(xi), V, S, 32, 1, hip.stream()))
+    xc = il.expand(V, -1, -1, -1).clone()
+    xc[:, :4] = xc[:, :4] / 0.18215
+    ref = torch.zeros(2 * V, 32, S, S)
+    ref[:V, :10] = torch.cat([x, xc], 1)
+    ref[V:, :5] = x
+    assert rel_err(xi.permute(0, 3, 1, 2), ref) < 1e-6
+
+
+def test_cfg_ddim_update_golden(hip):
+    """CFG combine + DDIM update against the reference's denoise_apply_impl outputs (tests/golden/schedule.npz)."""
+    from mvdfusion_amd.engine import ddim_step_table
+    from mvdfusion_amd.scheduler import make_tables
+    gd = load_golden("schedule")
+    tab = make_tables()
+    dd = {"timesteps": gd["ddim_timesteps"], "alphas": gd["ddim_alphas"], "alphas_prev": gd["ddim_alphas_prev"],
+          "sigmas": gd["ddim_sigmas"], "sqrt_one_minus_alphas": gd["ddim_sqrt_one_minus_alphas"]}
+    V, S = 2, 8
+    for index in (49, 25, 1, 0):
+        steps = ddim_step_table(tab, dd, [index]).cuda()
+        it = torch.zeros(1, dtype=torch.int32, device="cuda")
+        x = gd["x"].clone().cuda()
+        x0 = torch.empty_like(x)
+        eps = gd["eps"]
+        # fake "UNet head" layout: (2V, S, S, 8) with cond == uncond == eps  => guided eps == eps for any scale
+        e = torch.zeros(2 * V, S, S, 8)
+        e[:V, ..., :5] = eps.permute(0, 2, 3, 1)
+        e[V:, ..., :5] = eps.permute(0, 2, 3, 1)
+        noise = gd["noise"].reshape(1, V, 5, S, S).cuda()
+        hip.check(hip.lib().mvd_cfg_ddim_update(hip.ptr(e.cuda()), 8, hip.ptr(x), hip.ptr(x0), None, hip.ptr(noise),
+                                                V * 5 * S * S, hip.ptr(steps), hip.ptr(it), V, S, 1, 2.5, 1, hip.stream()))
+        assert rel_err(x, gd[f"x_prev_{index}"]) < 2e-6
+        assert rel_err(x0, gd[f"x0_{index}"]) < 2e-6
