@@ -192,8 +192,8 @@ def test_pixel_cross_attn(hip, D):
     sim = torch.einsum("phid,phjd->phij", qq, kk) * d ** -0.5
     ref = torch.einsum("phij,phjd->phid", sim.softmax(-1), vv).permute(0, 2, 1, 3).reshape(P, C)
     out = torch.empty(P, C, device="cuda")
-    hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q.cuda()), hip.ptr(k.cuda()), hip.ptr(v.cuda()), hip.ptr(out), P, D, H, d,
-                                             hip.stream()))
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()      # keep the device tensors alive across the raw-pointer call
+    hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(qc), hip.ptr(kc), hip.ptr(vc), hip.ptr(out), P, D, H, d, hip.stream()))
     assert rel_err(out, ref) < 2e-6
 
 
@@ -206,15 +206,16 @@ def test_view_mha_and_pool(hip, V):
     q, k, v = t.unbind(0)
     ref = (((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(N * V, C)
     out = torch.empty(N * V, C, device="cuda")
-    hip.check(hip.lib().mvd_view_mha(hip.ptr(qkv.cuda()), hip.ptr(out), N, V, H, d, hip.stream()))
+    qkvc = qkv.cuda()
+    hip.check(hip.lib().mvd_view_mha(hip.ptr(qkvc), hip.ptr(out), N, V, H, d, hip.stream()))
     assert rel_err(out, ref) < 2e-6
     x = torch.randn(N, V, C, generator=g(71))
     w, b = torch.randn(1, C, generator=g(72)) * 0.2, torch.randn(1, generator=g(73))
     wt = F.linear(x, w, b).softmax(dim=-2)
     refp = (x * wt).sum(-2)
     outp = torch.empty(N, C, device="cuda")
-    hip.check(hip.lib().mvd_view_pool(hip.ptr(x.cuda()), hip.ptr(w.cuda()), hip.ptr(b.cuda()), hip.ptr(outp), N, V, C,
-                                      hip.stream()))
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    hip.check(hip.lib().mvd_view_pool(hip.ptr(xc), hip.ptr(wc), hip.ptr(bc), hip.ptr(outp), N, V, C, hip.stream()))
     assert rel_err(outp, refp) < 2e-6
 
 
@@ -234,16 +235,19 @@ def test_area_pool_concat_input(hip):
     for f in (2, 4, 8):
         ref = F.interpolate(v, scale_factor=1.0 / f, mode="area").reshape(B, D, C, S // f, S // f).permute(0, 3, 4, 1, 2)
         out = torch.empty(B, S // f, S // f, D, C, device="cuda")
-        hip.check(hip.lib().mvd_area_pool(hip.ptr(vol.cuda()), hip.ptr(out), B, S, D, C, f, hip.stream()))
+        volc = vol.cuda()
+        hip.check(hip.lib().mvd_area_pool(hip.ptr(volc), hip.ptr(out), B, S, D, C, f, hip.stream()))
         assert rel_err(out, ref) < 1e-6
     a, b = torch.randn(100, 320, generator=g(91)), torch.randn(100, 640, generator=g(92))
     out = torch.empty(100, 960, device="cuda")
-    hip.check(hip.lib().mvd_concat_channels(hip.ptr(a.cuda()), 320, hip.ptr(b.cuda()), 640, hip.ptr(out), 100, hip.stream()))
+    ac, bc = a.cuda(), b.cuda()
+    hip.check(hip.lib().mvd_concat_channels(hip.ptr(ac), 320, hip.ptr(bc), 640, hip.ptr(out), 100, hip.stream()))
     assert torch.equal(out.cpu(), torch.cat([a, b], 1))
     V, S = 3, 32
     x, il = torch.randn(V, 5, S, S, generator=g(93)), torch.randn(1, 5, S, S, generator=g(94))
     xi = torch.empty(2 * V, S, S, 32, device="cuda")
-    hip.check(hip.lib().mvd_unet_input(hip.ptr(x.cuda()), hip.ptr(il.cuda()), hip.ptr(xi), V, S, 32, 1, hip.stream()))
+    xc, ilc = x.cuda(), il.cuda()
+    hip.check(hip.lib().mvd_unet_input(hip.ptr(xc), hip.ptr(ilc), hip.ptr(xi), V, S, 32, 1, hip.stream()))
     xc = il.expand(V, -1, -1, -1).clone()
     xc[:, :4] = xc[:, :4] / 0.18215
     ref = torch.zeros(2 * V, 32, S, S)
@@ -272,7 +276,8 @@ def test_cfg_ddim_update_golden(hip):
         e[:V, ..., :5] = eps.permute(0, 2, 3, 1)
         e[V:, ..., :5] = eps.permute(0, 2, 3, 1)
         noise = gd["noise"].reshape(1, V, 5, S, S).cuda()
-        hip.check(hip.lib().mvd_cfg_ddim_update(hip.ptr(e.cuda()), 8, hip.ptr(x), hip.ptr(x0), None, hip.ptr(noise),
+        ec = e.cuda()
+        hip.check(hip.lib().mvd_cfg_ddim_update(hip.ptr(ec), 8, hip.ptr(x), hip.ptr(x0), None, hip.ptr(noise),
                                                 V * 5 * S * S, hip.ptr(steps), hip.ptr(it), V, S, 1, 2.5, 1, hip.stream()))
         assert rel_err(x, gd[f"x_prev_{index}"]) < 2e-6
         assert rel_err(x0, gd[f"x0_{index}"]) < 2e-6
