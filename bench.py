@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""bench.py -- denoising-steps/sec of the MI355X-native MVD-Fusion hot path (BASELINE.json metric).
+
+A "step" is one DDIM iteration for all V views: GridAttn (depth unproject / reproject / cross-view aggregation) +
+the classifier-free-guidance pair of view-conditioned UNet passes (batched as 2V) + CFG combine + DDIM update, i.e.
+one replay of the captured hipGraph (DDIMSampler.sample's loop body, mvdfusion/sampler.py:119-142).
+
+  N=1  : BASELINE.json configs[1] -- V=4 views x 256^2 images (32x32 latents), D=1, cfg 2.5, full-width SD1.x UNet.
+  N>1  : BASELINE.json configs[2] -- V=8 views sharded by view over the N ranks (one process per GPU), one RCCL
+         all-gather of the updated latent rows per step (mvdfusion_amd/parallel.py).  Total work is fixed => "strong".
+
+Weights: deterministic non-zero synthetic fill of the real architecture (no checkpoints offline); data: synthetic GSO rig.
+Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel, HIP-event timed, algorithmic FLOPs against
+the dense bf16 MFMA peak) and `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+MFMA_BF16_DENSE_PEAK = 2.5e15  # FLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (dense; not the 2:1-sparse figure)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build(V, S, D, precision, sd=None):
+    from conftest import load_spec, model_config
+    from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
+    t0 = time.time()
+    if sd is None:
+        sd = syn.det_fill_state_dict(load_spec(320))
+    m = ViewFusion(**model_config(320, D=D, S=S, precision=precision))
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("scheduler.") for k in missing), (missing[:5], unexpected[:5])
+    m = m.cuda().eval()
+    log(f"[bench] model built in {time.time() - t0:.1f}s")
+    return m, sd
+
+
+def prepare(m, V, S, D, cfg_scale, q0=0, Vq=None, seed=0):
+    from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.engine import ddim_step_table
+    inp = syn.make_inputs(V, S, seed=seed)
+    dn, sn = syn.step_noise(V, S, D, 50, seed=seed)
+    eng = m.engine(V, S, D, cfg_scale != 1.0, q0=q0, Vq=Vq)
+    eng.set_conditioning(inp["batch_cameras"], inp["input_latents"].cuda(), inp["input_cameras"], inp["clip_v_embed"].cuda())
+    st, dd = m.ddim.tables()
+    eng.set_schedule(ddim_step_table(st, dd, [49 - i for i in range(50)]), dn, sn)
+    eng.x.copy_(inp["x_T"])
+    return eng, inp, dn, sn
+
+
+def run_steps(eng, n, cfg_scale, exchange=None, use_graph=True):
+    """n DDIM iterations (wrapping to a fresh sample every 50)."""
+    done = int(eng.iter.item())
+    for _ in range(n):
+        if done == 50:
+            eng.iter.zero_()
+            done = 0
+        eng.step(cfg_scale, do_update=True, use_graph=use_graph)
+        if exchange is not None:
+            exchange.gather(eng.x)
+        done += 1
+
+
+def profile_gemm_kernels(eng, cfg_scale):
+    """One eager (non-graph) step with HIP events around every mvd_gemm launch on the launch stream."""
+    from mvdfusion_amd import hip
+    recs = []
+    real = hip.gemm
+
+    def timed(A, W, out=None, **kw):
+        e0, e1 = hip.Event(), hip.Event()
+        e0.record()
+        r = real(A, W, out, **kw)
+        e1.record()
+        conv = kw.get("conv")
+        M = conv["B"] * conv["Hout"] * conv["Wout"] if conv else int(kw.get("M") or A.numel() // A.shape[-1])
+        N = W.n_real
+        Kp = W.K
+        big = M >= 1024 and W.N >= 128
+        bm = 128 if big else 64
+        tiles = -(-M // bm) * -(-W.N // bm)
+        split = kw.get("splitk", 0) == 0 and tiles < 256 and Kp // 32 >= 8
+        recs.append(dict(sym=f"gemm_kernel<{bm},{bm},{kw.get('prec', 3)},{1 if conv else 0}>", M=M, N=N, K=Kp,
+                         flops=2.0 * M * N * Kp, split=split, ev=(e0, e1)))
+        return r
+
+    hip.gemm = timed
+    try:
+        it = eng.iter.clone()
+        x = eng.x.clone()
+        eng.step(cfg_scale, do_update=True, use_graph=False)
+        torch.cuda.synchronize()
+        eng.iter.copy_(it)
+        eng.x.copy_(x)
+    finally:
+        hip.gemm = real
+    by = {}
+    for r in recs:
+        ms = r["ev"][0].elapsed_ms(r["ev"][1])
+        b = by.setdefault(r["sym"], dict(n=0, ms=0.0, flops=0.0, n_split=0))
+        b["n"] += 1
+        b["ms"] += ms
+        b["flops"] += r["flops"]
+        b["n_split"] += int(r["split"])
+    return by
+
+
+def cpu_baseline(sd, V, S, D, cfg_scale, n_timed=1):
+    """The CPU oracle (port of the reference path, pinned to it by tests/golden) on this host's cores."""
+    from mvdfusion_amd import synthetic as syn
+    from oracle import ref_torch as O
+    # PyTorch eager on "all host cores" collapses on a 256-core box (415 s/step measured: thread oversubscription on
+    # ~3000 small ops); 16 threads is near the sweet spot and is what `cores` reports.
+    torch.set_num_threads(min(16, os.cpu_count()))
+    inp = syn.make_inputs(V, S, seed=0)
+    dn, sn = syn.step_noise(V, S, D, 50, seed=0)
+    tab = O.ddpm_tables()
+    dd = O.ddim_schedule(tab)
+    cams = lambda c: {"R": c.R, "T": c.T, "f": c.focal_length, "p": c.principal_point}
+    x = inp["x_T"]
+    times = []
+    with torch.no_grad():
+        for i in range(1 + n_timed):
+            t0 = time.time()
+            x, _ = O.denoise_step(sd, x, cams(inp["batch_cameras"]), inp["input_latents"], cams(inp["input_cameras"]),
+                                  inp["clip_v_embed"], tab, dd, 49 - i, dn[i], sn[i], cfg_scale=cfg_scale, n_pts_per_ray=D)
+            times.append(time.time() - t0)
+    dt = sum(times[1:]) / n_timed
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_timed} timed DDIM steps (+1 warm-up) of the same V={V} workload, fp32 PyTorch eager, "
+                      f"{dt:.2f} s/step"}, x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=None)
+    ap.add_argument("--latent", type=int, default=32)
+    ap.add_argument("--depth-samples", type=int, default=1)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    N = max(a.gpus, world) if world > 1 else 1
+    V = a.views or (4 if N == 1 else 8)
+    S, D, cfg_scale = a.latent, a.depth_samples, 2.5
+
+    from mvdfusion_amd import hip
+    from mvdfusion_amd.parallel import ViewExchange
+    m, sd = build(V, S, D, a.precision)
+    ex = ViewExchange(V) if world > 1 else None
+    q0, Vq = (ex.q0, ex.Vq) if ex else (0, None)
+    eng, inp, dn, sn = prepare(m, V, S, D, cfg_scale, q0=q0, Vq=Vq)
+    graph = not a.no_graph
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run_steps(eng, a.warmup, cfg_scale, ex, graph)
+    sync()
+    ev0, ev1 = hip.Event(), hip.Event()
+    t0 = time.perf_counter()
+    ev0.record()
+    run_steps(eng, a.steps, cfg_scale, ex, graph)
+    ev1.record()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = dt * 1e3 / a.steps
+    gpu_ms = ev0.elapsed_ms(ev1) / a.steps
+
+    out = None
+    if rank == 0:
+        from mvdfusion_amd.hip import PREC_BF16X3
+        f_unet = {32: 225.09e9, 64: 1047.09e9}.get(S, 225.09e9 * (S / 32) ** 2) if D == 1 else 235.81e9
+        T = V * V * S * S * D
+        f_grid = T * (3516416 + 3072 * V) + V * S * S * D * 393216 + (V + 1) * S * S * 2560
+        step_flops = 2 * V * f_unet + f_grid
+        out = {
+            "metric": "denoising-steps/sec", "value": a.steps / dt, "unit": "steps/s", "n_gpus": N, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong" if N > 1 else "weak", "vs_baseline": None,
+            "dtype": "bf16x3 (split-bf16 MFMA operands, 3 products, fp32 accumulate)" if a.precision == "bf16x3" else "bf16",
+            "data": "synthetic",
+            "config": {"workload": (f"BASELINE.json configs[{1 if N == 1 else 2}]: V={V} views x {8 * S}^2 images "
+                                    f"({S}x{S} latents), D={D}, 50-step DDIM (eta 1), cfg {cfg_scale}, SD1.x UNet 320ch "
+                                    "+ 10 view-aligned transformers + GridAttn, random-init (deterministic fill) weights"),
+                       "views": V, "latent": S, "depth_samples": D, "cfg_scale": cfg_scale,
+                       "parallelism": "single GPU, CFG pair batched as 2V" if N == 1 else
+                       f"view-parallel: {V} views over {N} GPUs, 1 RCCL all-gather of latent rows per step",
+                       "hipgraph": graph},
+            "gpu_ms_per_step_hip_events": gpu_ms,
+            "algorithmic_tflop_per_step": step_flops / 1e12,
+            "algorithmic_tflops": step_flops / (dt / a.steps) / 1e12,
+        }
+    # ---- roofline of the dominant kernel (N == 1 only; HIP events around each launch on the launch stream)
+    if world == 1:
+        by = profile_gemm_kernels(eng, cfg_scale)
+        tot = sum(b["ms"] for b in by.values())
+        for k, b in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
+            log(f"[bench] {k:34s} launches {b['n']:4d} (split-K {b['n_split']:3d})  total {b['ms']:8.3f} ms  "
+                f"avg {b['ms'] / b['n'] * 1e3:8.1f} us  {b['flops'] / b['ms'] / 1e9:8.1f} TFLOP/s algorithmic")
+        dom, b = max(by.items(), key=lambda kv: kv[1]["ms"])
+        ach = b["flops"] / (b["ms"] * 1e-3)
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": b["n"],
+                           "avg_launch_us": b["ms"] / b["n"] * 1e3, "achieved": ach / 1e12, "peak": MFMA_BF16_DENSE_PEAK / 1e12,
+                           "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK, "traffic": None,
+                           "note": "algorithmic FLOPs = 2*M*N*K of the fp32 problem; the bf16x3 kernel issues 3 MFMA "
+                                   "products per algorithmic MAC, so its MFMA-pipe utilisation is 3x this fraction",
+                           "gemm_share_of_step_ms": tot}
+        if not a.no_cpu_baseline:
+            cb, _ = cpu_baseline(sd, V, S, D, cfg_scale)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+    else:
+        # view-parallel speed-up reference: the same V-view workload on ONE GPU (rank 0), unsharded
+        if rank == 0:
+            eng1, *_ = prepare(m, V, S, D, cfg_scale)
+            run_steps(eng1, a.warmup, cfg_scale, None, graph)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(eng1, a.steps, cfg_scale, None, graph)
+            torch.cuda.synchronize()
+            v1 = a.steps / (time.perf_counter() - t1)
+            out["view_parallel"] = {"views": V, "single_gpu_same_workload_steps_per_s": v1,
+                                    "speedup_over_single_gpu": out["value"] / v1}
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

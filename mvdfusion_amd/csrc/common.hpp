@@ -45,8 +45,11 @@ __device__ __forceinline__ u16 f32_to_bf16_rne(float f) {
 __device__ __forceinline__ float bf16_to_f32(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 __device__ __forceinline__ void split_bf16(float x, u16& hi, u16& lo) {
-  hi = f32_to_bf16_rne(x);
-  lo = f32_to_bf16_rne(x - bf16_to_f32(hi));
+  // compiler-native conversions (v_cvt_pk_bf16_f32 on gfx950, round-to-nearest-even)
+  const __bf16 h = (__bf16)x;
+  const __bf16 l = (__bf16)(x - (float)h);
+  hi = __builtin_bit_cast(u16, h);
+  lo = __builtin_bit_cast(u16, l);
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -8,6 +8,8 @@
 //   and by the other resident workgroups); LDS rows are padded to 80 B so the 16-lane ds_read_b128 groups
 //   spread over all banks.
 // NS = 1: acc += A_hi*B_hi.  NS = 3: acc += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi  (fp32 accumulate).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/mvd_hip.h"
 
@@ -384,15 +386,18 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   }
   p.nk = d.K / 32;
   p.nt16 = d.N / 16;
-  const bool big = d.M >= 1024 && d.N >= 128;
+  // 64x64 tiles (5 waves/SIMD resident) hide the staging latency far better than 128x128 (2 waves/SIMD) on every
+  // shape of the step (tools/gemm_bench.py: 2.7 ms vs 4.5 ms over the layer mix); 128x128 stays selectable.
+  bool big = false;
+  if (const char* e = getenv("MVD_GEMM_TILE")) big = atoi(e) >= 128 && d.N >= 128 && d.M >= 1024;
   const int BM = big ? 128 : 64, BN = big ? 128 : 64;
   int splits = d.splitk;
   const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
   if (splits == 0) {  // auto: aim for >= ~2 workgroups per CU, keep >= 4 k-tiles per slice
     splits = 1;
-    if (tiles < 256 && p.nk >= 8) {
-      splits = (int)((512 + tiles - 1) / tiles);
-      if (splits > p.nk / 4) splits = p.nk / 4;
+    if (tiles < 256 && p.nk >= 32) {
+      splits = (int)((768 + tiles - 1) / tiles);
+      if (splits > p.nk / 8) splits = p.nk / 8;
     }
   }
   if (splits < 1) splits = 1;

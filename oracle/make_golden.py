@@ -305,7 +305,8 @@ def gold_trajectory(model_channels, V, D, tag, steps=5, S=32):
                                    cam_dict(inp["input_cameras"]), inp["clip_v_embed"], tab, dd, index, dn[i], sn[i],
                                    cfg_scale=2.5, n_pts_per_ray=D, unet_kw=dict(model_channels=model_channels))
         xs.append(x)
-    save(tag, xs=torch.stack(xs))
+    keep = list(range(steps)) if steps <= 8 else [i for i in range(steps) if i % 5 == 4 or i == 0]
+    save(tag, xs=torch.stack([xs[i] for i in keep]), kept=np.asarray(keep))
 
 
 def synth_state_dict(model_channels, D, S=32):
@@ -346,6 +347,7 @@ ALL = {
     "step32_d3": lambda: gold_step(32, 2, 3, "step_mc32_v2_d3", indices=(30,)),
     "step320": lambda: gold_step(320, 4, 1, "step_mc320_v4_d1", indices=(49, 0)),
     "traj32": lambda: gold_trajectory(32, 4, 1, "traj_mc32_v4_d1", steps=5),
+    "traj320": lambda: gold_trajectory(320, 4, 1, "traj_mc320_v4_d1_50steps", steps=50),
 }
 
 if __name__ == "__main__":
