@@ -53,8 +53,8 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, void
  *                                  view_attn_efficient2.py:52-61,83,158,167 (timm Attention/Mlp linears)
  *   nn.Conv2d 1x1                  attention.py:245,259; openaimodel.py:241
  *   nn.Conv2d 3x3 (s1, s2, after nearest-2x upsample)   openaimodel.py:107,116,151,204,229-231; unet.py:323,499 */
-#define MVD_A_DENSE 0   /* A: (M, K) row-major fp32, leading dim lda */
-#define MVD_A_CONV3X3 1 /* A: NHWC (B, Hin, Win, Cin) fp32, pad 1; M = B*Hout*Wout, K = 9*Cin */
+#define MVD_A_DENSE 0   /* A: (M, K) row-major planes, leading dim lda (elements) */
+#define MVD_A_CONV3X3 1 /* A: NHWC (B, Hin, Win, Cin) planes, pad 1; M = B*Hout*Wout, K = 9*Cin */
 
 #define MVD_EPI_STORE 0 /* out[m,n] = res[m,n] + colscale[n] * act(acc + bias[n] + bias_b[m / rows_per_batch, n]) */
 #define MVD_EPI_GEGLU 1 /* out[m,j] = (acc_v + bias[j]) * gelu(acc_g + bias[N/2 + j]);  out has N/2 columns */
@@ -66,8 +66,12 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, void
 
 typedef struct mvd_gemm_desc {
   int M, N, K;      /* logical sizes; N % 16 == 0 after padding of the packed weight, K as packed (multiple of 32) */
-  const float* A;
-  int lda;
+  /* A operand: activations as split-bf16 planes (x ~= hi + lo, 2 x bf16 = the bytes of one fp32), produced by the
+   * previous kernel (mvd_groupnorm_nhwc, mvd_layernorm, mvd_attention, a GEMM epilogue, mvd_split_planes ...).
+   * A_lo may be NULL with MVD_PREC_BF16. */
+  const void* A_hi;
+  const void* A_lo;
+  int lda;          /* elements; multiple of 8 */
   int a_mode;       /* MVD_A_* */
   /* conv geometry (a_mode == MVD_A_CONV3X3) */
   int B, Hin, Win, Cin, Hout, Wout, stride, upsample; /* upsample: input is nearest-2x upsampled before the conv */
@@ -76,8 +80,11 @@ typedef struct mvd_gemm_desc {
   /* epilogue */
   int epi;          /* MVD_EPI_* */
   int act;          /* MVD_ACT_* */
-  float* out;
+  float* out;       /* fp32 output or NULL */
   int ldo;
+  void* out_hi;     /* optional split-bf16 plane output (feeds the next GEMM's A operand) */
+  void* out_lo;
+  int ldp;
   int n_store;      /* columns actually stored (<= N; lets N be padded to 16, e.g. the 5-channel UNet head) */
   const float* bias;     /* [N] or NULL */
   const float* bias_b;   /* [M / rows_per_batch][N] or NULL (per-view vector, e.g. the kv_len==1 cross-attention) */
@@ -100,6 +107,10 @@ typedef struct mvd_gemm_desc {
 
 int mvd_gemm(const mvd_gemm_desc* d, mvd_stream_t stream);
 
+/* fp32 (rows, cols) matrix with leading dim ldx -> split-bf16 planes (rows, ldp); columns [cols, ldp) are zero.
+ * Used where a GEMM consumes a tensor that only exists in fp32 (residual stream into the 1x1 skip / up / down convs). */
+int mvd_split_planes(const float* x, void* hi, void* lo, size_t rows, int cols, int ldx, int ldp, mvd_stream_t stream);
+
 /* fp32 matrix-vector products for the M<=16 cases (exact fp32 FMA):
  *   y[m, n] = act_out( sum_k W[n,k] * act_in(x[m,k]) + bias[n] ),  W (N,K) row-major fp32.
  * time_embed / emb_layers / adaLN / cc_projection / kv_len==1 cross-attention vectors:
@@ -114,11 +125,12 @@ int mvd_gemv(const float* W, const float* bias, const float* x, float* y, int M,
  * attention.py:76,243,274 and mvdfusion/attention.py:92,132 eps 1e-6; unet.py:496-498).
  * ws: B * chunks * groups * 2 doubles with chunks = mvd_groupnorm_chunks(HW). */
 int mvd_groupnorm_chunks(int HW);
-int mvd_groupnorm_nhwc(const float* x, float* y, const float* gamma, const float* beta, int B, int HW, int C,
-                       int groups, float eps, int silu, double* ws, mvd_stream_t stream);
+/* y_hi / y_lo: the normalised activations as split-bf16 planes (B*HW, C) -- GroupNorm only ever feeds a GEMM / conv. */
+int mvd_groupnorm_nhwc(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta, int B, int HW,
+                       int C, int groups, float eps, int silu, double* ws, mvd_stream_t stream);
 /* LayerNorm over the last dim.  w/b may be NULL (no affine).  w_plus_one: y = norm * (1 + w) + b
  * (adaLN "modulate", view_attn_efficient2.py:15-16,51,53,65-66); attention.py:211-213, mvdfusion/attention.py:35-37. */
-int mvd_layernorm(const float* x, float* y, const float* w, const float* b, int rows, int C, float eps,
+int mvd_layernorm(const float* x, void* y_hi, void* y_lo, const float* w, const float* b, int rows, int C, float eps,
                   int w_plus_one, mvd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -126,30 +138,32 @@ int mvd_layernorm(const float* x, float* y, const float* w, const float* b, int 
  * Operand planes are written by mvd_gemm(MVD_EPI_QKV):
  *   q/k : [B][heads][Lpad][dq]   bf16, dq  = roundup(dhead, 32), zero padded, q pre-scaled by dhead^-0.5
  *   vt  : [B][heads][dv][Lpad]   bf16, dv  = roundup(dhead, 16)   (V transposed: keys contiguous)
- * out : (B*L, heads*dhead) fp32 row-major (leading dim ldo), head-major channels ('b n (h d)'). */
+ * out : (B*L, heads*dhead) split-bf16 planes (leading dim ldo), head-major channels ('b n (h d)'): feeds to_out. */
 size_t mvd_attn_qk_plane_elems(int B, int heads, int L, int dhead);
 size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead);
 int mvd_attn_lpad(int L);
 int mvd_attention(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
-                  const void* vt_lo, float* out, int ldo, int B, int heads, int L, int dhead, int prec,
+                  const void* vt_lo, void* out_hi, void* out_lo, int ldo, int B, int heads, int L, int dhead, int prec,
                   mvd_stream_t stream);
 
 /* Per-pixel cross attention of one query token against D context tokens (DualAttnetionBlock attn2,
  * mvdfusion/attention.py:56-62; D = n_pts_per_ray).  q (P, C), k/v (P*D, C), out (P, C), C = heads*dhead. */
-int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, float* out, int P, int D, int heads,
-                         int dhead, mvd_stream_t stream);
+int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, void* out_hi, void* out_lo, int P, int D,
+                         int heads, int dhead, mvd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Layout / data-movement kernels. */
 /* UNet input (unet.py:167-187): x (V,5,S,S) NCHW, input_latents (1,5,S,S) NCHW ->
- * out (2V, S, S, cpad) NHWC: rows [0,V) = [x, il[:4]/0.18215, il[4]] , rows [V,2V) = [x, 0]; channels >= 10 zero.
+ * out (2V, S, S, cpad) NHWC split-bf16 planes: rows [0,V) = [x, il[:4]/0.18215, il[4]] , rows [V,2V) = [x, 0]; channels >= 10 zero.
  * With cfg == 0 only the first V rows are produced. */
-int mvd_unet_input(const float* x, const float* input_latents, float* out, int V, int S, int cpad, int cfg,
-                   mvd_stream_t stream);
+int mvd_unet_input(const float* x, const float* input_latents, void* out_hi, void* out_lo, int V, int S, int cpad,
+                   int cfg, mvd_stream_t stream);
 /* out[r, 0:Ca] = a[r], out[r, Ca:Ca+Cb] = b[r]  (torch.cat([h, hs.pop()], dim=1), unet.py:550) */
-int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, int rows, mvd_stream_t stream);
+int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_hi, void* out_lo,
+                        int rows, mvd_stream_t stream); /* out_hi/out_lo optional: planes for the 1x1 skip conv */
 /* area pooling by `factor` of vol (B, S, S, D, C) -> (B, S/f, S/f, D, C)  (unet.py:198-209) */
-int mvd_area_pool(const float* vol, float* out, int B, int S, int D, int C, int factor, mvd_stream_t stream);
+int mvd_area_pool(const float* vol, void* out_hi, void* out_lo, int B, int S, int D, int C, int factor,
+                  mvd_stream_t stream); /* output: split-bf16 planes (the pooled levels only feed to_k / to_v GEMMs) */
 /* out[i] = 0 (memset as a kernel so it is graph-capturable on any stream) */
 int mvd_fill_zero(float* p, size_t n, mvd_stream_t stream);
 
@@ -181,13 +195,14 @@ int mvd_zembed(const float* lat, const float* w, const float* b, float* feat, in
 int mvd_gridattn_tokens(const float* x, const float* depth_noise, const float* steps, const int* iter,
                         const float* grid_lin /* (S) = linspace(1-1/S, -1+1/S, S), ray_utils.py:263-267 */,
                         const float* feat, const float* in_feat, const float* cams, const float* in_cam,
-                        float* tokens, int V, int q0, int Vq, int S, int D, float depth_scale, float depth_shift,
-                        mvd_stream_t stream);
+                        void* tokens_hi, void* tokens_lo, int V, int q0, int Vq, int S, int D, float depth_scale,
+                        float depth_shift, mvd_stream_t stream);
 /* timm Attention core over the V reference views (:52): qkv (Nseq*V, 3*heads*dhead) -> out (Nseq*V, heads*dhead) */
-int mvd_view_mha(const float* qkv, float* out, int Nseq, int V, int heads, int dhead, mvd_stream_t stream);
+int mvd_view_mha(const float* qkv, void* out_hi, void* out_lo, int Nseq, int V, int heads, int dhead,
+                 mvd_stream_t stream); /* output planes */
 /* weight_layer + softmax over V + weighted sum (:83,396-397): x (Nseq*V, C) -> out (Nseq, C) */
-int mvd_view_pool(const float* x, const float* w, const float* b, float* out, int Nseq, int V, int C,
-                  mvd_stream_t stream);
+int mvd_view_pool(const float* x, const float* w, const float* b, void* out_hi, void* out_lo, int Nseq, int V, int C,
+                  mvd_stream_t stream); /* output planes */
 
 /* ------------------------------------------------------------------------------------------------
  * CFG combine + DDIM update (unet.py:195; sampler.py:43-66), fused elementwise.

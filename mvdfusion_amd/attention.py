@@ -86,24 +86,24 @@ class _TransformerCore(nn.Module):
     def self_attn(self, ctx, t, B, L, tag):
         """returns t + attn1(norm1(t)) pieces: the attention output `o` (pre to_out)."""
         C, M = self.dim, B * L
-        ln = ctx.ws.get(tag + ".ln", (M, C))
+        ln = ctx.ws.planes(tag + ".ln", M, C)
         ctx.layernorm(t, ln, self.norm1, M, C)
         planes = ctx.ws.attn_planes(B, self.n_heads, L, self.d_head)
         ctx.gemm(ln, self.attn1.packed("qkv"), None, epi=hip.EPI_QKV,
                  qkv=dict(planes=planes, heads=self.n_heads, dhead=self.d_head, L=L))
-        o = ctx.ws.get(tag + ".o", (M, C))
+        o = ctx.ws.planes(tag + ".o", M, C)
         hip.attention(planes, o, B, self.n_heads, L, self.d_head, prec=ctx.prec)
         return o
 
     def feed_forward(self, ctx, t2, M, tag):
         C = self.dim
-        ln = ctx.ws.get(tag + ".ln", (M, C))
+        ln = ctx.ws.planes(tag + ".ln", M, C)
         ctx.layernorm(t2, ln, self.norm3, M, C)
         w1, w2 = self.ff.packed()
-        g = ctx.ws.get(tag + ".g", (M, 4 * C))
-        ctx.gemm(ln, w1, g, epi=hip.EPI_GEGLU)
-        t3 = ctx.ws.get(tag + ".t3", (M, C))
-        ctx.gemm(g, w2, t3, res=t2)
+        g = ctx.ws.planes(tag + ".g", M, 4 * C)
+        ctx.gemm(ln, w1, None, epi=hip.EPI_GEGLU, out_planes=g)
+        t3 = ctx.ws.planes(tag + ".t3", M, C)          # only consumed by the proj_out GEMM: planes, no fp32 copy
+        ctx.gemm(g, w2, None, res=t2, out_planes=t3)
         return t3
 
 
@@ -140,7 +140,7 @@ class SpatialTransformer(nn.Module):
         M = B * L
         tb = self.transformer_blocks[0]
         w_in, w_out = self.packed()
-        n = ctx.ws.get("tf.n", (M, C))
+        n = ctx.ws.planes("tf.n", M, C)
         ctx.groupnorm(x, n, self.norm, B, L, C, silu=False)
         t = ctx.ws.get("tf.t", (M, C))
         ctx.gemm(n, w_in, t)
@@ -187,8 +187,8 @@ class ViewAlignedFeatureTransformer(nn.Module):
         M = B * L
         tb = self.aligned_attn_transformer_blocks[0]
         w_in, w_out = self.packed()
-        vol = ctx.vol_levels[self.level_mapper[H]]            # (M*D, 768): this view's own depth samples
-        n = ctx.ws.get("tf.n", (M, C))
+        vol = ctx.vol_levels[self.level_mapper[H]]            # planes (2, M*D, 768): this view's own depth samples
+        n = ctx.ws.planes("tf.n", M, C)
         ctx.groupnorm(x, n, self.aligned_attn_norm, B, L, C, silu=False)
         t = ctx.ws.get("tf.t", (M, C))
         ctx.gemm(n, w_in, t)
@@ -198,11 +198,11 @@ class ViewAlignedFeatureTransformer(nn.Module):
         a2 = tb.attn2.packed
         t2b = ctx.ws.get("tf.t2b", (M, C))
         if D == 1:
-            vv = ctx.ws.get("tf.vv", (M, C))
-            ctx.gemm(vol, a2("v"), vv)
+            vv = ctx.ws.planes("tf.vv", M, C)
+            ctx.gemm(vol, a2("v"), None, out_planes=vv)
             ctx.gemm(vv, a2("out"), t2b, res=t2)
         else:
-            ln2 = ctx.ws.get("tf.ln", (M, C))
+            ln2 = ctx.ws.planes("tf.ln", M, C)
             ctx.layernorm(t2, ln2, tb.norm2, M, C)
             q = ctx.ws.get("tf.q2", (M, C))
             ctx.gemm(ln2, a2("q"), q)
@@ -210,9 +210,9 @@ class ViewAlignedFeatureTransformer(nn.Module):
             v = ctx.ws.get("tf.v2", (M * D, C))
             ctx.gemm(vol, a2("k"), k)
             ctx.gemm(vol, a2("v"), v)
-            o2 = ctx.ws.get("tf.o2", (M, C))
-            hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o2), M, D,
-                                                     tb.n_heads, tb.d_head, hip.stream()))
+            o2 = ctx.ws.planes("tf.o2", M, C)
+            hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o2[0]), hip.ptr(o2[1]),
+                                                     M, D, tb.n_heads, tb.d_head, hip.stream()))
             ctx.gemm(o2, a2("out"), t2b, res=t2)
         t3 = tb.feed_forward(ctx, t2b, M, "tf")
         if out is None:

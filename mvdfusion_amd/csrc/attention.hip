@@ -18,7 +18,8 @@ template <int DQ, int DV, int NS>
 __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
                                                    const u16* __restrict__ k_hi, const u16* __restrict__ k_lo,
                                                    const u16* __restrict__ vt_hi, const u16* __restrict__ vt_lo,
-                                                   float* __restrict__ out, int ldo, int H, int L, int Lpad, int dhead) {
+                                                   u16* __restrict__ out_hi, u16* __restrict__ out_lo, int ldo, int H, int L, int Lpad,
+                                                   int dhead) {
   constexpr int NPL = NS == 3 ? 2 : 1;
   constexpr int KP = DQ + 8;       // LDS pitch of a K row (bf16 elements)
   constexpr int VP = KV_TILE + 8;  // LDS pitch of a V^T row
@@ -154,19 +155,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
   const float inv = 1.0f / l_tot;
   const int q = q0 + c;
   if (q < L) {
-    float* orow = out + ((size_t)b * L + q) * ldo + h * dhead;
+    const size_t orow = ((size_t)b * L + q) * ldo + h * dhead;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const int d0 = dt * 16 + g * 4;
-      if (d0 < dhead) *(float4*)(orow + d0) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      if (d0 < dhead) store_planes4(out_hi, out_lo, orow + d0, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
     }
   }
 }
 
 // one wave per pixel; lanes stride over channels of a head. q (P,C), k/v (P*D, C), D <= 8.
 __global__ __launch_bounds__(256) void pixel_xattn_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                          const float* __restrict__ v, float* __restrict__ out, int P, int D,
-                                                          int heads, int dhead) {
+                                                          const float* __restrict__ v, u16* __restrict__ out_hi,
+                                                          u16* __restrict__ out_lo, int P, int D, int heads, int dhead) {
   const int lane = threadIdx.x & 63;
   const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pix >= P) return;
@@ -190,14 +191,14 @@ __global__ __launch_bounds__(256) void pixel_xattn_kernel(const float* __restric
     for (int e = lane; e < dhead; e += 64) {
       float acc = 0.f;
       for (int j = 0; j < D; ++j) acc += (sc[j] / den) * v[((size_t)pix * D + j) * C + h * dhead + e];
-      out[(size_t)pix * C + h * dhead + e] = acc;
+      store_planes1(out_hi, out_lo, (size_t)pix * C + h * dhead + e, acc);
     }
   }
 }
 
 // one thread per (sequence, head, query view); qkv row layout [3][heads][dhead] (timm reshape B,N,3,H,hd).
-__global__ __launch_bounds__(256) void view_mha_kernel(const float* __restrict__ qkv, float* __restrict__ out, int Nseq, int V,
-                                                       int heads, int dhead) {
+__global__ __launch_bounds__(256) void view_mha_kernel(const float* __restrict__ qkv, u16* __restrict__ out_hi,
+                                                       u16* __restrict__ out_lo, int Nseq, int V, int heads, int dhead) {
   const size_t total = (size_t)Nseq * heads * V;
   const int C = heads * dhead;
   const float scale = rsqrtf((float)dhead);
@@ -220,19 +221,19 @@ __global__ __launch_bounds__(256) void view_mha_kernel(const float* __restrict__
       sc[j] = expf(sc[j] - mx);
       den += sc[j];
     }
-    float* orow = out + (n * V + vq) * C + h * dhead;
+    const size_t orow = (n * V + vq) * C + h * dhead;
     for (int d = 0; d < dhead; ++d) {
       float a = 0.f;
       for (int j = 0; j < V; ++j) a += (sc[j] / den) * qkv[(n * V + j) * 3 * C + 2 * C + h * dhead + d];
-      orow[d] = a;
+      store_planes1(out_hi, out_lo, orow + d, a);
     }
   }
 }
 
 // one wave per sequence: logits w.x_v + b, softmax over V, out = sum_v p_v x_v.  C % 64 == 0, C <= 512.
 __global__ __launch_bounds__(256) void view_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ out, int Nseq, int V,
-                                                        int C) {
+                                                        const float* __restrict__ bias, u16* __restrict__ out_hi,
+                                                        u16* __restrict__ out_lo, int Nseq, int V, int C) {
   const int lane = threadIdx.x & 63;
   const size_t n = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= (size_t)Nseq) return;
@@ -252,20 +253,20 @@ __global__ __launch_bounds__(256) void view_pool_kernel(const float* __restrict_
   for (int e = lane; e < C; e += 64) {
     float a = 0.f;
     for (int v = 0; v < V; ++v) a += x[(n * V + v) * C + e] * (lg[v] / den);
-    out[n * C + e] = a;
+    store_planes1(out_hi, out_lo, n * C + e, a);
   }
 }
 
 template <int NS>
 int launch_attn(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi, const void* vt_lo,
-                float* out, int ldo, int B, int H, int L, int Lpad, int dhead, hipStream_t s) {
+                void* out_hi, void* out_lo, int ldo, int B, int H, int L, int Lpad, int dhead, hipStream_t s) {
   const int dq = (dhead + 31) & ~31, dv = (dhead + 15) & ~15;
   dim3 grid(Lpad / 64, H, B), block(256);
 #define MVD_ATTN_CASE(DQ, DV)                                                                                          \
   if (dq == DQ && dv == DV) {                                                                                          \
     hipLaunchKernelGGL((attn_kernel<DQ, DV, NS>), grid, block, 0, s, (const u16*)q_hi, (const u16*)q_lo,               \
-                       (const u16*)k_hi, (const u16*)k_lo, (const u16*)vt_hi, (const u16*)vt_lo, out, ldo, H, L, Lpad, \
-                       dhead);                                                                                         \
+                       (const u16*)k_hi, (const u16*)k_lo, (const u16*)vt_hi, (const u16*)vt_lo, (u16*)out_hi,         \
+                       (u16*)out_lo, ldo, H, L, Lpad, dhead);                                                          \
     return 0;                                                                                                          \
   }
   MVD_ATTN_CASE(32, 16)
@@ -289,45 +290,49 @@ extern "C" size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead) {
 }
 
 extern "C" int mvd_attention(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
-                             const void* vt_lo, float* out, int ldo, int B, int heads, int L, int dhead, int prec,
-                             mvd_stream_t stream) {
-  MVD_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out, "mvd_attention: null pointer");
+                             const void* vt_lo, void* out_hi, void* out_lo, int ldo, int B, int heads, int L, int dhead,
+                             int prec, mvd_stream_t stream) {
+  MVD_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out_hi && out_lo, "mvd_attention: null pointer");
   MVD_CHECK_ARG(B > 0 && heads > 0 && L > 0 && dhead > 0 && dhead % 4 == 0, "mvd_attention: bad shape (dhead %% 4 == 0)");
-  MVD_CHECK_ARG(ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, "mvd_attention: out must be 16-byte aligned, ldo %% 4 == 0");
+  MVD_CHECK_ARG(ldo % 4 == 0 && ((uintptr_t)out_hi & 7) == 0 && ((uintptr_t)out_lo & 7) == 0,
+                "mvd_attention: out planes must be 8-byte aligned, ldo %% 4 == 0");
   MVD_CHECK_ARG(prec == MVD_PREC_BF16 || prec == MVD_PREC_BF16X3, "mvd_attention: bad prec");
   const int Lpad = mvd_attn_lpad(L);
   int rc;
   if (prec == MVD_PREC_BF16X3)
-    rc = launch_attn<3>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+    rc = launch_attn<3>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_hi, out_lo, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
   else
-    rc = launch_attn<1>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+    rc = launch_attn<1>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_hi, out_lo, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
   MVD_CHECK_ARG(rc == 0, "mvd_attention: unsupported head dim %d (supported: <=32, 33..64, 65..96 with dv 80, 160)", dhead);
   MVD_CHECK_LAUNCH("mvd_attention");
   return 0;
 }
 
-extern "C" int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, float* out, int P, int D, int heads,
-                                    int dhead, mvd_stream_t stream) {
-  MVD_CHECK_ARG(q && k && v && out && P > 0 && D > 0 && D <= 8 && heads > 0 && dhead > 0, "mvd_pixel_cross_attn: bad arguments (D <= 8)");
-  hipLaunchKernelGGL(pixel_xattn_kernel, dim3(cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, out, P, D, heads, dhead);
+extern "C" int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, void* out_hi, void* out_lo, int P, int D,
+                                    int heads, int dhead, mvd_stream_t stream) {
+  MVD_CHECK_ARG(q && k && v && out_hi && out_lo && P > 0 && D > 0 && D <= 8 && heads > 0 && dhead > 0, "mvd_pixel_cross_attn: bad arguments (D <= 8)");
+  hipLaunchKernelGGL(pixel_xattn_kernel, dim3(cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, (u16*)out_hi, (u16*)out_lo, P, D, heads,
+                     dhead);
   MVD_CHECK_LAUNCH("mvd_pixel_cross_attn");
   return 0;
 }
 
-extern "C" int mvd_view_mha(const float* qkv, float* out, int Nseq, int V, int heads, int dhead, mvd_stream_t stream) {
-  MVD_CHECK_ARG(qkv && out && Nseq > 0 && V > 0 && V <= 16 && heads > 0 && dhead > 0, "mvd_view_mha: bad arguments (V <= 16)");
+extern "C" int mvd_view_mha(const float* qkv, void* out_hi, void* out_lo, int Nseq, int V, int heads, int dhead,
+                            mvd_stream_t stream) {
+  MVD_CHECK_ARG(qkv && out_hi && out_lo && Nseq > 0 && V > 0 && V <= 16 && heads > 0 && dhead > 0, "mvd_view_mha: bad arguments (V <= 16)");
   const size_t total = (size_t)Nseq * heads * V;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(view_mha_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, out, Nseq, V, heads, dhead);
+  hipLaunchKernelGGL(view_mha_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, (u16*)out_hi, (u16*)out_lo, Nseq, V, heads,
+                     dhead);
   MVD_CHECK_LAUNCH("mvd_view_mha");
   return 0;
 }
 
-extern "C" int mvd_view_pool(const float* x, const float* w, const float* b, float* out, int Nseq, int V, int C,
+extern "C" int mvd_view_pool(const float* x, const float* w, const float* b, void* out_hi, void* out_lo, int Nseq, int V, int C,
                              mvd_stream_t stream) {
-  MVD_CHECK_ARG(x && w && b && out && Nseq > 0 && V > 0 && V <= 16 && C > 0, "mvd_view_pool: bad arguments (V <= 16)");
-  hipLaunchKernelGGL(view_pool_kernel, dim3(cdiv(Nseq, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, out, Nseq, V, C);
+  MVD_CHECK_ARG(x && w && b && out_hi && out_lo && Nseq > 0 && V > 0 && V <= 16 && C > 0, "mvd_view_pool: bad arguments (V <= 16)");
+  hipLaunchKernelGGL(view_pool_kernel, dim3(cdiv(Nseq, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, (u16*)out_hi, (u16*)out_lo, Nseq, V, C);
   MVD_CHECK_LAUNCH("mvd_view_pool");
   return 0;
 }

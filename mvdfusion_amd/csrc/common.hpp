@@ -52,6 +52,24 @@ __device__ __forceinline__ void split_bf16(float x, u16& hi, u16& lo) {
   lo = __builtin_bit_cast(u16, l);
 }
 
+// four consecutive elements -> 8 bytes in each plane (idx must be a multiple of 4)
+__device__ __forceinline__ void store_planes4(u16* __restrict__ hi, u16* __restrict__ lo, size_t idx, float a, float b,
+                                              float c, float d) {
+  u16 h[4], l[4];
+  split_bf16(a, h[0], l[0]);
+  split_bf16(b, h[1], l[1]);
+  split_bf16(c, h[2], l[2]);
+  split_bf16(d, h[3], l[3]);
+  *(uint2*)(hi + idx) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+  *(uint2*)(lo + idx) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+__device__ __forceinline__ void store_planes1(u16* __restrict__ hi, u16* __restrict__ lo, size_t idx, float a) {
+  u16 h, l;
+  split_bf16(a, h, l);
+  hi[idx] = h;
+  lo[idx] = l;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -27,6 +27,10 @@ class Workspace:
             self.bufs[key] = t
         return t
 
+    def planes(self, tag, rows, cols):
+        """Static split-bf16 plane pair (2, rows, cols) int16 (the A-operand format of mvd_gemm)."""
+        return self.get(tag, (2, rows, cols), torch.int16)
+
     def attn_planes(self, B, heads, L, dhead):
         key = ("attn_planes", B, heads, L, dhead)
         t = self.bufs.get(key)

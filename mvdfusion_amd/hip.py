@@ -26,10 +26,11 @@ class GemmDesc(C.Structure):
     """struct mvd_gemm_desc (field order must match include/mvd_hip.h)."""
     _fields_ = [
         ("M", _i), ("N", _i), ("K", _i),
-        ("A", _vp), ("lda", _i), ("a_mode", _i),
+        ("A_hi", _vp), ("A_lo", _vp), ("lda", _i), ("a_mode", _i),
         ("B", _i), ("Hin", _i), ("Win", _i), ("Cin", _i), ("Hout", _i), ("Wout", _i), ("stride", _i), ("upsample", _i),
         ("Wp", _vp), ("prec", _i),
-        ("epi", _i), ("act", _i), ("out", _vp), ("ldo", _i), ("n_store", _i),
+        ("epi", _i), ("act", _i), ("out", _vp), ("ldo", _i), ("out_hi", _vp), ("out_lo", _vp), ("ldp", _i),
+        ("n_store", _i),
         ("bias", _vp), ("bias_b", _vp), ("rows_per_batch", _i), ("colscale", _vp), ("res", _vp), ("ldr", _i),
         ("q_hi", _vp), ("q_lo", _vp), ("k_hi", _vp), ("k_lo", _vp), ("vt_hi", _vp), ("vt_lo", _vp),
         ("heads", _i), ("dhead", _i), ("L", _i), ("Lpad", _i), ("qscale", _f),
@@ -45,25 +46,26 @@ SIGNATURES = {
     "mvd_pack_linear_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mvd_pack_conv3x3_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mvd_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "mvd_split_planes": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "mvd_gemv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_groupnorm_chunks": (_i, [_i]),
-    "mvd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
-    "mvd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "mvd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "mvd_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "mvd_attn_qk_plane_elems": (_sz, [_i, _i, _i, _i]),
     "mvd_attn_vt_plane_elems": (_sz, [_i, _i, _i, _i]),
     "mvd_attn_lpad": (_i, [_i]),
-    "mvd_attention": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _vp]),
-    "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "mvd_unet_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp]),
-    "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvd_attention": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i, _i, _vp]),
+    "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvd_unet_input": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "mvd_area_pool": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvd_fill_zero": (_i, [_vp, _sz, _vp]),
     "mvd_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "mvd_advance_iter": (_i, [_vp, _vp]),
     "mvd_zembed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "mvd_gridattn_tokens": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _f, _f, _vp]),
-    "mvd_view_mha": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "mvd_view_pool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mvd_gridattn_tokens": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _f, _f, _vp]),
+    "mvd_view_mha": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvd_view_pool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mvd_cfg_ddim_update": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "mvd_graph_begin": (_i, [_vp]),
     "mvd_graph_end": (_i, [_vp, C.POINTER(_vp)]),
@@ -164,15 +166,34 @@ def pack_conv3x3(weight, bias=None):
 # ---------------------------------------------------------------------------------------------
 # ops (thin wrappers; all outputs are caller-provided tensors)
 # ---------------------------------------------------------------------------------------------
+def planes_like(rows, cols, device):
+    """Split-bf16 plane pair for a (rows, cols) activation: int16 tensor (2, rows, cols); [0] = hi, [1] = lo."""
+    return torch.empty(2, rows, cols, dtype=torch.int16, device=device)
+
+
+def split_planes(x, out=None, ldp=None):
+    """fp32 (rows, cols) -> planes (2, rows, ldp) with zero-padded columns (mvd_split_planes)."""
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    ldp = (cols + 7) // 8 * 8 if ldp is None else ldp
+    if out is None:
+        out = planes_like(rows, ldp, x.device)
+    check(lib().mvd_split_planes(ptr(x), ptr(out[0]), ptr(out[1]), rows, cols, cols, ldp, stream()))
+    return out
+
+
 def gemm(A, W, out=None, *, prec=PREC_BF16X3, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
-         bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None):
-    """out = epilogue(A @ W^T).  A: (M, K) fp32 (dense) or NHWC (B,H,W,C) with conv=dict(...).
+         bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
+         out_planes=None):
+    """out = epilogue(A @ W^T).  A: split-bf16 planes (2, M, K) (dense) or (2, B, H, W, C) with conv=dict(...).
 
     conv = dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
+    out: fp32 tensor or None; out_planes: (2, M, N') int16 plane pair or None (feeds the next GEMM).
     """
+    assert A.dtype == torch.int16 and A.shape[0] == 2, "A must be a split-bf16 plane pair (see hip.split_planes)"
     d = GemmDesc()
     d.N, d.K = W.N, W.K
-    d.A = A.data_ptr()
+    d.A_hi = A[0].data_ptr()
+    d.A_lo = A[1].data_ptr()
     d.Wp = W.data.data_ptr()
     d.prec = prec
     if conv is not None:
@@ -183,13 +204,16 @@ def gemm(A, W, out=None, *, prec=PREC_BF16X3, M=None, lda=None, bias=True, act=A
         assert conv["Cin"] * 9 == W.K, (conv["Cin"], W.K)
     else:
         d.a_mode = A_DENSE
-        d.M = int(M if M is not None else A.numel() // A.shape[-1])
+        d.M = int(M if M is not None else A[0].numel() // A.shape[-1])
         d.lda = int(lda if lda is not None else A.shape[-1])
         assert d.lda >= W.K, f"A has {d.lda} columns, packed K is {W.K} (pad A)"
     d.epi, d.act = epi, act
     if out is not None:
         d.out = out.data_ptr()
         d.ldo = int(ldo if ldo is not None else out.shape[-1])
+    if out_planes is not None:
+        d.out_hi, d.out_lo = out_planes[0].data_ptr(), out_planes[1].data_ptr()
+        d.ldp = int(out_planes.shape[-1])
     d.n_store = W.n_real
     if bias and W.bias is not None:
         d.bias = W.bias.data_ptr()
@@ -224,19 +248,23 @@ def gemv(W, bias, x, y, act_in=ACT_NONE, act_out=ACT_NONE):
 
 
 def groupnorm(x, y, gamma, beta, B, HW, Cc, eps, silu, ws):
-    check(lib().mvd_groupnorm_nhwc(ptr(x), ptr(y), ptr(gamma), ptr(beta), B, HW, Cc, 32, eps, int(silu), ptr(ws), stream()))
+    """y: plane pair (2, B*HW, C)."""
+    check(lib().mvd_groupnorm_nhwc(ptr(x), ptr(y[0]), ptr(y[1]), ptr(gamma), ptr(beta), B, HW, Cc, 32, eps, int(silu),
+                                   ptr(ws), stream()))
     return y
 
 
 def layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False):
-    check(lib().mvd_layernorm(ptr(x), ptr(y), ptr(w), ptr(b), rows, Cc, eps, int(w_plus_one), stream()))
+    """y: plane pair (2, rows, C)."""
+    check(lib().mvd_layernorm(ptr(x), ptr(y[0]), ptr(y[1]), ptr(w), ptr(b), rows, Cc, eps, int(w_plus_one), stream()))
     return y
 
 
 def attention(planes, out, B, heads, L, dhead, prec=PREC_BF16X3):
+    """out: plane pair (2, B*L, heads*dhead)."""
     qh, ql, kh, kl, vh, vl = planes
-    check(lib().mvd_attention(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(out), out.shape[-1], B, heads, L,
-                              dhead, prec, stream()))
+    check(lib().mvd_attention(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(out[0]), ptr(out[1]),
+                              out.shape[-1], B, heads, L, dhead, prec, stream()))
     return out
 
 

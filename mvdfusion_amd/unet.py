@@ -45,7 +45,8 @@ class Upsample(nn.Module):
             self._p = hip.pack_conv3x3(self.conv.weight, self.conv.bias)
         if out is None:
             out = ctx.act((ctx.B * 4 * H * W, self.out_channels))
-        ctx.gemm(x, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=2 * H, Wout=2 * W,
+        xp = hip.split_planes(x, ctx.ws.planes("updown.x", ctx.B * H * W, self.channels))   # raw residual stream -> planes
+        ctx.gemm(xp, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=2 * H, Wout=2 * W,
                                             stride=1, upsample=1))
         return out, 2 * H, 2 * W
 
@@ -63,7 +64,8 @@ class Downsample(nn.Module):
         Ho, Wo = H // 2, W // 2
         if out is None:
             out = ctx.act((ctx.B * Ho * Wo, self.out_channels))
-        ctx.gemm(x, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=Ho, Wout=Wo, stride=2,
+        xp = hip.split_planes(x, ctx.ws.planes("updown.x", ctx.B * H * W, self.channels))
+        ctx.gemm(xp, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=Ho, Wout=Wo, stride=2,
                                             upsample=0))
         return out, Ho, Wo
 
@@ -93,23 +95,26 @@ class ResBlock(TimestepBlock):
             self._p = (hip.pack_conv3x3(c1.weight, None), hip.pack_conv3x3(c2.weight, c2.bias), sk)
         return self._p
 
-    def run(self, ctx, x, H, W, out=None):
+    def run(self, ctx, x, H, W, out=None, x_planes=None):
+        """x: fp32 (M, Cin) residual stream; x_planes: its split-bf16 planes if the producer already wrote them."""
         B, Ci, Co = ctx.B, self.channels, self.out_channels
         M = B * H * W
         w1, w2, wsk = self.packed()
         geo = dict(B=B, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
-        a = ctx.ws.get("res.a", (M, Ci))
+        a = ctx.ws.planes("res.a", M, Ci)
         ctx.groupnorm(x, a, self.in_layers[0], B, H * W, Ci, silu=True)
         h = ctx.ws.get("res.h", (M, Co))
         # conv bias + Linear(SiLU(emb)) are folded into one per-step bias vector (UNetModel._time_biases)
         hip.gemm(a, w1, h, prec=ctx.prec, conv=dict(Cin=Ci, **geo), bias=False, colscale=None,
                  res=None, workspace=ctx.gemm_ws, bias_b=ctx.emb_bias[self], rows_per_batch=M)
-        a2 = ctx.ws.get("res.a2", (M, Co))
+        a2 = ctx.ws.planes("res.a2", M, Co)
         ctx.groupnorm(h, a2, self.out_layers[0], B, H * W, Co, silu=True)
         skip = x
         if wsk is not None:
+            if x_planes is None:
+                x_planes = hip.split_planes(x, ctx.ws.planes("res.xp", M, Ci))
             skip = ctx.ws.get("res.skip", (M, Co))
-            ctx.gemm(x, wsk, skip)
+            ctx.gemm(x_planes, wsk, skip)
         if out is None:
             out = ctx.act((M, Co))
         ctx.gemm(a2, w2, out, conv=dict(Cin=Co, **geo), res=skip)
@@ -117,13 +122,16 @@ class ResBlock(TimestepBlock):
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
-    def run(self, ctx, x, H, W, out=None):
-        """Run the layers in order; `out` (optional) is the buffer the LAST layer must write (skip tensors)."""
+    def run(self, ctx, x, H, W, out=None, x_planes=None):
+        """Run the layers in order; `out` (optional) is the buffer the LAST layer must write (skip tensors);
+        `x_planes`: split-bf16 planes of x when the caller has them (the concat kernel writes both)."""
         n = len(self)
         for i, layer in enumerate(self):
             dst = out if i == n - 1 else None
             if isinstance(layer, (Upsample, Downsample)):
                 x, H, W = layer.run(ctx, x, H, W, out=dst)
+            elif isinstance(layer, ResBlock):
+                x = layer.run(ctx, x, H, W, out=dst, x_planes=x_planes if i == 0 else None)
             else:
                 x = layer.run(ctx, x, H, W, out=dst)
         return x, H, W
@@ -244,7 +252,7 @@ class UNetModel(nn.Module):
         ctx.emb_bias = {b: out[0, lo:hi] for b, (lo, hi) in offs.items()}
 
     def run(self, ctx, x_in, t_sin, S):
-        """x_in: (B, S, S, 32) channels-last zero-padded input; t_sin: (1, model_channels) sinusoid; returns the
+        """x_in: split-bf16 planes (2, B*S*S, 32) of the channels-last zero-padded input; t_sin: (1, model_channels) sinusoid; returns the
         (B*S*S, 8) head output (first out_channels columns valid)."""
         B = ctx.B
         self.time_biases(ctx, t_sin)
@@ -268,12 +276,14 @@ class UNetModel(nn.Module):
             M = B * H * W
             ca, cb = h.shape[-1], sk.shape[-1]
             cat = ctx.ws.get("cat", (M, ca + cb))
-            hip.check(hip.lib().mvd_concat_channels(hip.ptr(h), ca, hip.ptr(sk), cb, hip.ptr(cat), M, hip.stream()))
-            h, H, W = blk.run(ctx, cat, H, W)
+            catp = ctx.ws.planes("catp", M, ca + cb)          # planes for the ResBlock's 1x1 skip conv
+            hip.check(hip.lib().mvd_concat_channels(hip.ptr(h), ca, hip.ptr(sk), cb, hip.ptr(cat), hip.ptr(catp[0]),
+                                                    hip.ptr(catp[1]), M, hip.stream()))
+            h, H, W = blk.run(ctx, cat, H, W, x_planes=catp)
         if self._head is None:
             self._head = hip.pack_conv3x3(self.out[2].weight, self.out[2].bias)
         M = B * H * W
-        a = ctx.ws.get("res.a", (M, self.model_channels))
+        a = ctx.ws.planes("res.a", M, self.model_channels)
         ctx.groupnorm(h, a, self.out[0], B, H * W, self.model_channels, silu=True)
         y = ctx.ws.get("head", (M, 8))
         ctx.gemm(a, self._head, y, conv=dict(B=B, Hin=H, Win=W, Cin=self.model_channels, Hout=H, Wout=W, stride=1,
@@ -304,13 +314,14 @@ class UNetWrapper(nn.Module):
         return self.unet_model.get_cross_attn_parameters(finetune_cross_attn=self.finetune_cross_attn,
                                                          finetune_view_attn=self.finetune_view_attn)
 
-    def volume_pyramid(self, ctx, vol, B, S, D):
-        """get_volume_feats_pyramid (unet.py:198-209): area pooling at x{1, 1/2, 1/4, 1/8}; vol (B,S,S,D,768)."""
-        levels = [vol.view(B * S * S * D, -1)]
+    def volume_pyramid(self, ctx, vol, vol_planes, B, S, D):
+        """get_volume_feats_pyramid (unet.py:198-209): area pooling at x{1, 1/2, 1/4, 1/8}; vol (B,S,S,D,768) fp32
+        and its split-bf16 planes.  Every level is returned as planes (they only feed the to_k / to_v GEMMs)."""
+        levels = [vol_planes]
         Cc = vol.shape[-1]
         for i in range(1, len(self.unet_model.channel_mult)):
             f = 2 ** i
-            o = ctx.ws.get(f"vol{i}", (B * (S // f) * (S // f) * D, Cc))
-            hip.check(hip.lib().mvd_area_pool(hip.ptr(vol), hip.ptr(o), B, S, D, Cc, f, hip.stream()))
+            o = ctx.ws.planes(f"vol{i}", B * (S // f) * (S // f) * D, Cc)
+            hip.check(hip.lib().mvd_area_pool(hip.ptr(vol), hip.ptr(o[0]), hip.ptr(o[1]), B, S, D, Cc, f, hip.stream()))
             levels.append(o)
         return levels

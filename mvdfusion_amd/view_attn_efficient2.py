@@ -61,17 +61,17 @@ class DiTBlock(nn.Module):
         mod = ctx.ws.get("ga.mod", (1, 6 * C))
         hip.gemv(lin.weight, lin.bias, c, mod, act_in=hip.ACT_SILU)
         sh1, sc1, g1, sh2, sc2, g2 = (mod[0, i * C:(i + 1) * C] for i in range(6))
-        ln = ctx.ws.get("ga.ln", (T, C))
+        ln = ctx.ws.planes("ga.ln", T, C)
         hip.layernorm(h, ln, sc1, sh1, T, C, eps=1e-6, w_plus_one=True)
         qkv = ctx.ws.get("ga.qkv", (T, 3 * C))
         ctx.gemm(ln, wqkv, qkv)
-        att = ctx.ws.get("ga.att", (T, C))
-        hip.check(hip.lib().mvd_view_mha(hip.ptr(qkv), hip.ptr(att), T // V, V, self.num_heads, C // self.num_heads,
-                                         hip.stream()))
+        att = ctx.ws.planes("ga.att", T, C)
+        hip.check(hip.lib().mvd_view_mha(hip.ptr(qkv), hip.ptr(att[0]), hip.ptr(att[1]), T // V, V, self.num_heads,
+                                         C // self.num_heads, hip.stream()))
         ctx.gemm(att, wproj, h_alt, res=h, colscale=g1)
         hip.layernorm(h_alt, ln, sc2, sh2, T, C, eps=1e-6, w_plus_one=True)
-        f1 = ctx.ws.get("ga.f1", (T, wfc1.N))
-        ctx.gemm(ln, wfc1, f1, act=hip.ACT_GELU)
+        f1 = ctx.ws.planes("ga.f1", T, wfc1.N)
+        ctx.gemm(ln, wfc1, None, act=hip.ACT_GELU, out_planes=f1)
         ctx.gemm(f1, wfc2, h, res=h_alt, colscale=g2)
         return h
 
@@ -121,7 +121,8 @@ class GridAttn(nn.Module):
                        hip.pack_linear(self.final_layer_b.weight, self.final_layer_b.bias))
         return self._p
 
-    def run(self, ctx, x, depth_noise, steps, it, cams_rec, in_cam_rec, input_latents, c, vol_out, V, S, D, q0=0, Vq=None):
+    def run(self, ctx, x, depth_noise, steps, it, cams_rec, in_cam_rec, input_latents, c, vol_out, V, S, D, q0=0, Vq=None,
+            vol_planes=None):
         """x (V,5,S,S) noisy latents; c (1,256) time conditioning (t_embed[:1]); vol_out: (>=V*S*S*D, 768) buffer
         whose first Vq*S*S*D rows receive the feature frustum (row = ((v*S + y)*S + x)*D + d) of the query views
         [q0, q0+Vq) (all V views by default; a view-parallel rank passes the range it owns)."""
@@ -142,19 +143,20 @@ class GridAttn(nn.Module):
             half = 1.0 / float(S)
             grid_lin = torch.linspace(1.0 - half, -1.0 + half, S, dtype=torch.float32).to(ctx.device)
             ctx.ws.bufs[("ga.lin", S)] = grid_lin
-        tokens = ctx.ws.get("ga.tokens", (T, hip.TOKEN_LD))
+        tokens = ctx.ws.planes("ga.tokens", T, hip.TOKEN_LD)
         hip.check(L.mvd_gridattn_tokens(hip.ptr(x), hip.ptr(depth_noise), hip.ptr(steps), hip.ptr(it), hip.ptr(grid_lin),
                                         hip.ptr(feat), hip.ptr(in_feat), hip.ptr(cams_rec), hip.ptr(in_cam_rec),
-                                        hip.ptr(tokens), V, q0, Vq, S, D, float(self.depth_scale), float(self.depth_shift),
-                                        hip.stream()))
+                                        hip.ptr(tokens[0]), hip.ptr(tokens[1]), V, q0, Vq, S, D, float(self.depth_scale),
+                                        float(self.depth_shift), hip.stream()))
         h = ctx.ws.get("ga.h", (T, self.hidden_size))
         h_alt = ctx.ws.get("ga.h_alt", (T, self.hidden_size))
         ctx.gemm(tokens, w_pre, h, act=hip.ACT_GELU)
         for blk in self.aggregation_transformer.layer_list:
             h = blk.run(ctx, h, h_alt, c, T, V)
         wl = self.aggregation_transformer.weight_layer
-        pool = ctx.ws.get("ga.pool", (nseq, self.hidden_size))
-        hip.check(L.mvd_view_pool(hip.ptr(h), hip.ptr(wl.weight), hip.ptr(wl.bias), hip.ptr(pool), nseq, V,
-                                  self.hidden_size, hip.stream()))
-        ctx.gemm(pool, w_fin, vol_out, M=nseq)
+        pool = ctx.ws.planes("ga.pool", nseq, self.hidden_size)
+        hip.check(L.mvd_view_pool(hip.ptr(h), hip.ptr(wl.weight), hip.ptr(wl.bias), hip.ptr(pool[0]), hip.ptr(pool[1]),
+                                  nseq, V, self.hidden_size, hip.stream()))
+        # the frustum is consumed as fp32 (area pooling) and as planes (level-0 to_k / to_v GEMMs): write both
+        ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes)
         return vol_out

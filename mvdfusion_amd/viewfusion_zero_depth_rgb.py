@@ -52,7 +52,8 @@ class StepEngine:
         self.in_cam = z(1, hip.CAM_RECORD)
         self.context = z(B, 768)               # rows [V,2V) stay zero: the null branch (unet.py:173)
         self.vol = z(B * S * S * D, 768)       # rows of the null branch stay zero (unet.py:190)
-        self.x_in = z(B, S, S, 32)
+        self.vol_planes = torch.zeros(2, B * S * S * D, 768, dtype=torch.int16, device=dev)   # same, as split-bf16 planes
+        self.x_in = torch.zeros(2, B * S * S, 32, dtype=torch.int16, device=dev)              # UNet input planes
         self.iter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.steps = z(1, hip.STEP_STRIDE)
         self.depth_noise = z(1, V, D, S, S)
@@ -96,7 +97,7 @@ class StepEngine:
         hip.gemv(m.time_embed[2].weight, m.time_embed[2].bias, te1, c)
         # view-aligned features (:303-313)
         m.view_attn.run(ctx, self.x, self.depth_noise, self.steps, self.iter, self.cams, self.in_cam,
-                        self.input_latents, c, self.vol, V, S, D, q0=q0, Vq=Vq)
+                        self.input_latents, c, self.vol, V, S, D, q0=q0, Vq=Vq, vol_planes=self.vol_planes)
         # cc_projection (:322)
         p = m.cc_projection
         c1 = ctx.ws.get("vf.cc1", (Vq, 768))
@@ -107,10 +108,10 @@ class StepEngine:
         ctx.context = self.context
         # UNet on the CFG batch (unet.py:167-196)
         xq, x0q, epsq = self.x[q0:q0 + Vq], self.x0[q0:q0 + Vq], self.eps[q0:q0 + Vq]
-        hip.check(L.mvd_unet_input(hip.ptr(xq), hip.ptr(self.input_latents), hip.ptr(self.x_in), Vq, S, 32,
-                                   int(self.cfg), st()))
+        hip.check(L.mvd_unet_input(hip.ptr(xq), hip.ptr(self.input_latents), hip.ptr(self.x_in[0]), hip.ptr(self.x_in[1]),
+                                   Vq, S, 32, int(self.cfg), st()))
         unet = m.unet_model.unet_model
-        ctx.vol_levels = m.unet_model.volume_pyramid(ctx, self.vol.view(B, S, S, D, 768), B, S, D)
+        ctx.vol_levels = m.unet_model.volume_pyramid(ctx, self.vol.view(B, S, S, D, 768), self.vol_planes, B, S, D)
         tsu = ctx.ws.get("vf.tsin_unet", (1, unet.model_channels))
         hip.check(L.mvd_timestep_embedding(hip.ptr(self.steps), hip.ptr(self.iter), hip.ptr(self.funet), hip.ptr(tsu),
                                            unet.model_channels, st()))

@@ -39,6 +39,13 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def planes_to_float(p):
+    """split-bf16 plane pair (2, ...) int16 -> fp32 value hi + lo."""
+    p = p.detach().cpu()
+    f = lambda t: (t.to(torch.int32) << 16).view(torch.float32)
+    return f(p[0]) + f(p[1])
+
+
 def rmse(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float(((a - b) ** 2).mean().sqrt())
