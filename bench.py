@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--views", type=int, default=None)
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--depth-samples", type=int, default=1)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16x3", "f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     a = ap.parse_args()
@@ -209,7 +209,9 @@ def main():
             "metric": "denoising-steps/sec", "value": a.steps / dt, "unit": "steps/s", "n_gpus": N, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong" if N > 1 else "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 MFMA operands, 3 products, fp32 accumulate)" if a.precision == "bf16x3" else "bf16",
+            "dtype": {"f16x3": "f16x3 (fp16 MFMA operands split hi+lo, 3 products, fp32 accumulate)",
+                      "bf16x3": "bf16x3 (bf16 MFMA operands split hi+lo, 3 products, fp32 accumulate)",
+                      "f16": "f16 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)"}[a.precision],
             "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[{1 if N == 1 else 2}]: V={V} views x {8 * S}^2 images "
                                     f"({S}x{S} latents), D={D}, 50-step DDIM (eta 1), cfg {cfg_scale}, SD1.x UNet 320ch "
@@ -234,8 +236,8 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": b["n"],
                            "avg_launch_us": b["ms"] / b["n"] * 1e3, "achieved": ach / 1e12, "peak": MFMA_BF16_DENSE_PEAK / 1e12,
                            "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK, "traffic": None,
-                           "note": "algorithmic FLOPs = 2*M*N*K of the fp32 problem; the bf16x3 kernel issues 3 MFMA "
-                                   "products per algorithmic MAC, so its MFMA-pipe utilisation is 3x this fraction",
+                           "note": "algorithmic FLOPs = 2*M*N*K of the fp32 problem against the dense 16-bit MFMA peak; the "
+                                   "x3 kernels issue 3 MFMA products per algorithmic MAC, so MFMA-pipe utilisation is 3x this",
                            "gemm_share_of_step_ms": tot}
         if not a.no_cpu_baseline:
             cb, _ = cpu_baseline(sd, V, S, D, cfg_scale)

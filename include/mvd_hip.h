@@ -13,9 +13,11 @@
  *     in a hipGraph (mvd_graph_*);
  *   - return 0 on success, <0 on error; the message is available from mvd_last_error(); nothing throws;
  *   - activations are fp32, channels-last: an image tensor is (B, H, W, C) == a row-major (B*H*W, C) matrix;
- *   - GEMM-shaped math runs on bf16 MFMA.  `prec` selects MVD_PREC_BF16 (one product) or MVD_PREC_BF16X3
- *     (operands split x = hi + lo, three products hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2^-17 relative
- *     operand error, which is what keeps the 50-step trajectory within the 1e-3 latent-RMSE budget).
+ *   - GEMM-shaped math runs on 16-bit MFMA (fp16 by default, bf16 in the -DMVD_OPERAND_BF16 build; same rate).
+ *     `prec` selects MVD_PREC_BF16 (= one product per operand pair) or MVD_PREC_BF16X3 (= operands split
+ *     x = hi + lo, three products hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2^-22 (fp16) / ~2^-17 (bf16) relative
+ *     operand error; the 50-step stochastic trajectory amplifies operand error by ~10^3, so the split is what keeps it
+ *     within the 1e-3 latent-RMSE budget).
  *   - one host thread per process / GPU (matches the reference's mp.spawn model, demo.py:208).
  */
 #ifndef MVD_HIP_H
@@ -34,18 +36,25 @@ typedef void* mvd_stream_t; /* hipStream_t */
 
 int mvd_version(void);
 const char* mvd_last_error(void);
+/* MFMA operand element type this library was built for: 0xf16 (fp16, default) or 0xbf16 (-DMVD_OPERAND_BF16).
+ * Every "split planes" / packed-weight buffer holds that type; the two flavours are separate .so files. */
+int mvd_operand_format(void);
 
 /* ------------------------------------------------------------------------------------------------
- * Weight packing (once per model load).  Packed image: [K/32][N/16][2 planes: hi, lo][16 n][32 k] bf16,
+ * Weight packing (once per model load).  Packed image: [K/32][N/16][16 n][32 k hi | 32 k lo] bf16 (2 KiB micro-tiles),
  * K padded to 32, N padded to 16 with zeros.  Bytes = mvd_packed_weight_bytes(N, K).
  * Replaces nothing in the reference (its weights stay fp32 nn.Parameters); the Python mirrors keep the
  * fp32 parameters under the reference's state_dict keys and pack on first use. */
 size_t mvd_packed_weight_bytes(int N, int K);
 /* w: (N, K) row-major fp32 with leading dimension ldw.  geglu != 0 interleaves value/gate row blocks of 16
  * (rows [0,N/2) = value, [N/2,N) = gate, attention.py:43-44) so a GEMM tile holds matching value/gate columns. */
-int mvd_pack_linear_weight(const float* w, int N, int K, int ldw, int geglu, void* packed, mvd_stream_t stream);
+/* scale: power of two applied to the weights before the split (keeps the low part out of fp16's subnormal range);
+ * the GEMM undoes it exactly through mvd_gemm_desc.acc_scale = 1/scale. */
+int mvd_pack_linear_weight(const float* w, int N, int K, int ldw, int geglu, float scale, void* packed,
+                           mvd_stream_t stream);
 /* w: (Cout, Cin, 3, 3) fp32 (nn.Conv2d layout).  Packed K index = (ky*3+kx)*cin_pad + ci. */
-int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, void* packed, mvd_stream_t stream);
+int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, float scale, void* packed,
+                            mvd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM / implicit-GEMM convolution with fused epilogue.
@@ -66,25 +75,25 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, void
 
 typedef struct mvd_gemm_desc {
   int M, N, K;      /* logical sizes; N % 16 == 0 after padding of the packed weight, K as packed (multiple of 32) */
-  /* A operand: activations as split-bf16 planes (x ~= hi + lo, 2 x bf16 = the bytes of one fp32), produced by the
-   * previous kernel (mvd_groupnorm_nhwc, mvd_layernorm, mvd_attention, a GEMM epilogue, mvd_split_planes ...).
-   * A_lo may be NULL with MVD_PREC_BF16. */
-  const void* A_hi;
-  const void* A_lo;
-  int lda;          /* elements; multiple of 8 */
+  /* A operand: activations in the SPLIT-PLANES format, produced by the previous kernel (mvd_groupnorm_nhwc,
+   * mvd_layernorm, mvd_attention, a GEMM epilogue, mvd_split_planes ...):  x ~= hi + lo as bf16; a (rows, lda) matrix
+   * is stored per row as lda/32 blocks of [32 x hi | 32 x lo] (128 contiguous bytes per row and 32-element k-block,
+   * the unit the kernel's LDS-DMA moves).  Same bytes as fp32.  128-byte aligned. */
+  const void* A;
+  int lda;          /* elements per row; multiple of 32 */
   int a_mode;       /* MVD_A_* */
   /* conv geometry (a_mode == MVD_A_CONV3X3) */
   int B, Hin, Win, Cin, Hout, Wout, stride, upsample; /* upsample: input is nearest-2x upsampled before the conv */
   const void* Wp;   /* packed weight (mvd_pack_*) */
+  float acc_scale;  /* accumulator scale = 1 / (pack scale); 0 is treated as 1 */
   int prec;         /* MVD_PREC_* */
   /* epilogue */
   int epi;          /* MVD_EPI_* */
   int act;          /* MVD_ACT_* */
   float* out;       /* fp32 output or NULL */
   int ldo;
-  void* out_hi;     /* optional split-bf16 plane output (feeds the next GEMM's A operand) */
-  void* out_lo;
-  int ldp;
+  void* out_sp;     /* optional split-planes output (feeds the next GEMM's A operand) */
+  int ldp;          /* elements per row of out_sp; multiple of 32 */
   int n_store;      /* columns actually stored (<= N; lets N be padded to 16, e.g. the 5-channel UNet head) */
   const float* bias;     /* [N] or NULL */
   const float* bias_b;   /* [M / rows_per_batch][N] or NULL (per-view vector, e.g. the kv_len==1 cross-attention) */
@@ -103,13 +112,17 @@ typedef struct mvd_gemm_desc {
   int splitk;
   float* workspace;
   size_t workspace_elems;
+  /* kernel configuration: 0 = built-in heuristic; 1 = 64x64 tile / 3 LDS stages, 2 = 64x64 / 2 stages,
+   * 3 = 128x128 / 2 stages, 4 = 128x128 / 3 stages.  The host mirror times the candidates once per distinct problem
+   * shape during the eager warm-up step and passes the winner from then on (mvdfusion_amd/hip.py: autotune). */
+  int cfg;
 } mvd_gemm_desc;
 
 int mvd_gemm(const mvd_gemm_desc* d, mvd_stream_t stream);
 
-/* fp32 (rows, cols) matrix with leading dim ldx -> split-bf16 planes (rows, ldp); columns [cols, ldp) are zero.
+/* fp32 (rows, cols) matrix with leading dim ldx -> split planes (rows, ldp), ldp % 32 == 0; columns [cols, ldp) are 0.
  * Used where a GEMM consumes a tensor that only exists in fp32 (residual stream into the 1x1 skip / up / down convs). */
-int mvd_split_planes(const float* x, void* hi, void* lo, size_t rows, int cols, int ldx, int ldp, mvd_stream_t stream);
+int mvd_split_planes(const float* x, void* sp, size_t rows, int cols, int ldx, int ldp, mvd_stream_t stream);
 
 /* fp32 matrix-vector products for the M<=16 cases (exact fp32 FMA):
  *   y[m, n] = act_out( sum_k W[n,k] * act_in(x[m,k]) + bias[n] ),  W (N,K) row-major fp32.
@@ -125,45 +138,45 @@ int mvd_gemv(const float* W, const float* bias, const float* x, float* y, int M,
  * attention.py:76,243,274 and mvdfusion/attention.py:92,132 eps 1e-6; unet.py:496-498).
  * ws: B * chunks * groups * 2 doubles with chunks = mvd_groupnorm_chunks(HW). */
 int mvd_groupnorm_chunks(int HW);
-/* y_hi / y_lo: the normalised activations as split-bf16 planes (B*HW, C) -- GroupNorm only ever feeds a GEMM / conv. */
-int mvd_groupnorm_nhwc(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta, int B, int HW,
-                       int C, int groups, float eps, int silu, double* ws, mvd_stream_t stream);
+/* y_sp: the normalised activations in split-planes format (B*HW, C), C % 32 == 0 -- GroupNorm only feeds GEMMs / convs. */
+int mvd_groupnorm_nhwc(const float* x, void* y_sp, const float* gamma, const float* beta, int B, int HW, int C,
+                       int groups, float eps, int silu, double* ws, mvd_stream_t stream);
 /* LayerNorm over the last dim.  w/b may be NULL (no affine).  w_plus_one: y = norm * (1 + w) + b
  * (adaLN "modulate", view_attn_efficient2.py:15-16,51,53,65-66); attention.py:211-213, mvdfusion/attention.py:35-37. */
-int mvd_layernorm(const float* x, void* y_hi, void* y_lo, const float* w, const float* b, int rows, int C, float eps,
-                  int w_plus_one, mvd_stream_t stream);
+int mvd_layernorm(const float* x, void* y_sp, const float* w, const float* b, int rows, int C, float eps,
+                  int w_plus_one, mvd_stream_t stream); /* y_sp: split planes (rows, C), C % 32 == 0 */
 
 /* ------------------------------------------------------------------------------------------------
  * Self-attention over the tokens of one view (CrossAttention with context=None, attention.py:170-193).
  * Operand planes are written by mvd_gemm(MVD_EPI_QKV):
  *   q/k : [B][heads][Lpad][dq]   bf16, dq  = roundup(dhead, 32), zero padded, q pre-scaled by dhead^-0.5
  *   vt  : [B][heads][dv][Lpad]   bf16, dv  = roundup(dhead, 16)   (V transposed: keys contiguous)
- * out : (B*L, heads*dhead) split-bf16 planes (leading dim ldo), head-major channels ('b n (h d)'): feeds to_out. */
+ * out : (B*L, ldo) split planes, head-major channels ('b n (h d)'): feeds the to_out GEMM. */
 size_t mvd_attn_qk_plane_elems(int B, int heads, int L, int dhead);
 size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead);
 int mvd_attn_lpad(int L);
 int mvd_attention(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
-                  const void* vt_lo, void* out_hi, void* out_lo, int ldo, int B, int heads, int L, int dhead, int prec,
+                  const void* vt_lo, void* out_sp, int ldo, int B, int heads, int L, int dhead, int prec,
                   mvd_stream_t stream);
 
 /* Per-pixel cross attention of one query token against D context tokens (DualAttnetionBlock attn2,
  * mvdfusion/attention.py:56-62; D = n_pts_per_ray).  q (P, C), k/v (P*D, C), out (P, C), C = heads*dhead. */
-int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, void* out_hi, void* out_lo, int P, int D,
-                         int heads, int dhead, mvd_stream_t stream);
+int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, void* out_sp, int P, int D, int heads,
+                         int dhead, mvd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Layout / data-movement kernels. */
 /* UNet input (unet.py:167-187): x (V,5,S,S) NCHW, input_latents (1,5,S,S) NCHW ->
- * out (2V, S, S, cpad) NHWC split-bf16 planes: rows [0,V) = [x, il[:4]/0.18215, il[4]] , rows [V,2V) = [x, 0]; channels >= 10 zero.
+ * out (2V*S*S, cpad) NHWC in split-planes format: rows [0,V) = [x, il[:4]/0.18215, il[4]] , rows [V,2V) = [x, 0]; channels >= 10 zero.
  * With cfg == 0 only the first V rows are produced. */
-int mvd_unet_input(const float* x, const float* input_latents, void* out_hi, void* out_lo, int V, int S, int cpad,
-                   int cfg, mvd_stream_t stream);
+int mvd_unet_input(const float* x, const float* input_latents, void* out_sp, int V, int S, int cpad, int cfg,
+                   mvd_stream_t stream);
 /* out[r, 0:Ca] = a[r], out[r, Ca:Ca+Cb] = b[r]  (torch.cat([h, hs.pop()], dim=1), unet.py:550) */
-int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_hi, void* out_lo,
-                        int rows, mvd_stream_t stream); /* out_hi/out_lo optional: planes for the 1x1 skip conv */
+int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_sp, int rows,
+                        mvd_stream_t stream); /* out_sp optional: split planes for the 1x1 skip conv */
 /* area pooling by `factor` of vol (B, S, S, D, C) -> (B, S/f, S/f, D, C)  (unet.py:198-209) */
-int mvd_area_pool(const float* vol, void* out_hi, void* out_lo, int B, int S, int D, int C, int factor,
-                  mvd_stream_t stream); /* output: split-bf16 planes (the pooled levels only feed to_k / to_v GEMMs) */
+int mvd_area_pool(const float* vol, void* out_sp, int B, int S, int D, int C, int factor,
+                  mvd_stream_t stream); /* output: split planes (the pooled levels only feed to_k / to_v GEMMs) */
 /* out[i] = 0 (memset as a kernel so it is graph-capturable on any stream) */
 int mvd_fill_zero(float* p, size_t n, mvd_stream_t stream);
 
@@ -195,14 +208,14 @@ int mvd_zembed(const float* lat, const float* w, const float* b, float* feat, in
 int mvd_gridattn_tokens(const float* x, const float* depth_noise, const float* steps, const int* iter,
                         const float* grid_lin /* (S) = linspace(1-1/S, -1+1/S, S), ray_utils.py:263-267 */,
                         const float* feat, const float* in_feat, const float* cams, const float* in_cam,
-                        void* tokens_hi, void* tokens_lo, int V, int q0, int Vq, int S, int D, float depth_scale,
-                        float depth_shift, mvd_stream_t stream);
+                        void* tokens_sp, int V, int q0, int Vq, int S, int D, float depth_scale, float depth_shift,
+                        mvd_stream_t stream);
 /* timm Attention core over the V reference views (:52): qkv (Nseq*V, 3*heads*dhead) -> out (Nseq*V, heads*dhead) */
-int mvd_view_mha(const float* qkv, void* out_hi, void* out_lo, int Nseq, int V, int heads, int dhead,
-                 mvd_stream_t stream); /* output planes */
+int mvd_view_mha(const float* qkv, void* out_sp, int Nseq, int V, int heads, int dhead,
+                 mvd_stream_t stream); /* output: split planes */
 /* weight_layer + softmax over V + weighted sum (:83,396-397): x (Nseq*V, C) -> out (Nseq, C) */
-int mvd_view_pool(const float* x, const float* w, const float* b, void* out_hi, void* out_lo, int Nseq, int V, int C,
-                  mvd_stream_t stream); /* output planes */
+int mvd_view_pool(const float* x, const float* w, const float* b, void* out_sp, int Nseq, int V, int C,
+                  mvd_stream_t stream); /* output: split planes */
 
 /* ------------------------------------------------------------------------------------------------
  * CFG combine + DDIM update (unet.py:195; sampler.py:43-66), fused elementwise.

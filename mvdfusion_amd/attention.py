@@ -211,8 +211,7 @@ class ViewAlignedFeatureTransformer(nn.Module):
             ctx.gemm(vol, a2("k"), k)
             ctx.gemm(vol, a2("v"), v)
             o2 = ctx.ws.planes("tf.o2", M, C)
-            hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o2[0]), hip.ptr(o2[1]),
-                                                     M, D, tb.n_heads, tb.d_head, hip.stream()))
+            hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o2), M, D, tb.n_heads, tb.d_head, hip.stream()))
             ctx.gemm(o2, a2("out"), t2b, res=t2)
         t3 = tb.feed_forward(ctx, t2b, M, "tf")
         if out is None:

@@ -18,8 +18,7 @@ template <int DQ, int DV, int NS>
 __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
                                                    const u16* __restrict__ k_hi, const u16* __restrict__ k_lo,
                                                    const u16* __restrict__ vt_hi, const u16* __restrict__ vt_lo,
-                                                   u16* __restrict__ out_hi, u16* __restrict__ out_lo, int ldo, int H, int L, int Lpad,
-                                                   int dhead) {
+                                                   u16* __restrict__ out_sp, int ldo, int H, int L, int Lpad, int dhead) {
   constexpr int NPL = NS == 3 ? 2 : 1;
   constexpr int KP = DQ + 8;       // LDS pitch of a K row (bf16 elements)
   constexpr int VP = KV_TILE + 8;  // LDS pitch of a V^T row
@@ -82,10 +81,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
         const bf16x8 kh = *(const bf16x8*)&sK[0][kt * 16 + c][ks * 32 + g * 8];
         if (NS == 3) {
           const bf16x8 kl = *(const bf16x8*)&sK[NPL - 1][kt * 16 + c][ks * 32 + g * 8];
-          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], s[kt], 0, 0, 0);
-          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], s[kt], 0, 0, 0);
+          s[kt] = MVD_MFMA_16x16x32(kl, qh[ks], s[kt], 0, 0, 0);
+          s[kt] = MVD_MFMA_16x16x32(kh, ql[ks], s[kt], 0, 0, 0);
         }
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], s[kt], 0, 0, 0);
+        s[kt] = MVD_MFMA_16x16x32(kh, qh[ks], s[kt], 0, 0, 0);
       }
     }
     // ---- online softmax (per query column c; keys are spread over registers and the 4 lane groups)
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
         if (NS == 3) {
           split_bf16(pv, H8.e[j], L8.e[j]);
         } else {
-          H8.e[j] = f32_to_bf16_rne(pv);
+          H8.e[j] = to_op_bits(pv);
         }
       }
       ph[u] = H8.v;
@@ -142,10 +141,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
         if (NS == 3) {
           VL.h2[0] = *(const uint2*)&sV[NPL - 1][dt * 16 + c][32 * u + 4 * g];
           VL.h2[1] = *(const uint2*)&sV[NPL - 1][dt * 16 + c][32 * u + 16 + 4 * g];
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VL.v, ph[u], o[dt], 0, 0, 0);
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VH.v, pl2[u], o[dt], 0, 0, 0);
+          o[dt] = MVD_MFMA_16x16x32(VL.v, ph[u], o[dt], 0, 0, 0);
+          o[dt] = MVD_MFMA_16x16x32(VH.v, pl2[u], o[dt], 0, 0, 0);
         }
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VH.v, ph[u], o[dt], 0, 0, 0);
+        o[dt] = MVD_MFMA_16x16x32(VH.v, ph[u], o[dt], 0, 0, 0);
       }
     }
   }
@@ -155,19 +154,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
   const float inv = 1.0f / l_tot;
   const int q = q0 + c;
   if (q < L) {
-    const size_t orow = ((size_t)b * L + q) * ldo + h * dhead;
+    const size_t orow = (size_t)b * L + q;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const int d0 = dt * 16 + g * 4;
-      if (d0 < dhead) store_planes4(out_hi, out_lo, orow + d0, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      if (d0 < dhead) store_sp4(out_sp, orow, ldo, h * dhead + d0, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
     }
   }
 }
 
 // one wave per pixel; lanes stride over channels of a head. q (P,C), k/v (P*D, C), D <= 8.
 __global__ __launch_bounds__(256) void pixel_xattn_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                          const float* __restrict__ v, u16* __restrict__ out_hi,
-                                                          u16* __restrict__ out_lo, int P, int D, int heads, int dhead) {
+                                                          const float* __restrict__ v, u16* __restrict__ out_sp, int P, int D,
+                                                          int heads, int dhead) {
   const int lane = threadIdx.x & 63;
   const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pix >= P) return;
@@ -191,14 +190,14 @@ __global__ __launch_bounds__(256) void pixel_xattn_kernel(const float* __restric
     for (int e = lane; e < dhead; e += 64) {
       float acc = 0.f;
       for (int j = 0; j < D; ++j) acc += (sc[j] / den) * v[((size_t)pix * D + j) * C + h * dhead + e];
-      store_planes1(out_hi, out_lo, (size_t)pix * C + h * dhead + e, acc);
+      store_sp1(out_sp, (size_t)pix, C, h * dhead + e, acc);
     }
   }
 }
 
 // one thread per (sequence, head, query view); qkv row layout [3][heads][dhead] (timm reshape B,N,3,H,hd).
-__global__ __launch_bounds__(256) void view_mha_kernel(const float* __restrict__ qkv, u16* __restrict__ out_hi,
-                                                       u16* __restrict__ out_lo, int Nseq, int V, int heads, int dhead) {
+__global__ __launch_bounds__(256) void view_mha_kernel(const float* __restrict__ qkv, u16* __restrict__ out_sp, int Nseq, int V,
+                                                       int heads, int dhead) {
   const size_t total = (size_t)Nseq * heads * V;
   const int C = heads * dhead;
   const float scale = rsqrtf((float)dhead);
@@ -221,19 +220,19 @@ __global__ __launch_bounds__(256) void view_mha_kernel(const float* __restrict__
       sc[j] = expf(sc[j] - mx);
       den += sc[j];
     }
-    const size_t orow = (n * V + vq) * C + h * dhead;
+    const size_t orow = n * V + vq;
     for (int d = 0; d < dhead; ++d) {
       float a = 0.f;
       for (int j = 0; j < V; ++j) a += (sc[j] / den) * qkv[(n * V + j) * 3 * C + 2 * C + h * dhead + d];
-      store_planes1(out_hi, out_lo, orow + d, a);
+      store_sp1(out_sp, orow, C, h * dhead + d, a);
     }
   }
 }
 
 // one wave per sequence: logits w.x_v + b, softmax over V, out = sum_v p_v x_v.  C % 64 == 0, C <= 512.
 __global__ __launch_bounds__(256) void view_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, u16* __restrict__ out_hi,
-                                                        u16* __restrict__ out_lo, int Nseq, int V, int C) {
+                                                        const float* __restrict__ bias, u16* __restrict__ out_sp, int Nseq, int V,
+                                                        int C) {
   const int lane = threadIdx.x & 63;
   const size_t n = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= (size_t)Nseq) return;
@@ -253,20 +252,20 @@ __global__ __launch_bounds__(256) void view_pool_kernel(const float* __restrict_
   for (int e = lane; e < C; e += 64) {
     float a = 0.f;
     for (int v = 0; v < V; ++v) a += x[(n * V + v) * C + e] * (lg[v] / den);
-    store_planes1(out_hi, out_lo, n * C + e, a);
+    store_sp1(out_sp, n, C, e, a);
   }
 }
 
 template <int NS>
 int launch_attn(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi, const void* vt_lo,
-                void* out_hi, void* out_lo, int ldo, int B, int H, int L, int Lpad, int dhead, hipStream_t s) {
+                void* out_sp, int ldo, int B, int H, int L, int Lpad, int dhead, hipStream_t s) {
   const int dq = (dhead + 31) & ~31, dv = (dhead + 15) & ~15;
   dim3 grid(Lpad / 64, H, B), block(256);
 #define MVD_ATTN_CASE(DQ, DV)                                                                                          \
   if (dq == DQ && dv == DV) {                                                                                          \
     hipLaunchKernelGGL((attn_kernel<DQ, DV, NS>), grid, block, 0, s, (const u16*)q_hi, (const u16*)q_lo,               \
-                       (const u16*)k_hi, (const u16*)k_lo, (const u16*)vt_hi, (const u16*)vt_lo, (u16*)out_hi,         \
-                       (u16*)out_lo, ldo, H, L, Lpad, dhead);                                                          \
+                       (const u16*)k_hi, (const u16*)k_lo, (const u16*)vt_hi, (const u16*)vt_lo, (u16*)out_sp, ldo, H, \
+                       L, Lpad, dhead);                                                                                \
     return 0;                                                                                                          \
   }
   MVD_ATTN_CASE(32, 16)
@@ -290,49 +289,45 @@ extern "C" size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead) {
 }
 
 extern "C" int mvd_attention(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
-                             const void* vt_lo, void* out_hi, void* out_lo, int ldo, int B, int heads, int L, int dhead,
-                             int prec, mvd_stream_t stream) {
-  MVD_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out_hi && out_lo, "mvd_attention: null pointer");
+                             const void* vt_lo, void* out_sp, int ldo, int B, int heads, int L, int dhead, int prec,
+                             mvd_stream_t stream) {
+  MVD_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out_sp, "mvd_attention: null pointer");
   MVD_CHECK_ARG(B > 0 && heads > 0 && L > 0 && dhead > 0 && dhead % 4 == 0, "mvd_attention: bad shape (dhead %% 4 == 0)");
-  MVD_CHECK_ARG(ldo % 4 == 0 && ((uintptr_t)out_hi & 7) == 0 && ((uintptr_t)out_lo & 7) == 0,
-                "mvd_attention: out planes must be 8-byte aligned, ldo %% 4 == 0");
+  MVD_CHECK_ARG(ldo % 32 == 0 && ((uintptr_t)out_sp & 127) == 0, "mvd_attention: out must be split planes (ldo %% 32 == 0, 128-byte aligned)");
   MVD_CHECK_ARG(prec == MVD_PREC_BF16 || prec == MVD_PREC_BF16X3, "mvd_attention: bad prec");
   const int Lpad = mvd_attn_lpad(L);
   int rc;
   if (prec == MVD_PREC_BF16X3)
-    rc = launch_attn<3>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_hi, out_lo, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+    rc = launch_attn<3>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
   else
-    rc = launch_attn<1>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_hi, out_lo, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+    rc = launch_attn<1>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
   MVD_CHECK_ARG(rc == 0, "mvd_attention: unsupported head dim %d (supported: <=32, 33..64, 65..96 with dv 80, 160)", dhead);
   MVD_CHECK_LAUNCH("mvd_attention");
   return 0;
 }
 
-extern "C" int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, void* out_hi, void* out_lo, int P, int D,
-                                    int heads, int dhead, mvd_stream_t stream) {
-  MVD_CHECK_ARG(q && k && v && out_hi && out_lo && P > 0 && D > 0 && D <= 8 && heads > 0 && dhead > 0, "mvd_pixel_cross_attn: bad arguments (D <= 8)");
-  hipLaunchKernelGGL(pixel_xattn_kernel, dim3(cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, (u16*)out_hi, (u16*)out_lo, P, D, heads,
-                     dhead);
+extern "C" int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, void* out_sp, int P, int D, int heads,
+                                    int dhead, mvd_stream_t stream) {
+  MVD_CHECK_ARG(q && k && v && out_sp && (heads * dhead) % 32 == 0 && P > 0 && D > 0 && D <= 8 && heads > 0 && dhead > 0, "mvd_pixel_cross_attn: bad arguments (D <= 8)");
+  hipLaunchKernelGGL(pixel_xattn_kernel, dim3(cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, (u16*)out_sp, P, D, heads, dhead);
   MVD_CHECK_LAUNCH("mvd_pixel_cross_attn");
   return 0;
 }
 
-extern "C" int mvd_view_mha(const float* qkv, void* out_hi, void* out_lo, int Nseq, int V, int heads, int dhead,
-                            mvd_stream_t stream) {
-  MVD_CHECK_ARG(qkv && out_hi && out_lo && Nseq > 0 && V > 0 && V <= 16 && heads > 0 && dhead > 0, "mvd_view_mha: bad arguments (V <= 16)");
+extern "C" int mvd_view_mha(const float* qkv, void* out_sp, int Nseq, int V, int heads, int dhead, mvd_stream_t stream) {
+  MVD_CHECK_ARG(qkv && out_sp && (heads * dhead) % 32 == 0 && Nseq > 0 && V > 0 && V <= 16 && heads > 0 && dhead > 0, "mvd_view_mha: bad arguments (V <= 16)");
   const size_t total = (size_t)Nseq * heads * V;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(view_mha_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, (u16*)out_hi, (u16*)out_lo, Nseq, V, heads,
-                     dhead);
+  hipLaunchKernelGGL(view_mha_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, (u16*)out_sp, Nseq, V, heads, dhead);
   MVD_CHECK_LAUNCH("mvd_view_mha");
   return 0;
 }
 
-extern "C" int mvd_view_pool(const float* x, const float* w, const float* b, void* out_hi, void* out_lo, int Nseq, int V, int C,
+extern "C" int mvd_view_pool(const float* x, const float* w, const float* b, void* out_sp, int Nseq, int V, int C,
                              mvd_stream_t stream) {
-  MVD_CHECK_ARG(x && w && b && out_hi && out_lo && Nseq > 0 && V > 0 && V <= 16 && C > 0, "mvd_view_pool: bad arguments (V <= 16)");
-  hipLaunchKernelGGL(view_pool_kernel, dim3(cdiv(Nseq, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, (u16*)out_hi, (u16*)out_lo, Nseq, V, C);
+  MVD_CHECK_ARG(x && w && b && out_sp && C % 32 == 0 && Nseq > 0 && V > 0 && V <= 16 && C > 0, "mvd_view_pool: bad arguments (V <= 16)");
+  hipLaunchKernelGGL(view_pool_kernel, dim3(cdiv(Nseq, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, (u16*)out_sp, Nseq, V, C);
   MVD_CHECK_LAUNCH("mvd_view_pool");
   return 0;
 }

@@ -9,7 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "gridattn.hip"]
-LIB = os.path.join(HERE, "libmvd_hip.so")
+LIB = os.path.join(HERE, "libmvd_hip.so")            # fp16 MFMA operands (default)
+LIB_BF16 = os.path.join(HERE, "libmvd_hip_bf16.so")  # bf16 MFMA operands (-DMVD_OPERAND_BF16)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -23,13 +24,17 @@ def _stale(out, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     common = [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "..", "..", "include", "mvd_hip.h")]
-    objs, jobs = [], []
-    for src in SOURCES:
-        s = os.path.join(HERE, src)
-        o = os.path.join(HERE, src.replace(".hip", ".o"))
-        objs.append(o)
-        if force or _stale(o, [s] + common):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+    flavours = [("", [], LIB), ("_bf16", ["-DMVD_OPERAND_BF16"], LIB_BF16)]
+    jobs, links = [], []
+    for suffix, defs, lib in flavours:
+        objs = []
+        for src in SOURCES:
+            s_ = os.path.join(HERE, src)
+            o = os.path.join(HERE, src.replace(".hip", suffix + ".o"))
+            objs.append(o)
+            if force or _stale(o, [s_] + common):
+                jobs.append([hipcc] + FLAGS + defs + ["-c", s_, "-o", o])
+        links.append((lib, objs))
 
     def run(cmd):
         if verbose:
@@ -40,10 +45,11 @@ def build(force=False, verbose=True):
         if verbose and r.stderr.strip():
             print(r.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    for lib, objs in links:
+        if jobs or force or _stale(lib, objs):
+            run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return LIB
 
 

@@ -4,8 +4,19 @@
 #include <stdint.h>
 #include <stdio.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// MFMA operand element type.  Default: fp16 (11-bit significand; the 2-term split x ~= hi + lo then carries ~22 bits,
+// i.e. fp32-class products).  -DMVD_OPERAND_BF16 builds the bf16 flavour (8-bit significand, ~16 bits split, scale-free
+// exponent range).  Both run at the same MFMA rate on gfx950.
+#ifdef MVD_OPERAND_BF16
+typedef __bf16 op_t;
+#define MVD_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MVD_OPERAND_FORMAT 0xbf16
+#else
+typedef _Float16 op_t;
+#define MVD_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define MVD_OPERAND_FORMAT 0xf16
+#endif
+typedef __attribute__((ext_vector_type(8))) op_t bf16x8;   // 8 MFMA operand elements (historical name)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short u16;
 
@@ -45,14 +56,42 @@ __device__ __forceinline__ u16 f32_to_bf16_rne(float f) {
 __device__ __forceinline__ float bf16_to_f32(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 __device__ __forceinline__ void split_bf16(float x, u16& hi, u16& lo) {
-  // compiler-native conversions (v_cvt_pk_bf16_f32 on gfx950, round-to-nearest-even)
-  const __bf16 h = (__bf16)x;
-  const __bf16 l = (__bf16)(x - (float)h);
+  // x ~= hi + lo in the operand type; compiler-native conversions (v_cvt_pk_*), round-to-nearest-even
+  const op_t h = (op_t)x;
+  const op_t l = (op_t)(x - (float)h);
   hi = __builtin_bit_cast(u16, h);
   lo = __builtin_bit_cast(u16, l);
 }
+__device__ __forceinline__ u16 to_op_bits(float x) { return __builtin_bit_cast(u16, (op_t)x); }
 
-// four consecutive elements -> 8 bytes in each plane (idx must be a multiple of 4)
+// ------------------------------------------------------------------------------------------------
+// "Split planes" activation format (the A operand of mvd_gemm): a (rows, K) matrix, K % 32 == 0, stored per row as
+// K/32 blocks of [32 x bf16 hi | 32 x bf16 lo] = 128 contiguous bytes per (row, 32-element k-block): exactly one cache
+// line and exactly the unit the GEMM's LDS-DMA moves per row per k-tile.  Same bytes as fp32.
+// Element (row, k): hi at  row*2*ld + (k>>5)*64 + (k&31)   (u16 units),  lo 32 u16 further.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t sp_index(size_t row, int ld, int k) { return row * 2 * (size_t)ld + (size_t)(k >> 5) * 64 + (k & 31); }
+
+// four consecutive elements k..k+3 (k % 4 == 0) of one row
+__device__ __forceinline__ void store_sp4(u16* __restrict__ base, size_t row, int ld, int k, float a, float b, float c, float d) {
+  u16 h[4], l[4];
+  split_bf16(a, h[0], l[0]);
+  split_bf16(b, h[1], l[1]);
+  split_bf16(c, h[2], l[2]);
+  split_bf16(d, h[3], l[3]);
+  u16* p = base + sp_index(row, ld, k);
+  *(uint2*)p = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+  *(uint2*)(p + 32) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+__device__ __forceinline__ void store_sp1(u16* __restrict__ base, size_t row, int ld, int k, float a) {
+  u16 h, l;
+  split_bf16(a, h, l);
+  u16* p = base + sp_index(row, ld, k);
+  p[0] = h;
+  p[32] = l;
+}
+
+// attention operand planes (separate hi / lo arrays): four consecutive elements -> 8 bytes in each plane
 __device__ __forceinline__ void store_planes4(u16* __restrict__ hi, u16* __restrict__ lo, size_t idx, float a, float b,
                                               float c, float d) {
   u16 h[4], l[4];

@@ -61,8 +61,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ W, 
 }
 
 __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict__ x, const float* __restrict__ il,
-                                                         u16* __restrict__ out_hi, u16* __restrict__ out_lo, int V, int S, int cpad,
-                                                         int nb) {
+                                                         u16* __restrict__ out_sp, int V, int S, int cpad, int nb) {
   const int SS = S * S;
   const size_t total = (size_t)nb * SS * cpad;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -77,13 +76,12 @@ __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict
       const float t = il[(size_t)(c - 5) * SS + pix];
       o = (c < 9) ? t / 0.18215f : t;
     }
-    store_planes1(out_hi, out_lo, e, o);
+    store_sp1(out_sp, e / cpad, cpad, c, o);
   }
 }
 
 __global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ a, int ca4, const float4* __restrict__ b, int cb4,
-                                                     float4* __restrict__ out, u16* __restrict__ out_hi, u16* __restrict__ out_lo,
-                                                     size_t rows) {
+                                                     float4* __restrict__ out, u16* __restrict__ out_sp, size_t rows) {
   const int c4 = ca4 + cb4;
   const size_t total = rows * c4;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -91,13 +89,13 @@ __global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ 
     const int c = (int)(e - r * c4);
     const float4 v = c < ca4 ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
     out[e] = v;
-    if (out_hi) store_planes4(out_hi, out_lo, e * 4, v.x, v.y, v.z, v.w);
+    if (out_sp) store_sp4(out_sp, r, c4 * 4, c * 4, v.x, v.y, v.z, v.w);
   }
 }
 
 // vol (B,S,S,D,C) -> out (B,S/f,S/f,D,C), mean over f x f windows (F.interpolate(mode='area') with integer ratio)
-__global__ __launch_bounds__(256) void area_pool_kernel(const float4* __restrict__ vol, u16* __restrict__ out_hi,
-                                                        u16* __restrict__ out_lo, int B, int S, int D, int C4, int f) {
+__global__ __launch_bounds__(256) void area_pool_kernel(const float4* __restrict__ vol, u16* __restrict__ out_sp, int B, int S,
+                                                        int D, int C4, int f) {
   const int So = S / f;
   const size_t total = (size_t)B * So * So * D * C4;
   const float inv = 1.0f / (float)(f * f);
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(256) void area_pool_kernel(const float4* __restrict
         acc.z += v.z;
         acc.w += v.w;
       }
-    store_planes4(out_hi, out_lo, e * 4, acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    store_sp4(out_sp, e / C4, C4 * 4, c * 4, acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
   }
 }
 
@@ -199,36 +197,36 @@ extern "C" int mvd_gemv(const float* W, const float* bias, const float* x, float
   return 0;
 }
 
-extern "C" int mvd_unet_input(const float* x, const float* input_latents, void* out_hi, void* out_lo, int V, int S, int cpad,
-                              int cfg, mvd_stream_t stream) {
-  MVD_CHECK_ARG(x && input_latents && out_hi && out_lo && V > 0 && S > 0 && cpad >= 10, "mvd_unet_input: bad arguments");
+extern "C" int mvd_unet_input(const float* x, const float* input_latents, void* out_sp, int V, int S, int cpad, int cfg,
+                              mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && input_latents && out_sp && cpad % 32 == 0 && V > 0 && S > 0 && cpad >= 10, "mvd_unet_input: bad arguments");
   const int nb = cfg ? 2 * V : V;
   const size_t total = (size_t)nb * S * S * cpad;
-  hipLaunchKernelGGL(unet_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, input_latents, (u16*)out_hi,
-                     (u16*)out_lo, V, S, cpad, nb);
+  hipLaunchKernelGGL(unet_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, input_latents, (u16*)out_sp, V,
+                     S, cpad, nb);
   MVD_CHECK_LAUNCH("mvd_unet_input");
   return 0;
 }
 
-extern "C" int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_hi, void* out_lo,
-                                   int rows, mvd_stream_t stream) {
+extern "C" int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_sp, int rows,
+                                   mvd_stream_t stream) {
+  if (out_sp) MVD_CHECK_ARG((Ca + Cb) % 32 == 0, "mvd_concat_channels: split-planes output needs (Ca+Cb) %% 32 == 0");
   MVD_CHECK_ARG(a && b && out && rows > 0 && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0,
                 "mvd_concat_channels: bad arguments (channel counts must be multiples of 4)");
   const size_t total = (size_t)rows * (Ca + Cb) / 4;
   hipLaunchKernelGGL(concat_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, Ca / 4,
-                     (const float4*)b, Cb / 4, (float4*)out, (u16*)out_hi, (u16*)out_lo, (size_t)rows);
+                     (const float4*)b, Cb / 4, (float4*)out, (u16*)out_sp, (size_t)rows);
   MVD_CHECK_LAUNCH("mvd_concat_channels");
   return 0;
 }
 
-extern "C" int mvd_area_pool(const float* vol, void* out_hi, void* out_lo, int B, int S, int D, int C, int factor,
-                             mvd_stream_t stream) {
-  MVD_CHECK_ARG(vol && out_hi && out_lo && B > 0 && S > 0 && D > 0 && C % 4 == 0 && factor >= 1 && S % factor == 0,
+extern "C" int mvd_area_pool(const float* vol, void* out_sp, int B, int S, int D, int C, int factor, mvd_stream_t stream) {
+  MVD_CHECK_ARG(vol && out_sp && C % 32 == 0 && B > 0 && S > 0 && D > 0 && C % 4 == 0 && factor >= 1 && S % factor == 0,
                 "mvd_area_pool: bad arguments");
   const int So = S / factor;
   const size_t total = (size_t)B * So * So * D * (C / 4);
   hipLaunchKernelGGL(area_pool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)vol,
-                     (u16*)out_hi, (u16*)out_lo, B, S, D, C / 4, factor);
+                     (u16*)out_sp, B, S, D, C / 4, factor);
   MVD_CHECK_LAUNCH("mvd_area_pool");
   return 0;
 }

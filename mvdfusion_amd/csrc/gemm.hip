@@ -2,16 +2,18 @@
 // DMA'd straight into LDS; fused epilogues.  See include/mvd_hip.h (mvd_gemm) for the contract.
 //
 // Operands
-//   A : activations as two bf16 planes (hi, lo) with x ~= hi + lo, written by the PRODUCING kernel (norms, attention,
-//       previous GEMM epilogue, ...) -- same bytes as fp32, no conversion work inside the GEMM.
-//   B : weights packed once at load time into 1 KiB micro-tiles [K/32][N/16][hi,lo][16 n][32 k].
+//   A : activations in the "split planes" format (common.hpp): x ~= hi + lo as bf16, per row and 32-element k-block
+//       [32 hi | 32 lo] = one 128-byte line, written by the PRODUCING kernel (norms, attention, previous GEMM
+//       epilogue, ...) -- same bytes as fp32, no conversion work inside the GEMM.
+//   B : weights packed once at load time into 2 KiB micro-tiles [K/32][N/16][16 n][32 hi | 32 lo].
 // Structure (per workgroup): block tile BM x BN, BK = 32, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile of
-// 16x16x32 MFMAs.  A k-tile of both operands is a set of 1 KiB granules (16 rows x 64 B); each wave instruction of
-// `global_load_lds_dwordx4` moves one granule global -> LDS with no VGPR round trip (LDS destination is lane-linear,
-// so the bank-conflict swizzle is applied to the per-lane SOURCE address and to the fragment reads: 16-byte chunk c of
-// row r lives at slot r*4 + (c ^ ((-(r>>2)) & 3)), which is conflict-free for the 16-lane ds_read_b128 groups).
-// Two LDS stages: the DMA of k-tile t+1 is in flight while the MFMAs of k-tile t run; rows/columns outside the
-// problem (M/N edges, conv zero padding) source a 16-byte zero page.
+// 16x16x32 MFMAs.  A k-tile of both operands is a set of 1 KiB granules (8 rows x one full 128-byte line each); every
+// wave instruction of `global_load_lds_dwordx4` moves one granule global -> LDS with no VGPR round trip (the LDS
+// destination is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and to the
+// fragment reads: 16-byte chunk cc (0-3 hi, 4-7 lo) of row r of a 16-row block lives at slot (r&7)*8 + (cc ^ (r>>1)),
+// which is conflict-free for the 16-lane ds_read_b128 groups).
+// 2-3 LDS stages: DMA of later k-tiles is in flight while the MFMAs of k-tile t run; rows/columns outside the problem
+// (M/N edges, conv zero padding) source a 16-byte zero page.
 // NS = 1: acc += A_hi*B_hi.   NS = 3: acc += A_lo*B_hi + A_hi*B_lo + A_hi*B_hi   (fp32 accumulate).
 #include <stdlib.h>
 
@@ -28,6 +30,7 @@ struct GemmParams {
   int nt16;      // packed N / 16
   int kt_per_split;
   int splits;
+  int tiles_m, tiles_n;
 };
 
 // ------------------------------------------------------------------------------------------------ epilogue
@@ -39,16 +42,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 __device__ __forceinline__ void store_out(const mvd_gemm_desc& d, int m, int n, float v) {
   if (d.out) d.out[(size_t)m * d.ldo + n] = v;
-  if (d.out_hi) {
-    u16 hi, lo;
-    split_bf16(v, hi, lo);
-    ((u16*)d.out_hi)[(size_t)m * d.ldp + n] = hi;
-    ((u16*)d.out_lo)[(size_t)m * d.ldp + n] = lo;
-  }
+  if (d.out_sp) store_sp1((u16*)d.out_sp, (size_t)m, d.ldp, n, v);
 }
 
+// scalar element path (split-K reduce kernel, ragged n_store edge)
 __device__ __forceinline__ void epi_store_elem(const mvd_gemm_desc& d, int m, int n, float v) {
   if (d.epi == MVD_EPI_STORE && n >= d.n_store) return;  // padded columns (bias / res have n_store entries)
+  v *= d.acc_scale;
   if (d.bias) v += d.bias[n];
   if (d.bias_b) v += d.bias_b[(size_t)(m / d.rows_per_batch) * d.N + n];
   if (d.epi == MVD_EPI_QKV) {
@@ -60,20 +60,14 @@ __device__ __forceinline__ void epi_store_elem(const mvd_gemm_desc& d, int m, in
     const int b = m / d.L;
     const int tok = m - b * d.L;
     if (which == 0) v *= d.qscale;
-    u16 hi, lo;
-    split_bf16(v, hi, lo);
     if (which < 2) {
       const int dq = (d.dhead + 31) & ~31;
       const size_t idx = ((size_t)(b * d.heads + head) * d.Lpad + tok) * dq + dd;
-      u16* ph = (u16*)(which == 0 ? d.q_hi : d.k_hi);
-      u16* pl = (u16*)(which == 0 ? d.q_lo : d.k_lo);
-      ph[idx] = hi;
-      pl[idx] = lo;
+      store_planes1((u16*)(which == 0 ? d.q_hi : d.k_hi), (u16*)(which == 0 ? d.q_lo : d.k_lo), idx, v);
     } else {
       const int dv = (d.dhead + 15) & ~15;
       const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
-      ((u16*)d.vt_hi)[idx] = hi;
-      ((u16*)d.vt_lo)[idx] = lo;
+      store_planes1((u16*)d.vt_hi, (u16*)d.vt_lo, idx, v);
     }
     return;
   }
@@ -87,6 +81,8 @@ __device__ __forceinline__ void epi_store_elem(const mvd_gemm_desc& d, int m, in
 __device__ __forceinline__ void epi_geglu_elem(const mvd_gemm_desc& d, int m, int p_value, float v, float g) {
   const int col = (p_value >> 5) * 16 + (p_value & 15);
   const int half = d.N >> 1;
+  v *= d.acc_scale;
+  g *= d.acc_scale;
   if (d.bias) {
     v += d.bias[col];
     g += d.bias[half + col];
@@ -94,47 +90,96 @@ __device__ __forceinline__ void epi_geglu_elem(const mvd_gemm_desc& d, int m, in
   store_out(d, m, col, v * gelu_erf(g));
 }
 
+// four consecutive columns n..n+3 of row m (all inside N): coalesced 16-byte traffic
+__device__ __forceinline__ void epi_store4(const mvd_gemm_desc& d, int m, int n, float4 v) {
+  v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
+  if (d.bias) {
+    const float4 b = *(const float4*)(d.bias + n);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  }
+  if (d.bias_b) {
+    const float4 b = *(const float4*)(d.bias_b + (size_t)(m / d.rows_per_batch) * d.N + n);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  }
+  if (d.act) {
+    v.x = apply_act(v.x, d.act); v.y = apply_act(v.y, d.act); v.z = apply_act(v.z, d.act); v.w = apply_act(v.w, d.act);
+  }
+  if (d.colscale) {
+    const float4 g = *(const float4*)(d.colscale + n);
+    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+  }
+  if (d.res) {
+    const float4 r = *(const float4*)(d.res + (size_t)m * d.ldr + n);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  if (d.out) *(float4*)(d.out + (size_t)m * d.ldo + n) = v;
+  if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, n, v.x, v.y, v.z, v.w);
+}
+
 // ------------------------------------------------------------------------------------------------ main kernel
-template <int BM, int BN, int WM, int WN, int NS, int AMODE>
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+  // counted wait on this wave's own DMA queue, then the workgroup barrier.  One asm statement with a memory clobber:
+  // the compiler neither drains the queue to 0 (as __syncthreads would with LDS-DMA in flight) nor moves LDS
+  // accesses across it.
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int AMODE, int STAGES>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr int NPL = (NS == 3) ? 2 : 1;
-  constexpr int A_GRAN = (BM / 16) * NPL, B_GRAN = (BN / 16) * NPL;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int A_GRAN = BM / 8, B_GRAN = BN / 8;     // 1 KiB granules (8 rows x 128 B: hi and lo of one 32-k block)
   constexpr int STAGE = (A_GRAN + B_GRAN) * 1024;
   constexpr int AI = A_GRAN / NW, BI = B_GRAN / NW;   // granules per wave per k-tile
+  constexpr int LPS = AI + BI;                        // DMA instructions per wave per stage
+  constexpr int LDW = WTN + 4;                        // fp32 pitch of the epilogue staging tile
+  constexpr int EPI_BYTES = NW * WTM * LDW * 4;
+  constexpr int SMEM = STAGES * STAGE > EPI_BYTES ? STAGES * STAGE : EPI_BYTES;
   static_assert(A_GRAN % NW == 0 && B_GRAN % NW == 0, "granules must divide evenly over the waves");
+  static_assert(WTN == 32, "epilogue assumes 32-column wave tiles (one GEGLU value/gate block, one QKV head-aligned block)");
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
   const mvd_gemm_desc& d = p.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (each XCD has a private 4 MiB L2).  Give every XCD a
+  // contiguous range of output tiles in n-fastest order, so the n-tiles that re-read one A row panel (and the
+  // neighbouring m-tiles that share the conv halo) hit the same L2 instead of 8 different ones.
+  int tile;
+  {
+    const int nb = p.tiles_n * p.tiles_m, bid = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (tile / p.tiles_n) * BM;
+  const int n0 = (tile % p.tiles_n) * BN;
   const int kt0 = blockIdx.z * p.kt_per_split;
   const int kt1 = min(p.nk, kt0 + p.kt_per_split);
+  const int nkt = kt1 - kt0;
 
-  // ---- per-lane staging roles.  Lane l of a granule fills slot l: row r = l>>2, stored chunk (l&3) holds source
-  //      chunk c = (l&3) ^ f(r),  f(r) = (-(r>>2)) & 3.
-  const int gr = lane >> 2;
-  const int gc = (lane & 3) ^ ((-(gr >> 2)) & 3);
+  // ---- per-lane staging roles.  Lane l of a granule fills slot l: row r = l>>3 (of 8), stored chunk l&7 holds source
+  //      chunk cc = (l&7) ^ f(R), f(R) = (R>>1) & 7 with R the row inside its 16-row MFMA block.
+  const int gr = lane >> 3;
   const u16* zero = (const u16*)g_zero_page;
 
-  const u16* a_src[AI];     // per A granule: source row base (k = 0) or zero page
+  const u16* a_src[AI];     // per A granule: source row base (k = 0, + this lane's chunk) or zero page
   int a_oy[AI], a_ox[AI];
   bool a_ok[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int gi = wave + i * NW;            // A granule index: mt * NPL + plane
-    const int mt = gi / NPL, plane = gi % NPL;
-    const int m = m0 + mt * 16 + gr;
+    const int gi = wave + i * NW;            // A granule index = 8-row group of the block tile
+    const int R = (gi & 1) * 8 + gr;
+    const int gc = (lane & 7) ^ ((R >> 1) & 7);
+    const int m = m0 + gi * 8 + gr;
     a_ok[i] = m < d.M;
-    const u16* base = (const u16*)(plane ? d.A_lo : d.A_hi);
+    const u16* base = (const u16*)d.A;
     if (AMODE == MVD_A_DENSE) {
-      a_src[i] = base + (size_t)(a_ok[i] ? m : 0) * d.lda + gc * 8;
+      a_src[i] = base + (size_t)(a_ok[i] ? m : 0) * 2 * d.lda + gc * 8;
       a_oy[i] = a_ox[i] = 0;
     } else {
       const int hw = d.Hout * d.Wout;
@@ -143,15 +188,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       const int rem = mm - b * hw;
       a_oy[i] = rem / d.Wout;
       a_ox[i] = rem - a_oy[i] * d.Wout;
-      a_src[i] = base + (size_t)b * d.Hin * d.Win * d.Cin + gc * 8;
+      a_src[i] = base + (size_t)b * d.Hin * d.Win * 2 * d.Cin + gc * 8;
     }
   }
-  const u16* b_src[BI];     // per B granule: micro-tile base at kt = 0 (+ this lane's chunk) or null (-> zero page)
+  const u16* b_src[BI];     // per B granule: micro-tile rows at kt = 0 (+ this lane's chunk) or null (-> zero page)
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int gi = wave + i * NW;            // B granule index: nt * NPL + plane
-    const int nt = (n0 >> 4) + gi / NPL, plane = gi % NPL;
-    b_src[i] = nt < p.nt16 ? (const u16*)d.Wp + ((size_t)nt * 2 + plane) * 512 + gr * 32 + gc * 8 : nullptr;
+    const int gi = wave + i * NW;            // B granule index = 8-row group
+    const int R = (gi & 1) * 8 + gr;
+    const int gc = (lane & 7) ^ ((R >> 1) & 7);
+    const int nt = (n0 >> 4) + (gi >> 1);
+    b_src[i] = nt < p.nt16 ? (const u16*)d.Wp + (size_t)nt * 1024 + R * 64 + gc * 8 : nullptr;
   }
   const size_t b_kstride = (size_t)p.nt16 * 1024;   // elements between consecutive k-tiles of the packed weight
 
@@ -161,7 +208,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     for (int i = 0; i < AI; ++i) {
       const u16* src;
       if (AMODE == MVD_A_DENSE) {
-        src = a_ok[i] ? a_src[i] + kt * 32 : zero;
+        src = a_ok[i] ? a_src[i] + kt * 64 : zero;
       } else {
         const int k0 = kt * 32;
         const int tap = k0 / d.Cin;
@@ -179,7 +226,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
           ix = a_ox[i] * d.stride + kx - 1;
           ok = ok && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
         }
-        src = ok ? a_src[i] + ((size_t)iy * d.Win + ix) * d.Cin + c0 : zero;
+        src = ok ? a_src[i] + ((size_t)iy * d.Win + ix) * 2 * d.Cin + c0 * 2 : zero;
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sbase + (wave + i * NW) * 1024), 16, 0, 0);
@@ -199,90 +246,162 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offset inside a granule: row = lane&15, k-chunk = lane>>4 (swizzled)
+  // fragment read offsets: row = lane&15 of a 16-row block (2 granules), hi chunk = lane>>4, lo chunk = 4 + (lane>>4)
   const int frow = lane & 15;
-  const int foff = (frow * 4 + ((lane >> 4) ^ ((-(frow >> 2)) & 3))) * 16;
+  const int fsw = (frow >> 1) & 7;
+  const int fbase = (frow >> 3) * 1024 + (frow & 7) * 128;
+  const int foff_hi = fbase + (((lane >> 4)) ^ fsw) * 16;
+  const int foff_lo = fbase + ((4 + (lane >> 4)) ^ fsw) * 16;
 
-  if (kt0 < kt1) stage(0, kt0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
-    const unsigned char* sA = smem + cur * STAGE + foff;
+  // ---- software pipeline: STAGES-1 k-tiles of DMA in flight ahead of the MFMAs
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nkt) stage(s, kt0 + s);
+  if (STAGES == 3 && nkt >= 2)
+    wait_vm_and_barrier<LPS>();
+  else
+    wait_vm_and_barrier<0>();
+  int buf = 0;
+  for (int it = 0; it < nkt; ++it) {
+    if (it + STAGES - 1 < nkt) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(nb, kt0 + it + STAGES - 1);
+    }
+    const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + A_GRAN * 1024;
     bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      ah[i] = *(const bf16x8*)(sA + ((wm * TM + i) * NPL) * 1024);
-      if (NS == 3) al[i] = *(const bf16x8*)(sA + ((wm * TM + i) * NPL + 1) * 1024);
+      ah[i] = *(const bf16x8*)(sA + (wm * TM + i) * 2048 + foff_hi);
+      if (NS == 3) al[i] = *(const bf16x8*)(sA + (wm * TM + i) * 2048 + foff_lo);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      bh[j] = *(const bf16x8*)(sB + ((wn * TN + j) * NPL) * 1024);
-      if (NS == 3) bl[j] = *(const bf16x8*)(sB + ((wn * TN + j) * NPL + 1) * 1024);
+      bh[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + foff_hi);
+      if (NS == 3) bl[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + foff_lo);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (NS == 3) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = MVD_MFMA_16x16x32(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = MVD_MFMA_16x16x32(ah[i], bl[j], acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = MVD_MFMA_16x16x32(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // k-tile it+1 must have landed (all waves) before anyone reads it; with 3 stages one more tile stays in flight
+    if (STAGES == 3 && it + 2 < nkt)
+      wait_vm_and_barrier<LPS>();
+    else
+      wait_vm_and_barrier<0>();
+    if (++buf == STAGES) buf = 0;
   }
 
-  // ---- epilogue.  C layout: row = (lane>>4)*4 + r, col = lane&15.
-  const int crow = (lane >> 4) * 4;
-  const int ccol = lane & 15;
-  const int wm0 = m0 + wm * (BM / WM), wn0 = n0 + wn * (BN / WN);
-  if (p.splits > 1) {
+  // ---- epilogue: transpose the wave tile through LDS so that global traffic is row-contiguous 16-byte accesses.
+  //      (the final barrier above guarantees nobody still reads the stage buffers; each wave owns a private region)
+  float* sC = (float*)smem + wave * (WTM * LDW);
+  {
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;   // C layout: row = (lane>>4)*4 + r, col = lane&15
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sC[(i * 16 + crow + r) * LDW + j * 16 + ccol] = acc[i][j][r];
+  }
+  const int wm0 = m0 + wm * WTM, wn0 = n0 + wn * WTN;
+  if (wn0 >= d.N) return;
+
+  if (p.splits > 1) {   // raw partial sums -> workspace slab
     float* ws = d.workspace + (size_t)blockIdx.z * d.M * d.N;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = wn0 + j * 16 + ccol;
-        if (n >= d.N) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = wm0 + i * 16 + crow + r;
-          if (m < d.M) ws[(size_t)m * d.N + n] = acc[i][j][r];
-        }
-      }
+    for (int ps = 0; ps < WTM / 8; ++ps) {
+      const int row = ps * 8 + (lane >> 3), col = (lane & 7) * 4;
+      const int m = wm0 + row, n = wn0 + col;
+      if (m < d.M && n < d.N) *(float4*)(ws + (size_t)m * d.N + n) = *(const float4*)(sC + row * LDW + col);
+    }
     return;
   }
-  if (d.epi == MVD_EPI_GEGLU) {
+  if (d.epi == MVD_EPI_GEGLU) {   // wave tile = 16 value columns | 16 gate columns
+    const int ocol0 = (wn0 >> 5) * 16;
+    const int half = d.N >> 1;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; j += 2) {
-        const int n = wn0 + j * 16 + ccol;
-        if (n >= d.N) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = wm0 + i * 16 + crow + r;
-          if (m < d.M) epi_geglu_elem(d, m, n, acc[i][j][r], acc[i][j + 1][r]);
-        }
+    for (int ps = 0; ps < WTM / 16; ++ps) {
+      const int row = ps * 16 + (lane >> 2), q = (lane & 3) * 4;
+      const int m = wm0 + row;
+      if (m >= d.M) continue;
+      float4 v = *(const float4*)(sC + row * LDW + q);
+      float4 g = *(const float4*)(sC + row * LDW + 16 + q);
+      const int col = ocol0 + q;
+      v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
+      g.x *= d.acc_scale; g.y *= d.acc_scale; g.z *= d.acc_scale; g.w *= d.acc_scale;
+      if (d.bias) {
+        const float4 bv = *(const float4*)(d.bias + col), bg = *(const float4*)(d.bias + half + col);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
       }
+      v.x *= gelu_erf(g.x); v.y *= gelu_erf(g.y); v.z *= gelu_erf(g.z); v.w *= gelu_erf(g.w);
+      if (d.out) *(float4*)(d.out + (size_t)m * d.ldo + col) = v;
+      if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, col, v.x, v.y, v.z, v.w);
+    }
     return;
   }
+  if (d.epi == MVD_EPI_QKV) {     // a 32-column aligned wave tile lies inside one of q / k / v
+    const int C = d.heads * d.dhead;
+    const int which = wn0 / C;
+    if (which < 2) {
+      const int dq = (d.dhead + 31) & ~31;
+      u16* ph = (u16*)(which == 0 ? d.q_hi : d.k_hi);
+      u16* pl = (u16*)(which == 0 ? d.q_lo : d.k_lo);
+      const float sc = (which == 0 ? d.qscale : 1.0f) * d.acc_scale;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+      for (int ps = 0; ps < WTM / 8; ++ps) {
+        const int row = ps * 8 + (lane >> 3), col = (lane & 7) * 4;
+        const int m = wm0 + row, n = wn0 + col;
+        if (m >= d.M) continue;
+        const float4 v = *(const float4*)(sC + row * LDW + col);
+        const int cc = n - which * C;
+        const int head = cc / d.dhead, dd = cc - head * d.dhead;
+        const int b = m / d.L, tok = m - b * d.L;
+        const size_t idx = ((size_t)(b * d.heads + head) * d.Lpad + tok) * dq + dd;
+        store_planes4(ph, pl, idx, v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+      }
+    } else {                      // V^T: each lane takes 4 consecutive tokens of one channel (8-byte stores, keys contiguous)
+      const int dv = (d.dhead + 15) & ~15;
+      const int col = lane & 31, rsel = lane >> 5;
+      const int cc = wn0 + col - 2 * C;
+      const int head = cc / d.dhead, dd = cc - head * d.dhead;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = wn0 + j * 16 + ccol;
-      if (n >= d.N) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = wm0 + i * 16 + crow + r;
-        if (m < d.M) epi_store_elem(d, m, n, acc[i][j][r]);
+      for (int ps = 0; ps < WTM / 8; ++ps) {
+        const int row = (ps * 2 + rsel) * 4;
+        const int m = wm0 + row;
+        if (m >= d.M) continue;
+        const int b = m / d.L, tok = m - b * d.L;
+        const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
+        store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, sC[row * LDW + col] * d.acc_scale, sC[(row + 1) * LDW + col] * d.acc_scale,
+                      sC[(row + 2) * LDW + col] * d.acc_scale, sC[(row + 3) * LDW + col] * d.acc_scale);
       }
     }
+    return;
+  }
+  // MVD_EPI_STORE
+#pragma unroll
+  for (int ps = 0; ps < WTM / 8; ++ps) {
+    const int row = ps * 8 + (lane >> 3), col = (lane & 7) * 4;
+    const int m = wm0 + row, n = wn0 + col;
+    if (m >= d.M || n >= d.N) continue;
+    const float4 v = *(const float4*)(sC + row * LDW + col);
+    if (n + 3 < d.n_store) {
+      epi_store4(d, m, n, v);
+    } else {
+      epi_store_elem(d, m, n, v.x);
+      epi_store_elem(d, m, n + 1, v.y);
+      epi_store_elem(d, m, n + 2, v.z);
+      epi_store_elem(d, m, n + 3, v.w);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ split-K reduce
@@ -313,15 +432,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-void launch_cfg(const GemmParams& p, hipStream_t s) {
-  dim3 grid(cdiv(p.d.N, BN), cdiv(p.d.M, BM), p.splits), block(WM * WN * 64);
+template <int BM, int BN, int WM, int WN, int STAGES>
+void launch_cfg(GemmParams& p, hipStream_t s) {
+  p.tiles_n = cdiv(p.d.N, BN);
+  p.tiles_m = cdiv(p.d.M, BM);
+  dim3 grid(p.tiles_n * p.tiles_m, 1, p.splits), block(WM * WN * 64);
   const bool conv = p.d.a_mode == MVD_A_CONV3X3;
   const bool x3 = p.d.prec == MVD_PREC_BF16X3;
-  if (!conv && x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3, MVD_A_DENSE>), grid, block, 0, s, p);
-  if (!conv && !x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_DENSE>), grid, block, 0, s, p);
-  if (conv && x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3, MVD_A_CONV3X3>), grid, block, 0, s, p);
-  if (conv && !x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_CONV3X3>), grid, block, 0, s, p);
+  if (!conv && x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3, MVD_A_DENSE, STAGES>), grid, block, 0, s, p);
+  if (!conv && !x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_DENSE, STAGES>), grid, block, 0, s, p);
+  if (conv && x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3, MVD_A_CONV3X3, STAGES>), grid, block, 0, s, p);
+  if (conv && !x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_CONV3X3, STAGES>), grid, block, 0, s, p);
 }
 
 }  // namespace
@@ -335,9 +456,8 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   MVD_CHECK_ARG(d.K % 32 == 0, "mvd_gemm: K=%d must be a multiple of 32 (pad the packed weight)", d.K);
   MVD_CHECK_ARG(d.N % 16 == 0, "mvd_gemm: N=%d must be a multiple of 16 (pad the packed weight)", d.N);
   MVD_CHECK_ARG(d.prec == MVD_PREC_BF16 || d.prec == MVD_PREC_BF16X3, "mvd_gemm: bad prec %d", d.prec);
-  MVD_CHECK_ARG(d.A_hi && d.Wp && (d.A_lo || d.prec == MVD_PREC_BF16), "mvd_gemm: null operand");
-  MVD_CHECK_ARG(((uintptr_t)d.A_hi & 15) == 0 && ((uintptr_t)d.A_lo & 15) == 0 && ((uintptr_t)d.Wp & 15) == 0,
-                "mvd_gemm: operands must be 16-byte aligned");
+  MVD_CHECK_ARG(d.A && d.Wp, "mvd_gemm: null operand");
+  MVD_CHECK_ARG(((uintptr_t)d.A & 127) == 0 && ((uintptr_t)d.Wp & 127) == 0, "mvd_gemm: operands must be 128-byte aligned");
   if (d.a_mode == MVD_A_CONV3X3) {
     MVD_CHECK_ARG(d.Cin % 32 == 0 && d.K == 9 * d.Cin, "mvd_gemm: conv needs Cin %% 32 == 0 and K == 9*Cin (Cin=%d K=%d)", d.Cin, d.K);
     MVD_CHECK_ARG(d.M == d.B * d.Hout * d.Wout, "mvd_gemm: conv M mismatch");
@@ -345,29 +465,42 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     if (d.upsample) MVD_CHECK_ARG(d.stride == 1 && d.Hout == 2 * d.Hin && d.Wout == 2 * d.Win, "mvd_gemm: upsample geometry");
   } else {
     MVD_CHECK_ARG(d.a_mode == MVD_A_DENSE, "mvd_gemm: bad a_mode");
-    MVD_CHECK_ARG(d.lda >= d.K && d.lda % 8 == 0, "mvd_gemm: lda=%d must be >= K=%d and a multiple of 8", d.lda, d.K);
+    MVD_CHECK_ARG(d.lda >= d.K && d.lda % 32 == 0, "mvd_gemm: lda=%d must be >= K=%d and a multiple of 32", d.lda, d.K);
   }
-  if (d.out_hi || d.out_lo) MVD_CHECK_ARG(d.out_hi && d.out_lo && d.ldp > 0, "mvd_gemm: plane output needs both planes and ldp");
+  if (d.out_sp) MVD_CHECK_ARG(d.ldp > 0 && d.ldp % 32 == 0 && ((uintptr_t)d.out_sp & 127) == 0,
+                              "mvd_gemm: split-plane output needs ldp %% 32 == 0 and 128-byte alignment");
+  if (d.out) MVD_CHECK_ARG(d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0, "mvd_gemm: out must be 16-byte aligned with ldo %% 4 == 0");
+  if (d.res) MVD_CHECK_ARG(d.ldr % 4 == 0 && ((uintptr_t)d.res & 15) == 0, "mvd_gemm: res must be 16-byte aligned with ldr %% 4 == 0");
+  MVD_CHECK_ARG(((uintptr_t)d.bias & 15) == 0 && ((uintptr_t)d.bias_b & 15) == 0 && ((uintptr_t)d.colscale & 15) == 0,
+                "mvd_gemm: bias / bias_b / colscale must be 16-byte aligned");
   if (d.epi == MVD_EPI_STORE) {
-    MVD_CHECK_ARG(d.out != nullptr || d.out_hi != nullptr, "mvd_gemm: no output");
+    MVD_CHECK_ARG(d.out != nullptr || d.out_sp != nullptr, "mvd_gemm: no output");
     if (d.n_store <= 0 || d.n_store > d.N) d.n_store = d.N;
     if (d.bias_b) MVD_CHECK_ARG(d.rows_per_batch > 0, "mvd_gemm: bias_b needs rows_per_batch");
   } else if (d.epi == MVD_EPI_GEGLU) {
-    MVD_CHECK_ARG((d.out != nullptr || d.out_hi != nullptr) && d.N % 32 == 0, "mvd_gemm: GEGLU needs an output and N %% 32 == 0");
+    MVD_CHECK_ARG((d.out != nullptr || d.out_sp != nullptr) && d.N % 32 == 0, "mvd_gemm: GEGLU needs an output and N %% 32 == 0");
     d.bias_b = nullptr;
   } else if (d.epi == MVD_EPI_QKV) {
     MVD_CHECK_ARG(d.q_hi && d.q_lo && d.k_hi && d.k_lo && d.vt_hi && d.vt_lo, "mvd_gemm: QKV planes missing");
     MVD_CHECK_ARG(d.heads > 0 && d.dhead > 0 && d.N == 3 * d.heads * d.dhead, "mvd_gemm: QKV needs N == 3*heads*dhead");
     MVD_CHECK_ARG(d.L > 0 && d.M % d.L == 0 && d.Lpad >= d.L, "mvd_gemm: QKV needs M %% L == 0");
+    MVD_CHECK_ARG(d.dhead % 4 == 0 && d.L % 4 == 0, "mvd_gemm: QKV needs dhead %% 4 == 0 and L %% 4 == 0");
   } else {
     MVD_CHECK_ARG(false, "mvd_gemm: bad epilogue %d", d.epi);
   }
+  if (d.acc_scale == 0.f) d.acc_scale = 1.f;
   p.nk = d.K / 32;
   p.nt16 = d.N / 16;
   // tile selection: 128x128 (8 waves, 2 workgroups / CU) once the grid fills the chip, else 64x64 (4 waves)
   const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
-  bool big = tiles128 >= 256;
+  bool big = tiles128 >= 128 && (d.N >= 512 || d.K >= 2048);
+  int stages = big ? 2 : 3;
+  if (d.cfg >= 1 && d.cfg <= 4) {
+    big = d.cfg >= 3;
+    stages = (d.cfg == 1 || d.cfg == 4) ? 3 : 2;
+  }
   if (const char* e = getenv("MVD_GEMM_TILE")) big = atoi(e) >= 128;
+  if (const char* e = getenv("MVD_GEMM_STAGES")) stages = atoi(e);
   const int BM = big ? 128 : 64, BN = big ? 128 : 64;
   int splits = d.splitk;
   const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
@@ -390,10 +523,14 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   p.kt_per_split = cdiv(p.nk, splits);
   p.splits = cdiv(p.nk, p.kt_per_split);
   hipStream_t s = (hipStream_t)stream;
-  if (big)
-    launch_cfg<128, 128, 2, 4>(p, s);
+  if (big && stages == 3)
+    launch_cfg<128, 128, 2, 4, 3>(p, s);
+  else if (big)
+    launch_cfg<128, 128, 2, 4, 2>(p, s);
+  else if (stages == 3)
+    launch_cfg<64, 64, 2, 2, 3>(p, s);
   else
-    launch_cfg<64, 64, 2, 2>(p, s);
+    launch_cfg<64, 64, 2, 2, 2>(p, s);
   MVD_CHECK_LAUNCH("mvd_gemm");
   if (p.splits > 1) {
     const size_t total = (size_t)d.M * d.N;
@@ -409,7 +546,8 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
 namespace {
 // one thread per packed element pair (hi, lo)
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, u16* __restrict__ out, int N, int K,
-                                                   int Np, int Kp, int ldw, int geglu, int conv_cin, int conv_cin_pad) {
+                                                   int Np, int Kp, int ldw, int geglu, int conv_cin, int conv_cin_pad,
+                                                   float scale) {
   const size_t total = (size_t)Np * Kp;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int n = (int)(e / Kp);   // packed row
@@ -430,30 +568,26 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
       }
     }
     u16 hi, lo;
-    split_bf16(v, hi, lo);
+    split_bf16(v * scale, hi, lo);
     const int kt = k >> 5, kk = k & 31, nt = n >> 4, nn = n & 15;
-    const size_t base = ((size_t)kt * (Np >> 4) + nt) * 1024 + nn * 32 + kk;
+    const size_t base = ((size_t)kt * (Np >> 4) + nt) * 1024 + nn * 64 + kk;   // [kt][nt][16 n][32 hi | 32 lo]
     out[base] = hi;
-    out[base + 512] = lo;
+    out[base + 32] = lo;
   }
 }
 
-// fp32 (rows, cols) with leading dim ldx -> bf16 planes (rows, ldp) ; columns [cols, ldp) are zero filled
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u16* __restrict__ hi, u16* __restrict__ lo,
-                                                           size_t rows, int cols, int ldx, int ldp) {
+// fp32 (rows, cols) with leading dim ldx -> split planes (rows, ldp); columns [cols, ldp) are zero filled
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u16* __restrict__ sp, size_t rows, int cols,
+                                                           int ldx, int ldp) {
   const int c4 = ldp >> 2;
   const size_t total = rows * c4;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const size_t r = e / c4;
     const int c = (int)(e - r * c4) * 4;
-    u16 h[4], l[4];
+    float v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float v = (c + j) < cols ? x[r * ldx + c + j] : 0.f;
-      split_bf16(v, h[j], l[j]);
-    }
-    *(uint2*)(hi + r * ldp + c) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-    *(uint2*)(lo + r * ldp + c) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    for (int j = 0; j < 4; ++j) v[j] = (c + j) < cols ? x[r * ldx + c + j] : 0.f;
+    store_sp4(sp, r, ldp, c, v[0], v[1], v[2], v[3]);
   }
 }
 }  // namespace
@@ -463,7 +597,10 @@ extern "C" size_t mvd_packed_weight_bytes(int N, int K) {
   return Np * Kp * 4;
 }
 
-extern "C" int mvd_pack_linear_weight(const float* w, int N, int K, int ldw, int geglu, void* packed, mvd_stream_t stream) {
+extern "C" int mvd_operand_format(void) { return MVD_OPERAND_FORMAT; }
+
+extern "C" int mvd_pack_linear_weight(const float* w, int N, int K, int ldw, int geglu, float scale, void* packed,
+                                      mvd_stream_t stream) {
   MVD_CHECK_ARG(w && packed && N > 0 && K > 0 && ldw >= K, "mvd_pack_linear_weight: bad arguments");
   if (geglu) MVD_CHECK_ARG(N % 32 == 0, "mvd_pack_linear_weight: geglu needs N %% 32 == 0");
   const int Np = (N + 15) & ~15, Kp = (K + 31) & ~31;
@@ -471,12 +608,13 @@ extern "C" int mvd_pack_linear_weight(const float* w, int N, int K, int ldw, int
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (u16*)packed, N, K, Np, Kp, ldw,
-                     geglu, 0, 0);
+                     geglu, 0, 0, scale);
   MVD_CHECK_LAUNCH("mvd_pack_linear_weight");
   return 0;
 }
 
-extern "C" int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, void* packed, mvd_stream_t stream) {
+extern "C" int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, float scale, void* packed,
+                                       mvd_stream_t stream) {
   MVD_CHECK_ARG(w && packed && Cout > 0 && Cin > 0 && cin_pad >= Cin && cin_pad % 32 == 0,
                 "mvd_pack_conv3x3_weight: bad arguments (cin_pad must be a multiple of 32)");
   const int Np = (Cout + 15) & ~15, Kp = 9 * cin_pad;
@@ -484,20 +622,18 @@ extern "C" int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int ci
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (u16*)packed, Cout, Kp, Np, Kp, 0,
-                     0, Cin, cin_pad);
+                     0, Cin, cin_pad, scale);
   MVD_CHECK_LAUNCH("mvd_pack_conv3x3_weight");
   return 0;
 }
 
-extern "C" int mvd_split_planes(const float* x, void* hi, void* lo, size_t rows, int cols, int ldx, int ldp,
-                                mvd_stream_t stream) {
-  MVD_CHECK_ARG(x && hi && lo && rows > 0 && cols > 0 && ldx >= cols && ldp >= cols && ldp % 8 == 0,
-                "mvd_split_planes: bad arguments (ldp must be a multiple of 8)");
+extern "C" int mvd_split_planes(const float* x, void* sp, size_t rows, int cols, int ldx, int ldp, mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && sp && rows > 0 && cols > 0 && ldx >= cols && ldp >= cols && ldp % 32 == 0,
+                "mvd_split_planes: bad arguments (ldp must be a multiple of 32)");
   const size_t total = rows * (size_t)(ldp / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (u16*)hi, (u16*)lo, rows, cols,
-                     ldx, ldp);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (u16*)sp, rows, cols, ldx, ldp);
   MVD_CHECK_LAUNCH("mvd_split_planes");
   return 0;
 }

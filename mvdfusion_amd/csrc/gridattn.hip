@@ -93,8 +93,7 @@ __global__ __launch_bounds__(256) void tokens_kernel(const float* __restrict__ x
                                                      const float* __restrict__ steps, const int* __restrict__ iter,
                                                      const float* __restrict__ grid_lin, const float* __restrict__ feat,
                                                      const float* __restrict__ in_feat, const float* __restrict__ cams,
-                                                     const float* __restrict__ in_cam, u16* __restrict__ tok_hi, u16* __restrict__ tok_lo,
-                                                     int V, int q0, int Vq, int S, int D, float depth_scale, float depth_shift) {
+                                                     const float* __restrict__ in_cam, u16* __restrict__ tok, int V, int q0, int Vq, int S, int D, float depth_scale, float depth_shift) {
   const int lane = threadIdx.x & 63;
   const int SS = S * S;
   const size_t npts = (size_t)Vq * SS * D;
@@ -164,17 +163,17 @@ __global__ __launch_bounds__(256) void tokens_kernel(const float* __restrict__ x
     rpl[3] = cv.C[1] * rpl[2] - cv.C[2] * rpl[1];
     rpl[4] = cv.C[2] * rpl[0] - cv.C[0] * rpl[2];
     rpl[5] = cv.C[0] * rpl[1] - cv.C[1] * rpl[0];
-    const size_t row = (pt * V + vr) * MVD_TOKEN_LD;
-    store_planes4(tok_hi, tok_lo, row + lane * 4, fr.x, fr.y, fr.z, fr.w);
-    store_planes4(tok_hi, tok_lo, row + 256 + lane * 4, fin.x, fin.y, fin.z, fin.w);
+    const size_t row = pt * V + vr;
+    store_sp4(tok, row, MVD_TOKEN_LD, lane * 4, fr.x, fr.y, fr.z, fr.w);
+    store_sp4(tok, row, MVD_TOKEN_LD, 256 + lane * 4, fin.x, fin.y, fin.z, fin.w);
     {
       const int e0 = lane, e1 = lane + 64;
-      store_planes1(tok_hi, tok_lo, row + 512 + e0, e0 < 90 ? harmonic(rpl, 6, e0) : harmonic(rdep, 1, e0 - 90));
-      if (e1 < 105) store_planes1(tok_hi, tok_lo, row + 512 + e1, e1 < 90 ? harmonic(rpl, 6, e1) : harmonic(rdep, 1, e1 - 90));
-      store_planes1(tok_hi, tok_lo, row + 617 + e0, qe0);
-      if (e1 < 105) store_planes1(tok_hi, tok_lo, row + 617 + e1, qe1);
+      store_sp1(tok, row, MVD_TOKEN_LD, 512 + e0, e0 < 90 ? harmonic(rpl, 6, e0) : harmonic(rdep, 1, e0 - 90));
+      if (e1 < 105) store_sp1(tok, row, MVD_TOKEN_LD, 512 + e1, e1 < 90 ? harmonic(rpl, 6, e1) : harmonic(rdep, 1, e1 - 90));
+      store_sp1(tok, row, MVD_TOKEN_LD, 617 + e0, qe0);
+      if (e1 < 105) store_sp1(tok, row, MVD_TOKEN_LD, 617 + e1, qe1);
     }
-    if (lane < MVD_TOKEN_LD - 722) store_planes1(tok_hi, tok_lo, row + 722 + lane, lane == 0 ? 1.0f : 0.0f);  // mask = 1, zero pad
+    if (lane < MVD_TOKEN_LD - 722) store_sp1(tok, row, MVD_TOKEN_LD, 722 + lane, lane == 0 ? 1.0f : 0.0f);  // mask = 1, zero pad
   }
 }
 
@@ -212,15 +211,15 @@ extern "C" int mvd_zembed(const float* lat, const float* w, const float* b, floa
 
 extern "C" int mvd_gridattn_tokens(const float* x, const float* depth_noise, const float* steps, const int* iter,
                                    const float* grid_lin, const float* feat, const float* in_feat, const float* cams,
-                                   const float* in_cam, void* tokens_hi, void* tokens_lo, int V, int q0, int Vq, int S, int D,
-                                   float depth_scale, float depth_shift, mvd_stream_t stream) {
-  MVD_CHECK_ARG(x && depth_noise && steps && iter && grid_lin && feat && in_feat && cams && in_cam && tokens_hi && tokens_lo,
+                                   const float* in_cam, void* tokens_sp, int V, int q0, int Vq, int S, int D, float depth_scale,
+                                   float depth_shift, mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && depth_noise && steps && iter && grid_lin && feat && in_feat && cams && in_cam && tokens_sp,
                 "mvd_gridattn_tokens: null pointer");
   MVD_CHECK_ARG(V > 0 && V <= 16 && S > 1 && D > 0, "mvd_gridattn_tokens: bad shape (V <= 16)");
   MVD_CHECK_ARG(q0 >= 0 && Vq > 0 && q0 + Vq <= V, "mvd_gridattn_tokens: bad query-view range [%d, %d) of %d", q0, q0 + Vq, V);
   const size_t npts = (size_t)Vq * S * S * D;
   hipLaunchKernelGGL(tokens_kernel, dim3(cdiv(npts, 4)), dim3(256), 0, (hipStream_t)stream, x, depth_noise, steps, iter,
-                     grid_lin, feat, in_feat, cams, in_cam, (u16*)tokens_hi, (u16*)tokens_lo, V, q0, Vq, S, D, depth_scale, depth_shift);
+                     grid_lin, feat, in_feat, cams, in_cam, (u16*)tokens_sp, V, q0, Vq, S, D, depth_scale, depth_shift);
   MVD_CHECK_LAUNCH("mvd_gridattn_tokens");
   return 0;
 }

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 
 // pass 2: finalise mean / rstd per group (fixed-order fp64 sum over chunks), fold gamma/beta into per-channel
 // scale/shift (y = x * a_c + b_c, as ATen's CPU GroupNorm does), apply, optional SiLU.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, u16* __restrict__ y_hi, u16* __restrict__ y_lo,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, u16* __restrict__ y_sp,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const double* __restrict__ ws, int HW, int C, int groups, int chunks,
                                                        float eps, int silu) {
@@ -100,13 +100,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       v.z = silu_f(v.z);
       v.w = silu_f(v.w);
     }
-    store_planes4(y_hi, y_lo, base + (size_t)i * 4, v.x, v.y, v.z, v.w);
+    store_sp4(y_sp, (size_t)b * HW + (size_t)chunk * rows + (size_t)(i * 4) / C, C, c, v.x, v.y, v.z, v.w);
   }
 }
 
 // LayerNorm: one wave per row, C <= 1280 (5 float4 per lane); two-pass statistics in registers.
 template <int MAXV>
-__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, u16* __restrict__ y_hi, u16* __restrict__ y_lo,
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, u16* __restrict__ y_sp,
                                                  const float* __restrict__ w, const float* __restrict__ bia, int rows, int C, float eps,
                                                  int w_plus_one) {
   const int lane = threadIdx.x & 63;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, u1
         o.z += bb.z;
         o.w += bb.w;
       }
-      store_planes4(y_hi, y_lo, (size_t)row * C + (size_t)idx * 4, o.x, o.y, o.z, o.w);
+      store_sp4(y_sp, (size_t)row, C, idx * 4, o.x, o.y, o.z, o.w);
     }
   }
 }
@@ -175,34 +175,36 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, u1
 
 extern "C" int mvd_groupnorm_chunks(int HW) { return gn_chunks(HW); }
 
-extern "C" int mvd_groupnorm_nhwc(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta, int B, int HW,
-                                  int C, int groups, float eps, int silu, double* ws, mvd_stream_t stream) {
-  MVD_CHECK_ARG(x && y_hi && y_lo && gamma && beta && ws, "mvd_groupnorm_nhwc: null pointer");
+extern "C" int mvd_groupnorm_nhwc(const float* x, void* y_sp, const float* gamma, const float* beta, int B, int HW, int C,
+                                  int groups, float eps, int silu, double* ws, mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && y_sp && gamma && beta && ws, "mvd_groupnorm_nhwc: null pointer");
+  MVD_CHECK_ARG(C % 32 == 0, "mvd_groupnorm_nhwc: split-planes output needs C %% 32 == 0 (C=%d)", C);
   MVD_CHECK_ARG(B > 0 && HW > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0, "mvd_groupnorm_nhwc: bad shape");
   MVD_CHECK_ARG(C <= GN_MAX_C && C % 4 == 0, "mvd_groupnorm_nhwc: C=%d must be <= %d and a multiple of 4", C, GN_MAX_C);
   const int chunks = gn_chunks(HW);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B), dim3(256), 0, s, x, ws, HW, C, groups, chunks);
   MVD_CHECK_LAUNCH("mvd_groupnorm_nhwc/stats");
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, B), dim3(256), 0, s, x, (u16*)y_hi, (u16*)y_lo, gamma, beta, ws, HW, C,
-                     groups, chunks, eps, silu);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, B), dim3(256), 0, s, x, (u16*)y_sp, gamma, beta, ws, HW, C, groups, chunks,
+                     eps, silu);
   MVD_CHECK_LAUNCH("mvd_groupnorm_nhwc/apply");
   return 0;
 }
 
-extern "C" int mvd_layernorm(const float* x, void* y_hi, void* y_lo, const float* w, const float* b, int rows, int C, float eps,
+extern "C" int mvd_layernorm(const float* x, void* y_sp, const float* w, const float* b, int rows, int C, float eps,
                              int w_plus_one, mvd_stream_t stream) {
-  MVD_CHECK_ARG(x && y_hi && y_lo && rows > 0, "mvd_layernorm: bad arguments");
-  u16 *yh = (u16*)y_hi, *yl = (u16*)y_lo;
+  MVD_CHECK_ARG(x && y_sp && rows > 0, "mvd_layernorm: bad arguments");
+  MVD_CHECK_ARG(C % 32 == 0, "mvd_layernorm: split-planes output needs C %% 32 == 0 (C=%d)", C);
+  u16* yh = (u16*)y_sp;
   MVD_CHECK_ARG(C % 4 == 0 && C >= 4 && C <= 1280, "mvd_layernorm: C=%d must be a multiple of 4 and <= 1280", C);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(cdiv(rows, 4));
   if (C <= 256)
-    hipLaunchKernelGGL(ln_kernel<1>, grid, dim3(256), 0, s, x, yh, yl, w, b, rows, C, eps, w_plus_one);
+    hipLaunchKernelGGL(ln_kernel<1>, grid, dim3(256), 0, s, x, yh, w, b, rows, C, eps, w_plus_one);
   else if (C <= 512)
-    hipLaunchKernelGGL(ln_kernel<2>, grid, dim3(256), 0, s, x, yh, yl, w, b, rows, C, eps, w_plus_one);
+    hipLaunchKernelGGL(ln_kernel<2>, grid, dim3(256), 0, s, x, yh, w, b, rows, C, eps, w_plus_one);
   else
-    hipLaunchKernelGGL(ln_kernel<5>, grid, dim3(256), 0, s, x, yh, yl, w, b, rows, C, eps, w_plus_one);
+    hipLaunchKernelGGL(ln_kernel<5>, grid, dim3(256), 0, s, x, yh, w, b, rows, C, eps, w_plus_one);
   MVD_CHECK_LAUNCH("mvd_layernorm");
   return 0;
 }

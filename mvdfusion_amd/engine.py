@@ -28,8 +28,9 @@ class Workspace:
         return t
 
     def planes(self, tag, rows, cols):
-        """Static split-bf16 plane pair (2, rows, cols) int16 (the A-operand format of mvd_gemm)."""
-        return self.get(tag, (2, rows, cols), torch.int16)
+        """Static split-planes buffer (rows, 2*cols) int16 (the A-operand format of mvd_gemm, csrc/common.hpp)."""
+        assert cols % 32 == 0, (tag, cols)
+        return self.get(tag, (rows, 2 * cols), torch.int16)
 
     def attn_planes(self, B, heads, L, dhead):
         key = ("attn_planes", B, heads, L, dhead)

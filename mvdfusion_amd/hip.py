@@ -9,7 +9,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmvd_hip.so")
+# two flavours of the same sources: fp16 MFMA operands (default) and bf16 (-DMVD_OPERAND_BF16)
+LIB_PATHS = {"f16": os.path.join(_HERE, "csrc", "libmvd_hip.so"), "bf16": os.path.join(_HERE, "csrc", "libmvd_hip_bf16.so")}
+LIB_PATH = LIB_PATHS["f16"]
+OPERAND_FORMAT = os.environ.get("MVD_OPERAND_FORMAT", "f16")   # chosen before the first call, fixed per process
 
 PREC_BF16, PREC_BF16X3 = 1, 3
 A_DENSE, A_CONV3X3 = 0, 1
@@ -26,15 +29,15 @@ class GemmDesc(C.Structure):
     """struct mvd_gemm_desc (field order must match include/mvd_hip.h)."""
     _fields_ = [
         ("M", _i), ("N", _i), ("K", _i),
-        ("A_hi", _vp), ("A_lo", _vp), ("lda", _i), ("a_mode", _i),
+        ("A", _vp), ("lda", _i), ("a_mode", _i),
         ("B", _i), ("Hin", _i), ("Win", _i), ("Cin", _i), ("Hout", _i), ("Wout", _i), ("stride", _i), ("upsample", _i),
-        ("Wp", _vp), ("prec", _i),
-        ("epi", _i), ("act", _i), ("out", _vp), ("ldo", _i), ("out_hi", _vp), ("out_lo", _vp), ("ldp", _i),
+        ("Wp", _vp), ("acc_scale", _f), ("prec", _i),
+        ("epi", _i), ("act", _i), ("out", _vp), ("ldo", _i), ("out_sp", _vp), ("ldp", _i),
         ("n_store", _i),
         ("bias", _vp), ("bias_b", _vp), ("rows_per_batch", _i), ("colscale", _vp), ("res", _vp), ("ldr", _i),
         ("q_hi", _vp), ("q_lo", _vp), ("k_hi", _vp), ("k_lo", _vp), ("vt_hi", _vp), ("vt_lo", _vp),
         ("heads", _i), ("dhead", _i), ("L", _i), ("Lpad", _i), ("qscale", _f),
-        ("splitk", _i), ("workspace", _vp), ("workspace_elems", _sz),
+        ("splitk", _i), ("workspace", _vp), ("workspace_elems", _sz), ("cfg", _i),
     ]
 
 
@@ -43,29 +46,30 @@ SIGNATURES = {
     "mvd_version": (_i, []),
     "mvd_last_error": (C.c_char_p, []),
     "mvd_packed_weight_bytes": (_sz, [_i, _i]),
-    "mvd_pack_linear_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "mvd_pack_conv3x3_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mvd_operand_format": (_i, []),
+    "mvd_pack_linear_weight": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "mvd_pack_conv3x3_weight": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "mvd_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
-    "mvd_split_planes": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "mvd_split_planes": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp]),
     "mvd_gemv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_groupnorm_chunks": (_i, [_i]),
-    "mvd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
-    "mvd_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "mvd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "mvd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "mvd_attn_qk_plane_elems": (_sz, [_i, _i, _i, _i]),
     "mvd_attn_vt_plane_elems": (_sz, [_i, _i, _i, _i]),
     "mvd_attn_lpad": (_i, [_i]),
-    "mvd_attention": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i, _i, _vp]),
-    "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "mvd_unet_input": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
-    "mvd_area_pool": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvd_attention": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _vp]),
+    "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvd_unet_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvd_fill_zero": (_i, [_vp, _sz, _vp]),
     "mvd_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "mvd_advance_iter": (_i, [_vp, _vp]),
     "mvd_zembed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "mvd_gridattn_tokens": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _f, _f, _vp]),
-    "mvd_view_mha": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "mvd_view_pool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mvd_gridattn_tokens": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _f, _f, _vp]),
+    "mvd_view_mha": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvd_view_pool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mvd_cfg_ddim_update": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "mvd_graph_begin": (_i, [_vp]),
     "mvd_graph_end": (_i, [_vp, C.POINTER(_vp)]),
@@ -84,16 +88,27 @@ def lib():
     """Load libmvd_hip.so (once).  Raises if it has not been built -- there is no CPU fallback."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATHS[OPERAND_FORMAT]
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} not found: build it with `python -m mvdfusion_amd.csrc.build` "
+                f"{path} not found: build it with `python -m mvdfusion_amd.csrc.build` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). mvdfusion_amd has no CPU fallback.")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
+        assert l.mvd_operand_format() == {"f16": 0xf16, "bf16": 0xbf16}[OPERAND_FORMAT]
         _lib = l
     return _lib
+
+
+def set_operand_format(fmt):
+    """'f16' (default) or 'bf16'; must be called before the first kernel call of the process."""
+    global OPERAND_FORMAT
+    assert fmt in LIB_PATHS
+    if _lib is not None and fmt != OPERAND_FORMAT:
+        raise RuntimeError(f"operand format already fixed to {OPERAND_FORMAT} for this process")
+    OPERAND_FORMAT = fmt
 
 
 def check(rc):
@@ -122,10 +137,21 @@ def _req(t, dtype=torch.float32):
 class PackedWeight:
     """A weight in the MFMA operand image (split bf16, [K/32][N/16][hi,lo][16][32]) plus its fp32 bias."""
 
-    __slots__ = ("data", "N", "K", "n_real", "bias", "geglu", "conv_cin")
+    __slots__ = ("data", "N", "K", "n_real", "bias", "geglu", "conv_cin", "acc_scale")
 
-    def __init__(self, data, N, K, n_real, bias, geglu=False, conv_cin=0):
+    def __init__(self, data, N, K, n_real, bias, geglu=False, conv_cin=0, acc_scale=1.0):
         self.data, self.N, self.K, self.n_real, self.bias, self.geglu, self.conv_cin = data, N, K, n_real, bias, geglu, conv_cin
+        self.acc_scale = acc_scale
+
+
+def _pack_scale(w):
+    """Power of two that brings max|w| to [1024, 2048): the low half of the fp16 split then stays a normal number for
+    every weight within 2^-13 of the largest one (exact to undo: the GEMM multiplies its accumulator by 1/scale)."""
+    import math
+    mx = float(w.abs().max())
+    if not (mx > 0.0) or not math.isfinite(mx):
+        return 1.0
+    return 2.0 ** (10 - math.floor(math.log2(mx)))
 
 
 def pack_linear(weight, bias=None, geglu=False):
@@ -134,13 +160,14 @@ def pack_linear(weight, bias=None, geglu=False):
     N, K = w.shape
     Np, Kp = (N + 15) // 16 * 16, (K + 31) // 32 * 32
     data = torch.empty(lib().mvd_packed_weight_bytes(N, K), dtype=torch.uint8, device=w.device)
-    check(lib().mvd_pack_linear_weight(ptr(w), N, K, K, int(geglu), ptr(data), stream()))
+    scale = _pack_scale(w)
+    check(lib().mvd_pack_linear_weight(ptr(w), N, K, K, int(geglu), scale, ptr(data), stream()))
     b = None
     if bias is not None:
         b = torch.zeros(Np, dtype=torch.float32, device=w.device)
         b[:N] = bias.detach().float()
     torch.cuda.current_stream().synchronize()  # w may be a temporary
-    return PackedWeight(data, Np, Kp, N, b, geglu)
+    return PackedWeight(data, Np, Kp, N, b, geglu, acc_scale=1.0 / scale)
 
 
 def pack_linear_cat(weights):
@@ -154,47 +181,53 @@ def pack_conv3x3(weight, bias=None):
     cin_pad = (Cin + 31) // 32 * 32
     Np = (Cout + 15) // 16 * 16
     data = torch.empty(Np * 9 * cin_pad * 4, dtype=torch.uint8, device=w.device)
-    check(lib().mvd_pack_conv3x3_weight(ptr(w), Cout, Cin, cin_pad, ptr(data), stream()))
+    scale = _pack_scale(w)
+    check(lib().mvd_pack_conv3x3_weight(ptr(w), Cout, Cin, cin_pad, scale, ptr(data), stream()))
     b = None
     if bias is not None:
         b = torch.zeros(Np, dtype=torch.float32, device=w.device)
         b[:Cout] = bias.detach().float()
     torch.cuda.current_stream().synchronize()
-    return PackedWeight(data, Np, 9 * cin_pad, Cout, b, conv_cin=cin_pad)
+    return PackedWeight(data, Np, 9 * cin_pad, Cout, b, conv_cin=cin_pad, acc_scale=1.0 / scale)
 
 
 # ---------------------------------------------------------------------------------------------
 # ops (thin wrappers; all outputs are caller-provided tensors)
 # ---------------------------------------------------------------------------------------------
 def planes_like(rows, cols, device):
-    """Split-bf16 plane pair for a (rows, cols) activation: int16 tensor (2, rows, cols); [0] = hi, [1] = lo."""
-    return torch.empty(2, rows, cols, dtype=torch.int16, device=device)
+    """Split-planes buffer for a (rows, cols) activation, cols % 32 == 0: int16 tensor (rows, 2*cols); per row and
+    32-element block [32 hi | 32 lo] bf16 (csrc/common.hpp)."""
+    assert cols % 32 == 0, cols
+    return torch.empty(rows, 2 * cols, dtype=torch.int16, device=device)
+
+
+def sp_cols(p):
+    return p.shape[-1] // 2
 
 
 def split_planes(x, out=None, ldp=None):
-    """fp32 (rows, cols) -> planes (2, rows, ldp) with zero-padded columns (mvd_split_planes)."""
+    """fp32 (rows, cols) -> split planes (rows, ldp) with zero-padded columns (mvd_split_planes)."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
-    ldp = (cols + 7) // 8 * 8 if ldp is None else ldp
+    ldp = (cols + 31) // 32 * 32 if ldp is None else ldp
     if out is None:
         out = planes_like(rows, ldp, x.device)
-    check(lib().mvd_split_planes(ptr(x), ptr(out[0]), ptr(out[1]), rows, cols, cols, ldp, stream()))
+    check(lib().mvd_split_planes(ptr(x), ptr(out), rows, cols, cols, ldp, stream()))
     return out
 
 
 def gemm(A, W, out=None, *, prec=PREC_BF16X3, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
          bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
          out_planes=None):
-    """out = epilogue(A @ W^T).  A: split-bf16 planes (2, M, K) (dense) or (2, B, H, W, C) with conv=dict(...).
-
-    conv = dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
-    out: fp32 tensor or None; out_planes: (2, M, N') int16 plane pair or None (feeds the next GEMM).
+    """out = epilogue(A @ W^T).  A: split planes (M, 2*K) int16 (dense) or the NHWC image rows (B*H*W, 2*C) with
+    conv=dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
+    out: fp32 tensor or None; out_planes: split-planes tensor or None (feeds the next GEMM).
     """
-    assert A.dtype == torch.int16 and A.shape[0] == 2, "A must be a split-bf16 plane pair (see hip.split_planes)"
+    assert A.dtype == torch.int16, "A must be in split-planes format (see hip.split_planes)"
     d = GemmDesc()
     d.N, d.K = W.N, W.K
-    d.A_hi = A[0].data_ptr()
-    d.A_lo = A[1].data_ptr()
+    d.A = A.data_ptr()
     d.Wp = W.data.data_ptr()
+    d.acc_scale = W.acc_scale
     d.prec = prec
     if conv is not None:
         d.a_mode = A_CONV3X3
@@ -204,16 +237,16 @@ def gemm(A, W, out=None, *, prec=PREC_BF16X3, M=None, lda=None, bias=True, act=A
         assert conv["Cin"] * 9 == W.K, (conv["Cin"], W.K)
     else:
         d.a_mode = A_DENSE
-        d.M = int(M if M is not None else A[0].numel() // A.shape[-1])
-        d.lda = int(lda if lda is not None else A.shape[-1])
+        d.M = int(M if M is not None else A.numel() // A.shape[-1])
+        d.lda = int(lda if lda is not None else A.shape[-1] // 2)
         assert d.lda >= W.K, f"A has {d.lda} columns, packed K is {W.K} (pad A)"
     d.epi, d.act = epi, act
     if out is not None:
         d.out = out.data_ptr()
         d.ldo = int(ldo if ldo is not None else out.shape[-1])
     if out_planes is not None:
-        d.out_hi, d.out_lo = out_planes[0].data_ptr(), out_planes[1].data_ptr()
-        d.ldp = int(out_planes.shape[-1])
+        d.out_sp = out_planes.data_ptr()
+        d.ldp = int(out_planes.shape[-1] // 2)
     d.n_store = W.n_real
     if bias and W.bias is not None:
         d.bias = W.bias.data_ptr()
@@ -235,8 +268,36 @@ def gemm(A, W, out=None, *, prec=PREC_BF16X3, M=None, lda=None, bias=True, act=A
     if workspace is not None:
         d.workspace = workspace.data_ptr()
         d.workspace_elems = workspace.numel()
+    key = (d.M, d.N, d.K, d.a_mode, d.Cin, d.stride, d.upsample, d.epi, d.prec, res is not None, out is not None,
+           out_planes is not None, splitk)
+    cfg = _TUNED.get(key)
+    if cfg is None and AUTOTUNE:
+        cfg = _autotune(d)
+        _TUNED[key] = cfg
+    d.cfg = cfg or 0
     check(lib().mvd_gemm(C.byref(d), stream()))
     return out
+
+
+AUTOTUNE = False          # set by the step engine around its eager warm-up step (never during graph capture)
+_TUNED = {}
+
+
+def _autotune(d, reps=3):
+    """Time the 4 kernel configurations on the actual operands (the op is idempotent) and return the fastest."""
+    best, best_ms = 0, float("inf")
+    for cfg in (1, 2, 3, 4):
+        d.cfg = cfg
+        check(lib().mvd_gemm(C.byref(d), stream()))
+        e0, e1 = Event(), Event()
+        e0.record()
+        for _ in range(reps):
+            check(lib().mvd_gemm(C.byref(d), stream()))
+        e1.record()
+        ms = e0.elapsed_ms(e1)
+        if ms < best_ms:
+            best, best_ms = cfg, ms
+    return best
 
 
 def gemv(W, bias, x, y, act_in=ACT_NONE, act_out=ACT_NONE):
@@ -248,23 +309,22 @@ def gemv(W, bias, x, y, act_in=ACT_NONE, act_out=ACT_NONE):
 
 
 def groupnorm(x, y, gamma, beta, B, HW, Cc, eps, silu, ws):
-    """y: plane pair (2, B*HW, C)."""
-    check(lib().mvd_groupnorm_nhwc(ptr(x), ptr(y[0]), ptr(y[1]), ptr(gamma), ptr(beta), B, HW, Cc, 32, eps, int(silu),
-                                   ptr(ws), stream()))
+    """y: split planes (B*HW, 2*C)."""
+    check(lib().mvd_groupnorm_nhwc(ptr(x), ptr(y), ptr(gamma), ptr(beta), B, HW, Cc, 32, eps, int(silu), ptr(ws), stream()))
     return y
 
 
 def layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False):
-    """y: plane pair (2, rows, C)."""
-    check(lib().mvd_layernorm(ptr(x), ptr(y[0]), ptr(y[1]), ptr(w), ptr(b), rows, Cc, eps, int(w_plus_one), stream()))
+    """y: split planes (rows, 2*C)."""
+    check(lib().mvd_layernorm(ptr(x), ptr(y), ptr(w), ptr(b), rows, Cc, eps, int(w_plus_one), stream()))
     return y
 
 
 def attention(planes, out, B, heads, L, dhead, prec=PREC_BF16X3):
-    """out: plane pair (2, B*L, heads*dhead)."""
+    """out: split planes (B*L, 2*heads*dhead)."""
     qh, ql, kh, kl, vh, vl = planes
-    check(lib().mvd_attention(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(out[0]), ptr(out[1]),
-                              out.shape[-1], B, heads, L, dhead, prec, stream()))
+    check(lib().mvd_attention(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(out), out.shape[-1] // 2, B, heads,
+                              L, dhead, prec, stream()))
     return out
 
 

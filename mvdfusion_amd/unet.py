@@ -252,7 +252,7 @@ class UNetModel(nn.Module):
         ctx.emb_bias = {b: out[0, lo:hi] for b, (lo, hi) in offs.items()}
 
     def run(self, ctx, x_in, t_sin, S):
-        """x_in: split-bf16 planes (2, B*S*S, 32) of the channels-last zero-padded input; t_sin: (1, model_channels) sinusoid; returns the
+        """x_in: split planes (B*S*S, 2*32) of the channels-last zero-padded input; t_sin: (1, model_channels) sinusoid; returns the
         (B*S*S, 8) head output (first out_channels columns valid)."""
         B = ctx.B
         self.time_biases(ctx, t_sin)
@@ -277,8 +277,8 @@ class UNetModel(nn.Module):
             ca, cb = h.shape[-1], sk.shape[-1]
             cat = ctx.ws.get("cat", (M, ca + cb))
             catp = ctx.ws.planes("catp", M, ca + cb)          # planes for the ResBlock's 1x1 skip conv
-            hip.check(hip.lib().mvd_concat_channels(hip.ptr(h), ca, hip.ptr(sk), cb, hip.ptr(cat), hip.ptr(catp[0]),
-                                                    hip.ptr(catp[1]), M, hip.stream()))
+            hip.check(hip.lib().mvd_concat_channels(hip.ptr(h), ca, hip.ptr(sk), cb, hip.ptr(cat), hip.ptr(catp), M,
+                                                    hip.stream()))
             h, H, W = blk.run(ctx, cat, H, W, x_planes=catp)
         if self._head is None:
             self._head = hip.pack_conv3x3(self.out[2].weight, self.out[2].bias)
@@ -322,6 +322,6 @@ class UNetWrapper(nn.Module):
         for i in range(1, len(self.unet_model.channel_mult)):
             f = 2 ** i
             o = ctx.ws.planes(f"vol{i}", B * (S // f) * (S // f) * D, Cc)
-            hip.check(hip.lib().mvd_area_pool(hip.ptr(vol), hip.ptr(o[0]), hip.ptr(o[1]), B, S, D, Cc, f, hip.stream()))
+            hip.check(hip.lib().mvd_area_pool(hip.ptr(vol), hip.ptr(o), B, S, D, Cc, f, hip.stream()))
             levels.append(o)
         return levels

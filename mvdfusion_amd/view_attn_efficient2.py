@@ -66,8 +66,8 @@ class DiTBlock(nn.Module):
         qkv = ctx.ws.get("ga.qkv", (T, 3 * C))
         ctx.gemm(ln, wqkv, qkv)
         att = ctx.ws.planes("ga.att", T, C)
-        hip.check(hip.lib().mvd_view_mha(hip.ptr(qkv), hip.ptr(att[0]), hip.ptr(att[1]), T // V, V, self.num_heads,
-                                         C // self.num_heads, hip.stream()))
+        hip.check(hip.lib().mvd_view_mha(hip.ptr(qkv), hip.ptr(att), T // V, V, self.num_heads, C // self.num_heads,
+                                         hip.stream()))
         ctx.gemm(att, wproj, h_alt, res=h, colscale=g1)
         hip.layernorm(h_alt, ln, sc2, sh2, T, C, eps=1e-6, w_plus_one=True)
         f1 = ctx.ws.planes("ga.f1", T, wfc1.N)
@@ -146,8 +146,8 @@ class GridAttn(nn.Module):
         tokens = ctx.ws.planes("ga.tokens", T, hip.TOKEN_LD)
         hip.check(L.mvd_gridattn_tokens(hip.ptr(x), hip.ptr(depth_noise), hip.ptr(steps), hip.ptr(it), hip.ptr(grid_lin),
                                         hip.ptr(feat), hip.ptr(in_feat), hip.ptr(cams_rec), hip.ptr(in_cam_rec),
-                                        hip.ptr(tokens[0]), hip.ptr(tokens[1]), V, q0, Vq, S, D, float(self.depth_scale),
-                                        float(self.depth_shift), hip.stream()))
+                                        hip.ptr(tokens), V, q0, Vq, S, D, float(self.depth_scale), float(self.depth_shift),
+                                        hip.stream()))
         h = ctx.ws.get("ga.h", (T, self.hidden_size))
         h_alt = ctx.ws.get("ga.h_alt", (T, self.hidden_size))
         ctx.gemm(tokens, w_pre, h, act=hip.ACT_GELU)
@@ -155,8 +155,8 @@ class GridAttn(nn.Module):
             h = blk.run(ctx, h, h_alt, c, T, V)
         wl = self.aggregation_transformer.weight_layer
         pool = ctx.ws.planes("ga.pool", nseq, self.hidden_size)
-        hip.check(L.mvd_view_pool(hip.ptr(h), hip.ptr(wl.weight), hip.ptr(wl.bias), hip.ptr(pool[0]), hip.ptr(pool[1]),
-                                  nseq, V, self.hidden_size, hip.stream()))
+        hip.check(L.mvd_view_pool(hip.ptr(h), hip.ptr(wl.weight), hip.ptr(wl.bias), hip.ptr(pool), nseq, V, self.hidden_size,
+                                  hip.stream()))
         # the frustum is consumed as fp32 (area pooling) and as planes (level-0 to_k / to_v GEMMs): write both
         ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes)
         return vol_out

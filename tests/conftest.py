@@ -40,10 +40,16 @@ def rel_err(a, b):
 
 
 def planes_to_float(p):
-    """split-bf16 plane pair (2, ...) int16 -> fp32 value hi + lo."""
+    """split planes (rows, 2*K) int16, per row K/32 blocks of [32 hi | 32 lo] (fp16 or bf16) -> fp32 (rows, K)."""
+    from mvdfusion_amd import hip
     p = p.detach().cpu()
-    f = lambda t: (t.to(torch.int32) << 16).view(torch.float32)
-    return f(p[0]) + f(p[1])
+    rows, k2 = p.shape
+    q = p.view(rows, k2 // 64, 2, 32)
+    if hip.OPERAND_FORMAT == "bf16":
+        f = lambda t: (t.to(torch.int32) << 16).view(torch.float32)
+    else:
+        f = lambda t: t.view(torch.float16).float()
+    return (f(q[:, :, 0, :].contiguous()) + f(q[:, :, 1, :].contiguous())).reshape(rows, k2 // 2)
 
 
 def rmse(a, b):
@@ -57,8 +63,12 @@ UNET_PARAMS = dict(image_size=32, in_channels=10, out_channels=5, model_channels
                    legacy=False)
 
 
-def model_config(mc=320, D=1, S=32, precision="bf16x3"):
+DEFAULT_PRECISION = "bf16x3" if os.environ.get("MVD_OPERAND_FORMAT") == "bf16" else "f16x3"
+
+
+def model_config(mc=320, D=1, S=32, precision=None):
     """The `params:` block of configs/mvd_gso.yaml (model part) as a dict."""
+    precision = precision or DEFAULT_PRECISION
     up = dict(UNET_PARAMS)
     up["model_channels"] = mc
     up["image_size"] = S
@@ -76,10 +86,11 @@ def model_config(mc=320, D=1, S=32, precision="bf16x3"):
 _MODELS = {}
 
 
-def build_model(mc=320, D=1, S=32, precision="bf16x3"):
+def build_model(mc=320, D=1, S=32, precision=None):
     """ViewFusion on cuda:0 with the deterministic non-zero fill (cached per configuration)."""
     from mvdfusion_amd import synthetic as syn
     from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
+    precision = precision or DEFAULT_PRECISION
     key = (mc, D, S, precision)
     if key not in _MODELS:
         m = ViewFusion(**model_config(mc, D, S, precision))

@@ -27,11 +27,11 @@ def main():
         g = torch.Generator().manual_seed(0)
         if conv:
             B, H, Cin = conv
-            A = torch.randn(B, H, H, Cin, generator=g).cuda()
+            A = hip.split_planes(torch.randn(B * H * H, Cin, generator=g).cuda())
             W = hip.pack_conv3x3((torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(K)).cuda(), torch.zeros(N).cuda())
             kw = dict(conv=dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, upsample=0))
         else:
-            A = torch.randn(M, K, generator=g).cuda()
+            A = hip.split_planes(torch.randn(M, K, generator=g).cuda())
             W = hip.pack_linear((torch.randn(N, K, generator=g) / math.sqrt(K)).cuda(), torch.zeros(N).cuda())
             kw = {}
         out = torch.empty(M, N, device="cuda")
