@@ -195,9 +195,72 @@ __global__ __launch_bounds__(256) void pixel_xattn_kernel(const float* __restric
   }
 }
 
-// one thread per (sequence, head, query view); qkv row layout [3][heads][dhead] (timm reshape B,N,3,H,hd).
-__global__ __launch_bounds__(256) void view_mha_kernel(const float* __restrict__ qkv, u16* __restrict__ out_sp, int Nseq, int V,
-                                                       int heads, int dhead) {
+// timm Attention core over the V reference views: one wavefront per sequence.  The V x 3C fp32 rows of the sequence
+// are read once with coalesced 16-byte loads into a wave-private LDS slab; lane (h, vq) then owns one query of one
+// head: V dot products of dhead = 32, softmax over the V keys, weighted sum of the V value rows, split-plane store.
+// qkv row layout [3][heads][dhead] (timm reshape B,N,3,H,hd).  Requires heads * V <= 64 and dhead == 32.
+template <int V>
+__global__ __launch_bounds__(256) void view_mha_kernel(const float* __restrict__ qkv, u16* __restrict__ out_sp, int Nseq, int heads,
+                                                       int dhead) {
+  constexpr int C = 256, ROW = 3 * C;
+  __shared__ __attribute__((aligned(16))) float s[4][V * ROW];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t n = (size_t)blockIdx.x * 4 + w;
+  if (n >= (size_t)Nseq) return;
+  const float4* src = (const float4*)(qkv + n * V * ROW);
+  float4* dst = (float4*)s[w];
+#pragma unroll
+  for (int i = 0; i < V * ROW / 4 / 64; ++i) dst[lane + 64 * i] = src[lane + 64 * i];
+  // (wave-private slab: no barrier needed, LDS operations of one wave complete in order)
+  const float scale = rsqrtf((float)dhead);
+  for (int item = lane; item < heads * V; item += 64) {
+    const int h = item / V, vq = item - h * V;
+    const float* q = s[w] + vq * ROW + h * 32;
+    float sc[V];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float* k = s[w] + j * ROW + C + h * 32;
+      float a = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < 8; ++d4) {
+        const float4 qq = *(const float4*)(q + d4 * 4), kk = *(const float4*)(k + d4 * 4);
+        a += (qq.x * scale) * kk.x;
+        a += (qq.y * scale) * kk.y;
+        a += (qq.z * scale) * kk.z;
+        a += (qq.w * scale) * kk.w;
+      }
+      sc[j] = a;
+      mx = fmaxf(mx, a);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      sc[j] = expf(sc[j] - mx);
+      den += sc[j];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) sc[j] = sc[j] / den;
+    const size_t orow = n * V + vq;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float4 vv = *(const float4*)(s[w] + j * ROW + 2 * C + h * 32 + d4 * 4);
+        o.x += sc[j] * vv.x;
+        o.y += sc[j] * vv.y;
+        o.z += sc[j] * vv.z;
+        o.w += sc[j] * vv.w;
+      }
+      store_sp4(out_sp, orow, C, h * 32 + d4 * 4, o.x, o.y, o.z, o.w);
+    }
+  }
+}
+
+// generic fallback (any V <= 16, any head size): one thread per (sequence, head, query view)
+__global__ __launch_bounds__(256) void view_mha_generic_kernel(const float* __restrict__ qkv, u16* __restrict__ out_sp, int Nseq, int V,
+                                                               int heads, int dhead) {
   const size_t total = (size_t)Nseq * heads * V;
   const int C = heads * dhead;
   const float scale = rsqrtf((float)dhead);
@@ -315,11 +378,23 @@ extern "C" int mvd_pixel_cross_attn(const float* q, const float* k, const float*
 }
 
 extern "C" int mvd_view_mha(const float* qkv, void* out_sp, int Nseq, int V, int heads, int dhead, mvd_stream_t stream) {
-  MVD_CHECK_ARG(qkv && out_sp && (heads * dhead) % 32 == 0 && Nseq > 0 && V > 0 && V <= 16 && heads > 0 && dhead > 0, "mvd_view_mha: bad arguments (V <= 16)");
+  MVD_CHECK_ARG(qkv && out_sp && (heads * dhead) % 32 == 0 && Nseq > 0 && V > 0 && V <= 16 && heads > 0 && dhead > 0,
+                "mvd_view_mha: bad arguments (V <= 16)");
+  hipStream_t s = (hipStream_t)stream;
+  const bool fast = heads == 8 && dhead == 32 && ((uintptr_t)qkv & 15) == 0;
+  const dim3 grid(cdiv(Nseq, 4)), block(256);
+#define MVD_VMHA(VV)                                                                                     \
+  if (fast && V == VV) {                                                                                 \
+    hipLaunchKernelGGL(view_mha_kernel<VV>, grid, block, 0, s, qkv, (u16*)out_sp, Nseq, heads, dhead);   \
+    MVD_CHECK_LAUNCH("mvd_view_mha");                                                                    \
+    return 0;                                                                                            \
+  }
+  MVD_VMHA(2) MVD_VMHA(3) MVD_VMHA(4) MVD_VMHA(8)
+#undef MVD_VMHA
   const size_t total = (size_t)Nseq * heads * V;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(view_mha_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, (u16*)out_sp, Nseq, V, heads, dhead);
+  hipLaunchKernelGGL(view_mha_generic_kernel, dim3(blocks), block, 0, s, qkv, (u16*)out_sp, Nseq, V, heads, dhead);
   MVD_CHECK_LAUNCH("mvd_view_mha");
   return 0;
 }

@@ -423,6 +423,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     }
     return;
   }
+  if (d.epi == MVD_EPI_STORE) {   // 4 columns per thread: 16-byte slab reads, vector epilogue
+    const size_t MN4 = MN >> 2;
+    const float inv = 1.0f / d.acc_scale;   // epi_store4 re-applies acc_scale; slabs hold raw accumulators
+    (void)inv;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < MN4; e += (size_t)gridDim.x * 256) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int z = 0; z < p.splits; ++z) {
+        const float4 t = *(const float4*)(d.workspace + z * MN + e * 4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      const int m = (int)((e * 4) / d.N);
+      const int n = (int)(e * 4 - (size_t)m * d.N);
+      if (n + 3 < d.n_store) {
+        epi_store4(d, m, n, v);
+      } else {
+        epi_store_elem(d, m, n, v.x);
+        epi_store_elem(d, m, n + 1, v.y);
+        epi_store_elem(d, m, n + 2, v.z);
+        epi_store_elem(d, m, n + 3, v.w);
+      }
+    }
+    return;
+  }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < MN; e += (size_t)gridDim.x * 256) {
     float v = 0.f;
     for (int z = 0; z < p.splits; ++z) v += d.workspace[z * MN + e];
@@ -506,9 +529,9 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
   if (splits == 0) {  // auto: fill the chip on the small-M, huge-K (weight-bandwidth-bound) layers
     splits = 1;
-    if (tiles < 256 && p.nk >= 32) {
-      splits = (int)((768 + tiles - 1) / tiles);
-      if (splits > p.nk / 8) splits = p.nk / 8;
+    if (tiles <= 96 && p.nk >= 64) {     // e.g. the 4x4 / 8x8 layers: M = 128..512, K up to 23040
+      splits = (int)((512 + tiles - 1) / tiles);
+      if (splits > p.nk / 16) splits = p.nk / 16;
     }
   }
   if (splits < 1) splits = 1;

@@ -9,33 +9,60 @@ namespace {
 constexpr int GN_MAX_C = 2560;
 
 __host__ __device__ inline int gn_chunks(int HW) {
-  int c = HW / 16;           // >= 16 rows per chunk at 32x32
+  int c = HW / 8;            // 8 rows per workgroup: >= 1024 workgroups at 32x32 x 8 views
   if (c < 1) c = 1;
-  if (c > 64) c = 64;
+  if (c > 128) c = 128;
   while (HW % c) --c;
   return c;
 }
 
 // pass 1: per (batch, row-chunk) partial sum / sum of squares per group.
-// grid (chunks, B), 256 threads; thread t owns channels t, t+256, ...
+// grid (chunks, B), 256 threads arranged as TY row-slices x TX float4 columns: every global access is a coalesced
+// 16-byte load; per-thread fp32 partials over <= rows/TY rows, then a fixed-order fp64 reduction (deterministic).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ ws, int HW, int C,
                                                        int groups, int chunks) {
   __shared__ float s_sum[GN_MAX_C];
   __shared__ float s_sq[GN_MAX_C];
+  __shared__ float s_part[2][4][GN_MAX_C / 4];     // used when TY > 1 (C <= 512): [sum|sq][ty][C]
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int rows = HW / chunks;
-  const float* xb = x + ((size_t)b * HW + (size_t)chunk * rows) * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < rows; ++r) {
-      const float v = xb[(size_t)r * C + c];
-      s += v;
-      q += v * v;
+  const int C4 = C >> 2;
+  const int TX = C4 < 256 ? C4 : 256;
+  int TY = 256 / TX;
+  if (TY > 4) TY = 4;
+  if (C > GN_MAX_C / 4) TY = 1;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const float4* xb = (const float4*)(x + ((size_t)b * HW + (size_t)chunk * rows) * C);
+  if (ty < TY) {
+    for (int c4 = tx; c4 < C4; c4 += TX) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = ty; r < rows; r += TY) {
+        const float4 v = xb[(size_t)r * C4 + c4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+      }
+      if (TY == 1) {
+        *(float4*)&s_sum[c4 * 4] = s;
+        *(float4*)&s_sq[c4 * 4] = q;
+      } else {
+        *(float4*)&s_part[0][ty][c4 * 4] = s;
+        *(float4*)&s_part[1][ty][c4 * 4] = q;
+      }
     }
-    s_sum[c] = s;
-    s_sq[c] = q;
   }
   __syncthreads();
+  if (TY > 1) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.f, q = 0.f;
+      for (int t = 0; t < TY; ++t) {
+        s += s_part[0][t][c];
+        q += s_part[1][t][c];
+      }
+      s_sum[c] = s;
+      s_sq[c] = q;
+    }
+    __syncthreads();
+  }
   const int cg = C / groups;
   if (threadIdx.x < groups) {
     double s = 0.0, q = 0.0;
@@ -50,24 +77,38 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 }
 
 // pass 2: finalise mean / rstd per group (fixed-order fp64 sum over chunks), fold gamma/beta into per-channel
-// scale/shift (y = x * a_c + b_c, as ATen's CPU GroupNorm does), apply, optional SiLU.
+// scale/shift (y = x * a_c + b_c, as ATen's CPU GroupNorm does), apply, optional SiLU, write split planes.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, u16* __restrict__ y_sp,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const double* __restrict__ ws, int HW, int C, int groups, int chunks,
                                                        float eps, int silu) {
   __shared__ float s_a[GN_MAX_C];
   __shared__ float s_b[GN_MAX_C];
+  __shared__ double s_ps[8][64], s_pq[8][64];
   __shared__ float s_mean[64];
   __shared__ float s_rstd[64];
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int rows = HW / chunks;
   const int cg = C / groups;
+  {   // 8 slices x groups threads sum the chunk partials (each slice in a fixed order), then a fixed-order combine
+    const int g = threadIdx.x % 32, sl = threadIdx.x / 32;
+    for (int gg = g; gg < groups; gg += 32) {
+      double s = 0.0, q = 0.0;
+      for (int k = sl; k < chunks; k += 8) {
+        const double* o = ws + (((size_t)b * chunks + k) * groups + gg) * 2;
+        s += o[0];
+        q += o[1];
+      }
+      s_ps[sl][gg] = s;
+      s_pq[sl][gg] = q;
+    }
+  }
+  __syncthreads();
   if (threadIdx.x < groups) {
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-      const double* o = ws + (((size_t)b * chunks + k) * groups + threadIdx.x) * 2;
-      s += o[0];
-      q += o[1];
+    for (int sl = 0; sl < 8; ++sl) {
+      s += s_ps[sl][threadIdx.x];
+      q += s_pq[sl][threadIdx.x];
     }
     const double n = (double)HW * cg;
     const double mean = s / n;
@@ -84,11 +125,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     s_b[c] = beta[c] - s_mean[g] * a;
   }
   __syncthreads();
-  const size_t base = ((size_t)b * HW + (size_t)chunk * rows) * C;
-  const int n4 = rows * C / 4;
-  const float4* x4 = (const float4*)(x + base);
+  const size_t row0 = (size_t)b * HW + (size_t)chunk * rows;
+  const int C4 = C >> 2;
+  const int n4 = rows * C4;
+  const float4* x4 = (const float4*)(x + row0 * C);
   for (int i = threadIdx.x; i < n4; i += 256) {
-    const int c = (i * 4) % C;
+    const int r = i / C4;
+    const int c = (i - r * C4) * 4;
     float4 v = x4[i];
     v.x = v.x * s_a[c] + s_b[c];
     v.y = v.y * s_a[c + 1] + s_b[c + 1];
@@ -100,7 +143,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       v.z = silu_f(v.z);
       v.w = silu_f(v.w);
     }
-    store_sp4(y_sp, (size_t)b * HW + (size_t)chunk * rows + (size_t)(i * 4) / C, C, c, v.x, v.y, v.z, v.w);
+    store_sp4(y_sp, row0 + r, C, c, v.x, v.y, v.z, v.w);
   }
 }
 

@@ -309,6 +309,46 @@ def gold_trajectory(model_channels, V, D, tag, steps=5, S=32):
     save(tag, xs=torch.stack([xs[i] for i in keep]), kept=np.asarray(keep))
 
 
+def gold_trajectory_f64(model_channels, V, D, tag, steps=50, S=32):
+    """The same trajectory evaluated in float64 (weights / inputs / noise identical, arithmetic in double): the
+    roundoff-free value of the reference algorithm.  Random-weight networks amplify fp32 roundoff by ~10^3 over the
+    50 stochastic steps, so this -- not one particular fp32 evaluation order -- is what a 1e-3 tolerance is measured
+    against; the fp32 oracle's own deviation from it is stored alongside (`fp32_oracle_rmse`)."""
+    sd, _ = synth_state_dict(model_channels, D, S)
+    inp = syn.make_inputs(V, S, seed=11)
+    dn, sn = syn.step_noise(V, S, D, 50, seed=11)
+    ref32 = load_npz(tag.replace("_f64", ""))
+    torch.set_default_dtype(torch.float64)
+    try:
+        sd64 = {k: v.double() for k, v in sd.items()}
+        tab = {k: v.double() for k, v in O.ddpm_tables().items()}
+        dd = O.ddim_schedule(O.ddpm_tables())
+        dd = {k: (v.double() if v.is_floating_point() else v) for k, v in dd.items()}
+        c64 = lambda c: {k: v.double() for k, v in cam_dict(c).items()}
+        x = inp["x_T"].double()
+        xs = []
+        t0 = time.time()
+        for i in range(steps):
+            with torch.no_grad():
+                x, _ = O.denoise_step(sd64, x, c64(inp["batch_cameras"]), inp["input_latents"].double(),
+                                      c64(inp["input_cameras"]), inp["clip_v_embed"].double(), tab, dd, 50 - i - 1,
+                                      dn[i].double(), sn[i].double(), cfg_scale=2.5, n_pts_per_ray=D,
+                                      unet_kw=dict(model_channels=model_channels))
+            xs.append(x)
+            if i % 10 == 0:
+                print(f"    f64 step {i} ({time.time() - t0:.0f}s)", flush=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    keep = [int(k) for k in ref32["kept"]]
+    dev = [float(((torch.from_numpy(ref32["xs"][j]).double() - xs[k]) ** 2).mean().sqrt()) for j, k in enumerate(keep)]
+    print("  fp32 oracle vs float64:", ["%.2e" % d for d in dev])
+    save(tag, xs=torch.stack([xs[k] for k in keep]).float(), kept=np.asarray(keep), fp32_oracle_rmse=np.asarray(dev))
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
 def synth_state_dict(model_channels, D, S=32):
     """The flat state_dict of the hot-path parameters from shapes alone (spec fixture) + det_fill."""
     spec = json.load(open(os.path.join(GOLD, f"state_dict_spec_mc{model_channels}.json")))
@@ -348,6 +388,7 @@ ALL = {
     "step320": lambda: gold_step(320, 4, 1, "step_mc320_v4_d1", indices=(49, 0)),
     "traj32": lambda: gold_trajectory(32, 4, 1, "traj_mc32_v4_d1", steps=5),
     "traj320": lambda: gold_trajectory(320, 4, 1, "traj_mc320_v4_d1_50steps", steps=50),
+    "traj320_f64": lambda: gold_trajectory_f64(320, 4, 1, "traj_mc320_v4_d1_50steps_f64", steps=50),
 }
 
 if __name__ == "__main__":

@@ -130,11 +130,11 @@ def gridattn_tokens(feat, in_feat, cams, in_cam, depth, S):
     R, T, f, p = cams["R"], cams["T"], cams["f"], cams["p"]
     # ray grid utils/ray_utils.py:263-269 (x along columns, y along rows, +X left / +Y up)
     half = 1.0 / float(S)
-    lin = torch.linspace(1.0 - half, -1.0 + half, S, dtype=torch.float32)
+    lin = torch.linspace(1.0 - half, -1.0 + half, S, dtype=torch.float32).to(R.dtype)
     yy, xx = torch.meshgrid(lin, lin, indexing="ij")
     xy = torch.stack([xx, yy], dim=-1).reshape(1, S * S, 2).expand(V, -1, -1)
     # utils/ray_utils.py:175-202: unproject planes z=1 and z=2
-    ones = torch.ones(V, S * S)
+    ones = torch.ones(V, S * S, dtype=R.dtype)
     p1 = unproject_ndc(R, T, f, p, xy, ones)
     p2 = unproject_ndc(R, T, f, p, xy, 2.0 * ones)
     dirs = p2 - p1
@@ -164,7 +164,7 @@ def gridattn_tokens(feat, in_feat, cams, in_cam, depth, S):
     qo = C[None, :, None, :].expand_as(qdir)
     q_pl = harmonic_embedding(torch.cat((qdir, torch.cross(qo, qdir, dim=-1)), dim=-1)).expand(V, -1, -1, -1)
     q_dep = harmonic_embedding(lengths.reshape(1, V, S * S * D, 1)).expand(V, -1, -1, -1)
-    mask = torch.ones(V, V, S * S * D, 1)
+    mask = torch.ones(V, V, S * S * D, 1, dtype=R.dtype)
     return torch.cat((ref_feat, inp_feat, ref_pl, ref_depth, q_pl, q_dep, mask), dim=-1)
 
 
@@ -321,7 +321,7 @@ def unet_forward(sd, pre, x, timesteps, context, volume_levels, model_channels=3
                  channel_mult=(1, 2, 4, 4), num_res_blocks=2, attention_resolutions=(4, 2, 1)):
     """UNetModel.forward mvdfusion/unet.py:524-556."""
     inp, mid, out = unet_layout(model_channels, channel_mult, num_res_blocks, attention_resolutions)
-    emb = timestep_embedding(timesteps, model_channels)
+    emb = timestep_embedding(timesteps, model_channels).to(x.dtype)
     emb = _lin(sd, pre + "time_embed.2", F.silu(_lin(sd, pre + "time_embed.0", emb)))
 
     def run(block_pre, layers, h):
@@ -393,7 +393,7 @@ def unet_train_forward(sd, pre, x, t1, clip_embed, volume_feats, x_concat, **kw)
 
 def embed_time(sd, t, dim=256):
     """ViewFusion.embed_time viewfusion_zero_depth_rgb.py:276-279."""
-    e = timestep_embedding(t, dim)
+    e = timestep_embedding(t, dim).to(sd["time_embed.0.weight"].dtype)
     return _lin(sd, "time_embed.2", F.silu(_lin(sd, "time_embed.0", e)))
 
 
