@@ -89,12 +89,15 @@ def profile_gemm_kernels(eng, cfg_scale):
         M = conv["B"] * conv["Hout"] * conv["Wout"] if conv else int(kw.get("M") or A.numel() // A.shape[-1])
         N = W.n_real
         Kp = W.K
-        big = M >= 1024 and W.N >= 128
-        bm = 128 if big else 64
-        tiles = -(-M // bm) * -(-W.N // bm)
-        split = kw.get("splitk", 0) == 0 and tiles < 256 and Kp // 32 >= 8
-        recs.append(dict(sym=f"gemm_kernel<{bm},{bm},{kw.get('prec', 3)},{1 if conv else 0}>", M=M, N=N, K=Kp,
-                         flops=2.0 * M * N * Kp, split=split, ev=(e0, e1)))
+        c = (hip.LAST_CFG - 1) % 4 + 1 if hip.LAST_CFG else 0     # tuned kernel configuration of this call
+        bm = {0: "auto", 1: 64, 2: 64, 3: 128, 4: 128}[c]
+        st = {0: "auto", 1: 3, 2: 2, 3: 2, 4: 3}[c]
+        tiles = -(-M // (bm if c else 64)) * -(-W.N // (bm if c else 64))
+        split = kw.get("splitk", 0) == 0 and tiles <= 96 and Kp // 32 >= 64
+        # template args: <BM, BN, WM, WN, NS, AMODE, STAGES> as in csrc/gemm.hip
+        wmn = "2, 4" if bm == 128 else "2, 2"
+        recs.append(dict(sym=f"gemm_kernel<{bm}, {bm}, {wmn}, {kw.get('prec', 3)}, {1 if conv else 0}, {st}>", M=M, N=N,
+                         K=Kp, flops=2.0 * M * N * Kp, split=split, ev=(e0, e1)))
         return r
 
     hip.gemm = timed

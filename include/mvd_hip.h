@@ -113,7 +113,8 @@ typedef struct mvd_gemm_desc {
   float* workspace;
   size_t workspace_elems;
   /* kernel configuration: 0 = built-in heuristic; 1 = 64x64 tile / 3 LDS stages, 2 = 64x64 / 2 stages,
-   * 3 = 128x128 / 2 stages, 4 = 128x128 / 3 stages.  The host mirror times the candidates once per distinct problem
+   * 3 = 128x128 / 2 stages, 4 = 128x128 / 3 stages (tile order across the 8 XCDs chosen by the byte-cost model);
+   * 5-8 = the same four with the n-fastest tile order forced, 9-12 = with the m-fastest order forced.  The host mirror times the candidates once per distinct problem
    * shape during the eager warm-up step and passes the winner from then on (mvdfusion_amd/hip.py: autotune). */
   int cfg;
 } mvd_gemm_desc;

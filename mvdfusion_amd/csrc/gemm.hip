@@ -31,6 +31,7 @@ struct GemmParams {
   int kt_per_split;
   int splits;
   int tiles_m, tiles_n;
+  int m_fastest;
 };
 
 // ------------------------------------------------------------------------------------------------ epilogue
@@ -156,8 +157,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (tile / p.tiles_n) * BM;
-  const int n0 = (tile % p.tiles_n) * BN;
+  // n-fastest: an XCD re-uses one A row panel across its n-tiles (and streams all of W);
+  // m-fastest: an XCD keeps a W column panel resident and streams A -- chosen per problem by bytes moved.
+  const int m0 = (p.m_fastest ? tile % p.tiles_m : tile / p.tiles_n) * BM;
+  const int n0 = (p.m_fastest ? tile / p.tiles_m : tile % p.tiles_n) * BN;
   const int kt0 = blockIdx.z * p.kt_per_split;
   const int kt1 = min(p.nk, kt0 + p.kt_per_split);
   const int nkt = kt1 - kt0;
@@ -459,6 +462,15 @@ template <int BM, int BN, int WM, int WN, int STAGES>
 void launch_cfg(GemmParams& p, hipStream_t s) {
   p.tiles_n = cdiv(p.d.N, BN);
   p.tiles_m = cdiv(p.d.M, BM);
+  {
+    // bytes each XCD pulls through its L2 under the two tile orders (8 XCDs, operands are 4 B per element)
+    const double W = (double)p.d.N * p.d.K * 4.0;
+    const double A = (double)p.d.M * p.d.K * 4.0 / (p.d.a_mode == MVD_A_CONV3X3 ? 9.0 : 1.0);
+    const double rep_m = p.tiles_m < 8 ? p.tiles_m : 8, rep_n = p.tiles_n < 8 ? p.tiles_n : 8;
+    const double cost_nfast = W * rep_m + A, cost_mfast = W + A * rep_n;
+    p.m_fastest = cost_mfast < cost_nfast;
+    if (p.d.cfg > 4) p.m_fastest = p.d.cfg > 8 ? 1 : 0;     // 5..8 force n-fastest, 9..12 force m-fastest (autotune)
+  }
   dim3 grid(p.tiles_n * p.tiles_m, 1, p.splits), block(WM * WN * 64);
   const bool conv = p.d.a_mode == MVD_A_CONV3X3;
   const bool x3 = p.d.prec == MVD_PREC_BF16X3;
@@ -518,9 +530,10 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
   bool big = tiles128 >= 128 && (d.N >= 512 || d.K >= 2048);
   int stages = big ? 2 : 3;
-  if (d.cfg >= 1 && d.cfg <= 4) {
-    big = d.cfg >= 3;
-    stages = (d.cfg == 1 || d.cfg == 4) ? 3 : 2;
+  if (d.cfg >= 1 && d.cfg <= 12) {
+    const int c = (d.cfg - 1) % 4 + 1;
+    big = c >= 3;
+    stages = (c == 1 || c == 4) ? 3 : 2;
   }
   if (const char* e = getenv("MVD_GEMM_TILE")) big = atoi(e) >= 128;
   if (const char* e = getenv("MVD_GEMM_STAGES")) stages = atoi(e);
@@ -529,7 +542,7 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
   if (splits == 0) {  // auto: fill the chip on the small-M, huge-K (weight-bandwidth-bound) layers
     splits = 1;
-    if (tiles <= 96 && p.nk >= 64) {     // e.g. the 4x4 / 8x8 layers: M = 128..512, K up to 23040
+    if (tiles < 224 && p.nk >= 64) {     // e.g. the 4x4 / 8x8 layers: M = 128..512, K up to 23040
       splits = (int)((512 + tiles - 1) / tiles);
       if (splits > p.nk / 16) splits = p.nk / 16;
     }

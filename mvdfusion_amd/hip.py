@@ -275,10 +275,13 @@ def gemm(A, W, out=None, *, prec=PREC_BF16X3, M=None, lda=None, bias=True, act=A
         cfg = _autotune(d)
         _TUNED[key] = cfg
     d.cfg = cfg or 0
+    global LAST_CFG
+    LAST_CFG = d.cfg
     check(lib().mvd_gemm(C.byref(d), stream()))
     return out
 
 
+LAST_CFG = 0
 AUTOTUNE = False          # set by the step engine around its eager warm-up step (never during graph capture)
 _TUNED = {}
 
@@ -286,7 +289,7 @@ _TUNED = {}
 def _autotune(d, reps=3):
     """Time the 4 kernel configurations on the actual operands (the op is idempotent) and return the fastest."""
     best, best_ms = 0, float("inf")
-    for cfg in (1, 2, 3, 4):
+    for cfg in (5, 6, 7, 8, 9, 10, 11, 12):
         d.cfg = cfg
         check(lib().mvd_gemm(C.byref(d), stream()))
         e0, e1 = Event(), Event()
