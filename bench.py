@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--views", type=int, default=None)
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--depth-samples", type=int, default=1)
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16x3", "f16", "bf16"])
+    ap.add_argument("--precision", default="f16x4", choices=["f16x4", "f16x3", "bf16x3", "f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     a = ap.parse_args()
@@ -212,7 +212,8 @@ def main():
             "metric": "denoising-steps/sec", "value": a.steps / dt, "unit": "steps/s", "n_gpus": N, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong" if N > 1 else "weak", "vs_baseline": None,
-            "dtype": {"f16x3": "f16x3 (fp16 MFMA operands split hi+lo, 3 products, fp32 accumulate)",
+            "dtype": {"f16x4": "f16x4 (fp16 MFMA operands split hi+lo, all 4 partial products, fp32 accumulate)",
+                      "f16x3": "f16x3 (fp16 MFMA operands split hi+lo, 3 products, fp32 accumulate)",
                       "bf16x3": "bf16x3 (bf16 MFMA operands split hi+lo, 3 products, fp32 accumulate)",
                       "f16": "f16 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)"}[a.precision],
             "data": "synthetic",

@@ -31,8 +31,9 @@ extern "C" {
 typedef void* mvd_stream_t; /* hipStream_t */
 
 #define MVD_VERSION 100
-#define MVD_PREC_BF16 1
-#define MVD_PREC_BF16X3 3
+#define MVD_PREC_BF16 1   /* one product per operand pair (hi only) */
+#define MVD_PREC_BF16X3 3 /* hi*hi + hi*lo + lo*hi */
+#define MVD_PREC_X4 4     /* all four partial products of the (hi+lo)(hi+lo) split: fp32-class products */
 
 int mvd_version(void);
 const char* mvd_last_error(void);

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
                                                    const u16* __restrict__ k_hi, const u16* __restrict__ k_lo,
                                                    const u16* __restrict__ vt_hi, const u16* __restrict__ vt_lo,
                                                    u16* __restrict__ out_sp, int ldo, int H, int L, int Lpad, int dhead) {
-  constexpr int NPL = NS == 3 ? 2 : 1;
+  constexpr int NPL = NS >= 3 ? 2 : 1;
   constexpr int KP = DQ + 8;       // LDS pitch of a K row (bf16 elements)
   constexpr int VP = KV_TILE + 8;  // LDS pitch of a V^T row
   constexpr int QS = DQ / 32;      // MFMA k-steps over the head dim
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
 #pragma unroll
     for (int ks = 0; ks < QS; ++ks) {
       qh[ks] = *(const bf16x8*)(q_hi + qoff + ks * 32);
-      if (NS == 3) ql[ks] = *(const bf16x8*)(q_lo + qoff + ks * 32);
+      if (NS >= 3) ql[ks] = *(const bf16x8*)(q_lo + qoff + ks * 32);
     }
   }
   f32x4 o[DT];
@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
 #pragma unroll
       for (int ks = 0; ks < QS; ++ks) {
         const bf16x8 kh = *(const bf16x8*)&sK[0][kt * 16 + c][ks * 32 + g * 8];
-        if (NS == 3) {
+        if (NS >= 3) {
           const bf16x8 kl = *(const bf16x8*)&sK[NPL - 1][kt * 16 + c][ks * 32 + g * 8];
+          if (NS == 4) s[kt] = MVD_MFMA_16x16x32(kl, ql[ks], s[kt], 0, 0, 0);
           s[kt] = MVD_MFMA_16x16x32(kl, qh[ks], s[kt], 0, 0, 0);
           s[kt] = MVD_MFMA_16x16x32(kh, ql[ks], s[kt], 0, 0, 0);
         }
@@ -121,14 +122,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float pv = j < 4 ? s[2 * u][j] : s[2 * u + 1][j - 4];
-        if (NS == 3) {
+        if (NS >= 3) {
           split_bf16(pv, H8.e[j], L8.e[j]);
         } else {
           H8.e[j] = to_op_bits(pv);
         }
       }
       ph[u] = H8.v;
-      if (NS == 3) pl2[u] = L8.v;
+      if (NS >= 3) pl2[u] = L8.v;
     }
     // ---- O^T += V^T P^T
 #pragma unroll
@@ -138,9 +139,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
         union { bf16x8 v; uint2 h2[2]; } VH, VL;
         VH.h2[0] = *(const uint2*)&sV[0][dt * 16 + c][32 * u + 4 * g];
         VH.h2[1] = *(const uint2*)&sV[0][dt * 16 + c][32 * u + 16 + 4 * g];
-        if (NS == 3) {
+        if (NS >= 3) {
           VL.h2[0] = *(const uint2*)&sV[NPL - 1][dt * 16 + c][32 * u + 4 * g];
           VL.h2[1] = *(const uint2*)&sV[NPL - 1][dt * 16 + c][32 * u + 16 + 4 * g];
+          if (NS == 4) o[dt] = MVD_MFMA_16x16x32(VL.v, pl2[u], o[dt], 0, 0, 0);
           o[dt] = MVD_MFMA_16x16x32(VL.v, ph[u], o[dt], 0, 0, 0);
           o[dt] = MVD_MFMA_16x16x32(VH.v, pl2[u], o[dt], 0, 0, 0);
         }
@@ -357,10 +359,12 @@ extern "C" int mvd_attention(const void* q_hi, const void* q_lo, const void* k_h
   MVD_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out_sp, "mvd_attention: null pointer");
   MVD_CHECK_ARG(B > 0 && heads > 0 && L > 0 && dhead > 0 && dhead % 4 == 0, "mvd_attention: bad shape (dhead %% 4 == 0)");
   MVD_CHECK_ARG(ldo % 32 == 0 && ((uintptr_t)out_sp & 127) == 0, "mvd_attention: out must be split planes (ldo %% 32 == 0, 128-byte aligned)");
-  MVD_CHECK_ARG(prec == MVD_PREC_BF16 || prec == MVD_PREC_BF16X3, "mvd_attention: bad prec");
+  MVD_CHECK_ARG(prec == MVD_PREC_BF16 || prec == MVD_PREC_BF16X3 || prec == MVD_PREC_X4, "mvd_attention: bad prec");
   const int Lpad = mvd_attn_lpad(L);
   int rc;
-  if (prec == MVD_PREC_BF16X3)
+  if (prec == MVD_PREC_X4)
+    rc = launch_attn<4>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+  else if (prec == MVD_PREC_BF16X3)
     rc = launch_attn<3>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
   else
     rc = launch_attn<1>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);

@@ -14,7 +14,8 @@
 // which is conflict-free for the 16-lane ds_read_b128 groups).
 // 2-3 LDS stages: DMA of later k-tiles is in flight while the MFMAs of k-tile t run; rows/columns outside the problem
 // (M/N edges, conv zero padding) source a 16-byte zero page.
-// NS = 1: acc += A_hi*B_hi.   NS = 3: acc += A_lo*B_hi + A_hi*B_lo + A_hi*B_hi   (fp32 accumulate).
+// NS = 1: acc += A_hi*B_hi.  NS = 3: acc += A_lo*B_hi + A_hi*B_lo + A_hi*B_hi.  NS = 4: + A_lo*B_lo first (the kernel is
+// operand-delivery bound, not MFMA bound, so the 4th product is almost free and removes the 2^-22 truncation term).
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -277,18 +278,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       ah[i] = *(const bf16x8*)(sA + (wm * TM + i) * 2048 + foff_hi);
-      if (NS == 3) al[i] = *(const bf16x8*)(sA + (wm * TM + i) * 2048 + foff_lo);
+      if (NS >= 3) al[i] = *(const bf16x8*)(sA + (wm * TM + i) * 2048 + foff_lo);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       bh[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + foff_hi);
-      if (NS == 3) bl[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + foff_lo);
+      if (NS >= 3) bl[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + foff_lo);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (NS == 3) {
+        if (NS == 4) acc[i][j] = MVD_MFMA_16x16x32(al[i], bl[j], acc[i][j], 0, 0, 0);
+        if (NS >= 3) {
           acc[i][j] = MVD_MFMA_16x16x32(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = MVD_MFMA_16x16x32(ah[i], bl[j], acc[i][j], 0, 0, 0);
         }
@@ -473,11 +475,13 @@ void launch_cfg(GemmParams& p, hipStream_t s) {
   }
   dim3 grid(p.tiles_n * p.tiles_m, 1, p.splits), block(WM * WN * 64);
   const bool conv = p.d.a_mode == MVD_A_CONV3X3;
-  const bool x3 = p.d.prec == MVD_PREC_BF16X3;
-  if (!conv && x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3, MVD_A_DENSE, STAGES>), grid, block, 0, s, p);
-  if (!conv && !x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_DENSE, STAGES>), grid, block, 0, s, p);
-  if (conv && x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3, MVD_A_CONV3X3, STAGES>), grid, block, 0, s, p);
-  if (conv && !x3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_CONV3X3, STAGES>), grid, block, 0, s, p);
+  const int ns = p.d.prec;
+  if (!conv && ns == 4) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 4, MVD_A_DENSE, STAGES>), grid, block, 0, s, p);
+  if (!conv && ns == 3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3, MVD_A_DENSE, STAGES>), grid, block, 0, s, p);
+  if (!conv && ns == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_DENSE, STAGES>), grid, block, 0, s, p);
+  if (conv && ns == 4) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 4, MVD_A_CONV3X3, STAGES>), grid, block, 0, s, p);
+  if (conv && ns == 3) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3, MVD_A_CONV3X3, STAGES>), grid, block, 0, s, p);
+  if (conv && ns == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_CONV3X3, STAGES>), grid, block, 0, s, p);
 }
 
 }  // namespace
@@ -490,7 +494,7 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   MVD_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "mvd_gemm: bad sizes M=%d N=%d K=%d", d.M, d.N, d.K);
   MVD_CHECK_ARG(d.K % 32 == 0, "mvd_gemm: K=%d must be a multiple of 32 (pad the packed weight)", d.K);
   MVD_CHECK_ARG(d.N % 16 == 0, "mvd_gemm: N=%d must be a multiple of 16 (pad the packed weight)", d.N);
-  MVD_CHECK_ARG(d.prec == MVD_PREC_BF16 || d.prec == MVD_PREC_BF16X3, "mvd_gemm: bad prec %d", d.prec);
+  MVD_CHECK_ARG(d.prec == MVD_PREC_BF16 || d.prec == MVD_PREC_BF16X3 || d.prec == MVD_PREC_X4, "mvd_gemm: bad prec %d", d.prec);
   MVD_CHECK_ARG(d.A && d.Wp, "mvd_gemm: null operand");
   MVD_CHECK_ARG(((uintptr_t)d.A & 127) == 0 && ((uintptr_t)d.Wp & 127) == 0, "mvd_gemm: operands must be 128-byte aligned");
   if (d.a_mode == MVD_A_CONV3X3) {

@@ -51,7 +51,7 @@ class Workspace:
 class Ctx:
     """Per-model execution context handed down the module tree."""
 
-    def __init__(self, device, prec=hip.PREC_BF16X3):
+    def __init__(self, device, prec=hip.PREC_X4):
         self.device = torch.device(device)
         self.ws = Workspace(device)
         self.prec = prec

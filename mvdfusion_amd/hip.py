@@ -14,7 +14,7 @@ LIB_PATHS = {"f16": os.path.join(_HERE, "csrc", "libmvd_hip.so"), "bf16": os.pat
 LIB_PATH = LIB_PATHS["f16"]
 OPERAND_FORMAT = os.environ.get("MVD_OPERAND_FORMAT", "f16")   # chosen before the first call, fixed per process
 
-PREC_BF16, PREC_BF16X3 = 1, 3
+PREC_BF16, PREC_BF16X3, PREC_X4 = 1, 3, 4
 A_DENSE, A_CONV3X3 = 0, 1
 EPI_STORE, EPI_GEGLU, EPI_QKV = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
@@ -215,7 +215,7 @@ def split_planes(x, out=None, ldp=None):
     return out
 
 
-def gemm(A, W, out=None, *, prec=PREC_BF16X3, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
+def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
          bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
          out_planes=None):
     """out = epilogue(A @ W^T).  A: split planes (M, 2*K) int16 (dense) or the NHWC image rows (B*H*W, 2*C) with
@@ -323,7 +323,7 @@ def layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False):
     return y
 
 
-def attention(planes, out, B, heads, L, dhead, prec=PREC_BF16X3):
+def attention(planes, out, B, heads, L, dhead, prec=PREC_X4):
     """out: split planes (B*L, 2*heads*dhead)."""
     qh, ql, kh, kl, vh, vl = planes
     check(lib().mvd_attention(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(out), out.shape[-1] // 2, B, heads,

@@ -151,7 +151,7 @@ class ViewFusion(nn.Module):
                  clip_path="", unet_cc_path="", z_scale_factor=0.18215, vae_max_batch=8, objective="noise",
                  loss_type="l2", embed_camera_pose=True, finetune_projection=False, finetune_unet=False,
                  finetune_cross_attn=True, finetune_view_attn=True, feed_prev_depth=False, drop_conditions=False,
-                 vae=None, clip_image_encoder=None, precision="f16x3", **kwargs):
+                 vae=None, clip_image_encoder=None, precision="f16x4", **kwargs):
         super().__init__()
         assert embed_camera_pose, "this build implements the embed_camera_pose=True configuration of configs/*.yaml"
         assert not feed_prev_depth, "feed_prev_depth=False in every shipped config (viewfusion_zero_depth_rgb.py:39)"
@@ -160,12 +160,13 @@ class ViewFusion(nn.Module):
         self.embed_camera_pose, self.finetune_cross_attn, self.finetune_view_attn = \
             embed_camera_pose, finetune_cross_attn, finetune_view_attn
         self.feed_prev_depth, self.drop_conditions = feed_prev_depth, drop_conditions
-        # precision = MFMA operand type x number of products: "f16x3" (default: fp16 operands split hi+lo, 3 products,
-        # ~22 operand bits), "bf16x3" (~16 bits), "f16" / "bf16" (one product).  The operand type selects the library
+        # precision = MFMA operand type x number of partial products of the (hi+lo)(hi+lo) operand split:
+        # "f16x4" (default: fp16, all 4 products -- fp32-class; +4 % time over x3 because the GEMMs are operand-delivery
+        # bound), "f16x3" (drops lo*lo, ~2^-22), "bf16x3" (~2^-16), "f16" / "bf16" (one product, hi only).  The operand type selects the library
         # flavour and is fixed per process.
         hip.set_operand_format("bf16" if precision.startswith("bf16") else "f16")
         self.precision_name = precision
-        self.precision = hip.PREC_BF16X3 if precision.endswith("x3") else hip.PREC_BF16
+        self.precision = {"x3": hip.PREC_BF16X3, "x4": hip.PREC_X4}.get(precision[-2:], hip.PREC_BF16)
 
         def params(cfg):
             return dict(cfg.get("params", cfg)) if hasattr(cfg, "get") else dict(cfg)

@@ -63,7 +63,7 @@ UNET_PARAMS = dict(image_size=32, in_channels=10, out_channels=5, model_channels
                    legacy=False)
 
 
-DEFAULT_PRECISION = "bf16x3" if os.environ.get("MVD_OPERAND_FORMAT") == "bf16" else "f16x3"
+DEFAULT_PRECISION = "bf16x3" if os.environ.get("MVD_OPERAND_FORMAT") == "bf16" else "f16x4"
 
 
 def model_config(mc=320, D=1, S=32, precision=None):
