@@ -1,7 +1,7 @@
 import sys, os, json, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
 from conftest import build_model, load_golden, rmse
-import tests.test_gpu_model as T
+import test_gpu_model as T
 prec = sys.argv[1]
 gd = load_golden("traj_mc320_v4_d1_50steps_f64"); g32 = load_golden("traj_mc320_v4_d1_50steps")
 m = build_model(320, precision=prec)
