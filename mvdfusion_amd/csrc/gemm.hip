@@ -17,6 +17,7 @@
 // NS = 1: acc += A_hi*B_hi.  NS = 3: acc += A_lo*B_hi + A_hi*B_lo + A_hi*B_hi.  NS = 4: + A_lo*B_lo first (the kernel is
 // operand-delivery bound, not MFMA bound, so the 4th product is almost free and removes the 2^-22 truncation term).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.hpp"
 #include "../../include/mvd_hip.h"
@@ -121,10 +122,27 @@ __device__ __forceinline__ void epi_store4(const mvd_gemm_desc& d, int m, int n,
 // ------------------------------------------------------------------------------------------------ main kernel
 template <int N>
 __device__ __forceinline__ void wait_vm_and_barrier() {
-  // counted wait on this wave's own DMA queue, then the workgroup barrier.  One asm statement with a memory clobber:
-  // the compiler neither drains the queue to 0 (as __syncthreads would with LDS-DMA in flight) nor moves LDS
-  // accesses across it.
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(N) : "memory");
+  // Counted wait on this wave's own DMA queue plus a full wait on its LDS reads, then the workgroup barrier, as ONE asm
+  // statement with a memory clobber.  vmcnt(N): the compiler does not drain the DMA queue to 0 (as __syncthreads would
+  // with LDS-DMA in flight).  lgkmcnt(0): the fragment reads issued before the barrier must have RETURNED before any
+  // other wave is released to overwrite the buffer (next DMA, or the epilogue staging tile) -- the compiler is free to
+  // sink the MFMAs that consume them, and with them its own lgkmcnt wait, below the barrier.
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory");
+}
+
+// Instruction-mix hint for one pipelined k-tile: SLOTS groups of [a few MFMAs, one memory instruction]; the first LPS
+// memory slots are the LDS-DMA issues (longest latency), the rest the LDS fragment reads of the next k-tile.
+template <int G, int SLOTS, int NM, int LPS>
+__device__ __forceinline__ void sched_pattern() {
+  if constexpr (G < SLOTS) {
+    constexpr int mf = NM * (G + 1) / SLOTS - NM * G / SLOTS;
+    if constexpr (mf > 0) __builtin_amdgcn_sched_group_barrier(0x008, mf, 0);   // MFMA
+    if constexpr (G < LPS)
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        // VMEM read (the LDS-DMA)
+    else
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        // DS read
+    sched_pattern<G + 1, SLOTS, NM, LPS>();
+  }
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int AMODE, int STAGES>
@@ -138,7 +156,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   constexpr int LPS = AI + BI;                        // DMA instructions per wave per stage
   constexpr int LDW = WTN + 4;                        // fp32 pitch of the epilogue staging tile
   constexpr int EPI_BYTES = NW * WTM * LDW * 4;
-  constexpr int SMEM = STAGES * STAGE > EPI_BYTES ? STAGES * STAGE : EPI_BYTES;
+  constexpr bool PIPE = STAGES == 3;                   // 3 = register-pipelined loop (still two LDS buffers)
+  constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
   static_assert(A_GRAN % NW == 0 && B_GRAN % NW == 0, "granules must divide evenly over the waves");
   static_assert(WTN == 32, "epilogue assumes 32-column wave tiles (one GEGLU value/gate block, one QKV head-aligned block)");
 
@@ -206,41 +225,76 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   }
   const size_t b_kstride = (size_t)p.nt16 * 1024;   // elements between consecutive k-tiles of the packed weight
 
-  auto stage = [&](int buf, int kt) {
+  // Running DMA source pointers: every stage() call moves each of them one k-tile forward, so that the steady-state
+  // loop carries no address arithmetic beyond one 64-bit add per granule.  Rows / weight tiles outside the problem
+  // (and conv taps that fall into the zero padding) point at the zero page with step 0.
+  const u16* a_cur[AI];
+  int a_step[AI];
+  int c_tap = 0, c_c0 = 0;                    // conv: current filter tap and channel offset (uniform)
+  auto set_tap = [&](int tap) {               // conv: per-lane source of this tap (called once per Cin/32 k-tiles)
+    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int iy, ix;
+      bool ok = a_ok[i];
+      if (d.upsample) {
+        const int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
+        ok = ok && uy >= 0 && uy < d.Hout && ux >= 0 && ux < d.Wout;
+        iy = uy >> 1;
+        ix = ux >> 1;
+      } else {
+        iy = a_oy[i] * d.stride + ky - 1;
+        ix = a_ox[i] * d.stride + kx - 1;
+        ok = ok && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
+      }
+      const int off = ok ? (iy * d.Win + ix) * 2 * d.Cin + c_c0 * 2 : 0;
+      a_cur[i] = ok ? a_src[i] + off : zero;
+      a_step[i] = ok ? 64 : 0;
+    }
+  };
+  if (AMODE == MVD_A_DENSE) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      a_cur[i] = a_ok[i] ? a_src[i] + (size_t)kt0 * 64 : zero;
+      a_step[i] = a_ok[i] ? 64 : 0;
+    }
+  } else {
+    const int k0 = kt0 * 32;
+    c_tap = k0 / d.Cin;
+    c_c0 = k0 - c_tap * d.Cin;
+    set_tap(c_tap);
+  }
+  const u16* b_cur[BI];
+  size_t b_step[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    b_cur[i] = b_src[i] ? b_src[i] + (size_t)kt0 * b_kstride : zero;
+    b_step[i] = b_src[i] ? b_kstride : 0;
+  }
+
+  auto stage = [&](int buf) {                 // DMA the next k-tile (consecutive calls walk kt0, kt0+1, ...)
     unsigned char* sbase = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const u16* src;
-      if (AMODE == MVD_A_DENSE) {
-        src = a_ok[i] ? a_src[i] + kt * 64 : zero;
-      } else {
-        const int k0 = kt * 32;
-        const int tap = k0 / d.Cin;
-        const int c0 = k0 - tap * d.Cin;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        int iy, ix;
-        bool ok = a_ok[i];
-        if (d.upsample) {
-          const int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
-          ok = ok && uy >= 0 && uy < d.Hout && ux >= 0 && ux < d.Wout;
-          iy = uy >> 1;
-          ix = ux >> 1;
-        } else {
-          iy = a_oy[i] * d.stride + ky - 1;
-          ix = a_ox[i] * d.stride + kx - 1;
-          ok = ok && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
-        }
-        src = ok ? a_src[i] + ((size_t)iy * d.Win + ix) * 2 * d.Cin + c0 * 2 : zero;
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_cur[i],
                                        (__attribute__((address_space(3))) void*)(sbase + (wave + i * NW) * 1024), 16, 0, 0);
+      a_cur[i] += a_step[i];
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const u16* src = b_src[i] ? b_src[i] + (size_t)kt * b_kstride : zero;
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
+          (const __attribute__((address_space(1))) void*)b_cur[i],
           (__attribute__((address_space(3))) void*)(sbase + (A_GRAN + wave + i * NW) * 1024), 16, 0, 0);
+      b_cur[i] += b_step[i];
+    }
+  };
+  auto advance_tap = [&]() {                  // conv bookkeeping after each stage(): uniform branch, taken every Cin/32 tiles
+    if (AMODE != MVD_A_DENSE) {
+      c_c0 += 32;
+      if (c_c0 == d.Cin) {
+        c_c0 = 0;
+        if (++c_tap < 9) set_tap(c_tap);
+      }
     }
   };
 
@@ -257,24 +311,33 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   const int foff_hi = fbase + (((lane >> 4)) ^ fsw) * 16;
   const int foff_lo = fbase + ((4 + (lane >> 4)) ^ fsw) * 16;
 
-  // ---- software pipeline: STAGES-1 k-tiles of DMA in flight ahead of the MFMAs
+  auto mfma_tile = [&](const bf16x8 (&ah)[TM], const bf16x8 (&al)[TM], const bf16x8 (&bh)[TN], const bf16x8 (&bl)[TN]) {
+    // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependency); every accumulator
+    // still receives lo*lo, lo*hi, hi*lo, hi*hi in that order per k-tile (the summation order is part of the numerics).
+    if (NS == 4) {
 #pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nkt) stage(s, kt0 + s);
-  if (STAGES == 3 && nkt >= 2)
-    wait_vm_and_barrier<LPS>();
-  else
-    wait_vm_and_barrier<0>();
-  int buf = 0;
-  for (int it = 0; it < nkt; ++it) {
-    if (it + STAGES - 1 < nkt) {
-      int nb = buf + STAGES - 1;
-      if (nb >= STAGES) nb -= STAGES;
-      stage(nb, kt0 + it + STAGES - 1);
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(al[i], bl[j], acc[i][j], 0, 0, 0);
     }
+    if (NS >= 3) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(ah[i], bl[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  };
+  auto read_frags = [&](int buf, bf16x8 (&ah)[TM], bf16x8 (&al)[TM], bf16x8 (&bh)[TN], bf16x8 (&bl)[TN]) {
     const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + A_GRAN * 1024;
-    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       ah[i] = *(const bf16x8*)(sA + (wm * TM + i) * 2048 + foff_hi);
@@ -285,23 +348,68 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       bh[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + foff_hi);
       if (NS >= 3) bl[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + foff_lo);
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (NS == 4) acc[i][j] = MVD_MFMA_16x16x32(al[i], bl[j], acc[i][j], 0, 0, 0);
-        if (NS >= 3) {
-          acc[i][j] = MVD_MFMA_16x16x32(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = MVD_MFMA_16x16x32(ah[i], bl[j], acc[i][j], 0, 0, 0);
-        }
-        acc[i][j] = MVD_MFMA_16x16x32(ah[i], bh[j], acc[i][j], 0, 0, 0);
-      }
-    // k-tile it+1 must have landed (all waves) before anyone reads it; with 3 stages one more tile stays in flight
-    if (STAGES == 3 && it + 2 < nkt)
+  };
+
+  if (PIPE) {
+    // ---- register-pipelined loop, two LDS buffers.  While the MFMAs of k-tile t run out of one fragment register set,
+    //      the wave reads k-tile t+1 from LDS into the other set and issues the DMA of k-tile t+2 into the buffer that
+    //      tile t occupied (its fragments are already in registers).  One barrier per k-tile; the DMA it waits for was
+    //      issued a whole iteration earlier, so neither LDS nor L2 latency sits between two MFMA bursts.
+    bf16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+    stage(0);
+    advance_tap();
+    if (nkt > 1) {
+      stage(1);
+      advance_tap();
       wait_vm_and_barrier<LPS>();
-    else
+    } else {
       wait_vm_and_barrier<0>();
-    if (++buf == STAGES) buf = 0;
+    }
+    read_frags(0, fah[0], fal[0], fbh[0], fbl[0]);
+    auto step = [&](auto parity, auto steady, int it) {
+      constexpr int P = decltype(parity)::value;
+      constexpr bool FULL = decltype(steady)::value;   // steady state: no conditions -> one basic block to schedule
+      // k-tile it+1 has landed for every wave, and every wave's fragment reads of buffer P have returned
+      wait_vm_and_barrier<0>();
+      if (FULL || it + 2 < nkt) stage(P);
+      if (FULL || it + 1 < nkt) read_frags(P ^ 1, fah[P ^ 1], fal[P ^ 1], fbh[P ^ 1], fbl[P ^ 1]);
+      mfma_tile(fah[P], fal[P], fbh[P], fbl[P]);
+      if (FULL) {
+        constexpr int NM = TM * TN * NS, NR = (TM + TN) * (NS >= 3 ? 2 : 1);
+        sched_pattern<0, LPS + NR, NM, LPS>();
+      }
+      if (FULL || it + 2 < nkt) advance_tap();
+    };
+    using std::integral_constant;
+    int it = 0;
+    for (; it + 3 < nkt; it += 2) {
+      step(integral_constant<int, 0>{}, integral_constant<bool, true>{}, it);
+      step(integral_constant<int, 1>{}, integral_constant<bool, true>{}, it + 1);
+    }
+    for (; it < nkt; ++it) {
+      if (it & 1)
+        step(integral_constant<int, 1>{}, integral_constant<bool, false>{}, it);
+      else
+        step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, it);
+    }
+    __syncthreads();   // the epilogue reuses the stage buffers
+  } else {
+    // ---- plain two-buffer loop: DMA of k-tile t+1 in flight while tile t is read and multiplied
+    stage(0);
+    advance_tap();
+    wait_vm_and_barrier<0>();
+    int buf = 0;
+    for (int it = 0; it < nkt; ++it) {
+      if (it + 1 < nkt) {
+        stage(buf ^ 1);
+        advance_tap();
+      }
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      read_frags(buf, ah, al, bh, bl);
+      mfma_tile(ah, al, bh, bl);
+      wait_vm_and_barrier<0>();   // k-tile it+1 landed (all waves); nobody still reads buffer `buf`
+      buf ^= 1;
+    }
   }
 
   // ---- epilogue: transpose the wave tile through LDS so that global traffic is row-contiguous 16-byte accesses.
@@ -460,6 +568,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
+// Split-K selection by a small time model (unit: 0.7 us ~ one DMA round trip).  What matters most is how evenly
+// tiles*splits workgroups divide over the 256 CUs (192 tiles: 1, 2 or 3 splits all leave a CU with 180 k-tiles, 4 splits
+// give every CU 3 x 45), then whether enough workgroups are co-resident to hide the per-k-tile DMA latency, then the cost
+// of the fp32 partial-sum round trip.
+static int choose_splits(long tiles, int nk, bool big, bool pipelined, size_t mn) {
+  const double t_mfma = big ? 0.75 : 0.19;          // MFMA-pipe time of one k-tile of one workgroup
+  const double t_lat = pipelined ? 0.4 : 1.0;       // exposed DMA latency per k-tile of a workgroup running alone
+  const double t_epi = big ? 2.0 : 0.7;
+  const int coresident = big ? (pipelined ? 1 : 2) : (pipelined ? 3 : 5);
+  const double red_fixed = 6.0, red_per_split = (double)mn * 8.0 / 3.0e12 / 0.7e-6;
+  int best = 1;
+  double best_t = 1e30;
+  const int smax = nk / 8 < 1 ? 1 : (nk / 8 > 32 ? 32 : nk / 8);
+  for (int sp = 1; sp <= smax; ++sp) {
+    const int iters = (nk + sp - 1) / sp;
+    if ((long)iters * (sp - 1) >= nk) continue;      // an empty trailing split
+    const long per_cu = (tiles * sp + 255) / 256;
+    const long rounds = (per_cu + coresident - 1) / coresident;
+    const double busy = (double)per_cu * (iters * t_mfma + t_epi);
+    const double lat = (double)rounds * (iters * t_lat + t_epi);
+    double t = busy > lat ? busy : lat;
+    if (sp > 1) t += red_fixed + sp * red_per_split;
+    if (t < best_t * 0.97) {                          // prefer fewer splits unless clearly better
+      best_t = t;
+      best = sp;
+    }
+  }
+  return best;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES>
 void launch_cfg(GemmParams& p, hipStream_t s) {
   p.tiles_n = cdiv(p.d.N, BN);
@@ -533,7 +671,7 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   // tile selection: 128x128 (8 waves, 2 workgroups / CU) once the grid fills the chip, else 64x64 (4 waves)
   const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
   bool big = tiles128 >= 128 && (d.N >= 512 || d.K >= 2048);
-  int stages = big ? 2 : 3;
+  int stages = 2;        // 2 = plain two-buffer loop, 3 = register-pipelined loop
   if (d.cfg >= 1 && d.cfg <= 12) {
     const int c = (d.cfg - 1) % 4 + 1;
     big = c >= 3;
@@ -544,13 +682,8 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   const int BM = big ? 128 : 64, BN = big ? 128 : 64;
   int splits = d.splitk;
   const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
-  if (splits == 0) {  // auto: fill the chip on the small-M, huge-K (weight-bandwidth-bound) layers
-    splits = 1;
-    if (tiles < 224 && p.nk >= 64) {     // e.g. the 4x4 / 8x8 layers: M = 128..512, K up to 23040
-      splits = (int)((512 + tiles - 1) / tiles);
-      if (splits > p.nk / 16) splits = p.nk / 16;
-    }
-  }
+  if (const char* e = getenv("MVD_GEMM_SPLITK")) splits = atoi(e);
+  if (splits == 0) splits = choose_splits(tiles, p.nk, big, stages == 3, (size_t)d.M * d.N);
   if (splits < 1) splits = 1;
   if (splits > p.nk) splits = p.nk;
   if (splits > 1) {

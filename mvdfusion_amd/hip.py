@@ -217,7 +217,7 @@ def split_planes(x, out=None, ldp=None):
 
 def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
          bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
-         out_planes=None):
+         out_planes=None, cfg=None):
     """out = epilogue(A @ W^T).  A: split planes (M, 2*K) int16 (dense) or the NHWC image rows (B*H*W, 2*C) with
     conv=dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
     out: fp32 tensor or None; out_planes: split-planes tensor or None (feeds the next GEMM).
@@ -270,7 +270,8 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.workspace_elems = workspace.numel()
     key = (d.M, d.N, d.K, d.a_mode, d.Cin, d.stride, d.upsample, d.epi, d.prec, res is not None, out is not None,
            out_planes is not None, splitk)
-    cfg = _TUNED.get(key)
+    if cfg is None:
+        cfg = _TUNED.get(key)
     if cfg is None and AUTOTUNE:
         cfg = _autotune(d)
         _TUNED[key] = cfg

@@ -20,10 +20,14 @@ SHAPES = [  # (name, M, N, K, conv(B,H,Cin) or None)
 
 
 def main():
-    prec = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    prec = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    only = sys.argv[2] if len(sys.argv) > 2 else None
     ws = torch.empty(64 * 1024 * 1024, device="cuda")
+    hip.AUTOTUNE = bool(os.environ.get("MVD_BENCH_TUNE"))
     tot_ms, tot_fl = 0.0, 0.0
     for name, M, N, K, conv in SHAPES:
+        if only and only not in name:
+            continue
         g = torch.Generator().manual_seed(0)
         if conv:
             B, H, Cin = conv
@@ -40,15 +44,28 @@ def main():
             hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, **kw)
         torch.cuda.synchronize()
         reps = 20
+        class _Direct:                # MVD_BENCH_NOGRAPH=1: plain launches (for rocprofv3 counter passes)
+            def launch(self):
+                for _ in range(reps):
+                    hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, **kw)
+        if os.environ.get("MVD_BENCH_NOGRAPH"):
+            graph = _Direct()
+        else:
+            graph = hip.Graph()          # replayed graph: no host launch overhead between the kernels
+            with graph:
+                for _ in range(reps):
+                    hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, **kw)
+        graph.launch()
+        torch.cuda.synchronize()
         e0, e1 = hip.Event(), hip.Event()
         e0.record()
-        for _ in range(reps):
-            hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, **kw)
+        graph.launch()
         e1.record()
         ms = e0.elapsed_ms(e1) / reps
         fl = 2.0 * M * N * K
         tot_ms += ms
         tot_fl += fl
+        name = f"{name} c{hip.LAST_CFG}"
         print(f"{name:20s} M={M:6d} N={N:6d} K={K:6d}  {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TF/s (x{prec} MFMA: {prec*fl/ms/1e9:7.1f})")
     print(f"TOTAL {tot_ms:.3f} ms  {tot_fl/tot_ms/1e9:.1f} TF/s algorithmic")
 
