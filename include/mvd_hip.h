@@ -97,8 +97,9 @@ typedef struct mvd_gemm_desc {
   int ldp;          /* elements per row of out_sp; multiple of 32 */
   int n_store;      /* columns actually stored (<= N; lets N be padded to 16, e.g. the 5-channel UNet head) */
   const float* bias;     /* [N] or NULL */
-  const float* bias_b;   /* [M / rows_per_batch][N] or NULL (per-view vector, e.g. the kv_len==1 cross-attention) */
+  const float* bias_b;   /* [M / rows_per_batch][ldbb] or NULL (per-view vector, e.g. the kv_len==1 cross-attention) */
   int rows_per_batch;
+  int ldbb;              /* row stride of bias_b in floats (multiple of 4); 0 = N */
   const float* colscale; /* [N] or NULL (adaLN gate) */
   const float* res;      /* [M][ldr] or NULL */
   int ldr;
@@ -107,16 +108,18 @@ typedef struct mvd_gemm_desc {
   int heads, dhead, L, Lpad; /* rows m = b*L + token */
   float qscale;              /* dhead^-0.5, applied to q in fp32 before the split */
   /* split-K: 1 = none; >1 = that many K slices; 0 = choose automatically (fills the 256 CUs when the tile grid
-   * is small, i.e. the weight-bandwidth-bound low-resolution layers).  Partial fp32 slabs (splitk*M*N) go to
-   * `workspace` and are reduced by a second kernel that applies the epilogue; without a workspace (or when it is
-   * too small: workspace_elems) the GEMM runs unsplit. */
+   * is small or divides badly over them -- a small time model, gemm.hip: choose_splits).  Partial fp32 slabs
+   * (splitk*M*N) go to `workspace`; a second kernel sums them in slice order 0..splitk-1 and applies the
+   * epilogue; without a workspace (or when it is too small: workspace_elems) the GEMM runs unsplit. */
   int splitk;
   float* workspace;
   size_t workspace_elems;
-  /* kernel configuration: 0 = built-in heuristic; 1 = 64x64 tile / 3 LDS stages, 2 = 64x64 / 2 stages,
-   * 3 = 128x128 / 2 stages, 4 = 128x128 / 3 stages (tile order across the 8 XCDs chosen by the byte-cost model);
-   * 5-8 = the same four with the n-fastest tile order forced, 9-12 = with the m-fastest order forced.  The host mirror times the candidates once per distinct problem
-   * shape during the eager warm-up step and passes the winner from then on (mvdfusion_amd/hip.py: autotune). */
+  /* kernel configuration: 0 = built-in heuristic; 1 = 64x64 tile / register-pipelined loop, 2 = 64x64 / plain loop,
+   * 3 = 128x128 / plain loop, 4 = 128x128 / register-pipelined loop (tile order across the 8 XCDs chosen by the
+   * byte-cost model); 5-8 = the same four with the n-fastest tile order forced, 9-12 = with the m-fastest order forced.
+   * Both loops keep two k-tiles in LDS; the pipelined one also double-buffers the MFMA fragments in registers.  The
+   * host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
+   * winner from then on (mvdfusion_amd/hip.py: autotune). */
   int cfg;
 } mvd_gemm_desc;
 

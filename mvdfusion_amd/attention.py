@@ -147,10 +147,14 @@ class SpatialTransformer(nn.Module):
         o = tb.self_attn(ctx, t, B, L, "tf")
         # attn2 on the length-1 CLIP context: per-view vector to_out(to_v(ctx_b)), broadcast over the pixels
         a2 = tb.attn2
-        v1 = ctx.ws.get("tf.v1", (B, C))
-        ctx.gemv_rows(a2.to_v.weight, None, ctx.context, v1)
-        vec = ctx.ws.get("tf.vec", (B, C))
-        ctx.gemv_rows(a2.to_out[0].weight, a2.to_out[0].bias, v1, vec)
+        xvec = getattr(ctx, "xattn_vec", None)
+        if xvec is not None and self in xvec:
+            vec = xvec[self]       # slice of the one batched GEMV over all 16 layers (UNetModel.cross_attn_vectors)
+        else:
+            v1 = ctx.ws.get("tf.v1", (B, C))
+            ctx.gemv_rows(a2.to_v.weight, None, ctx.context, v1)
+            vec = ctx.ws.get("tf.vec", (B, C))
+            ctx.gemv_rows(a2.to_out[0].weight, a2.to_out[0].bias, v1, vec)
         t2 = ctx.ws.get("tf.t2", (M, C))
         ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L)
         t3 = tb.feed_forward(ctx, t2, M, "tf")

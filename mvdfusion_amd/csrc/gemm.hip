@@ -53,7 +53,7 @@ __device__ __forceinline__ void epi_store_elem(const mvd_gemm_desc& d, int m, in
   if (d.epi == MVD_EPI_STORE && n >= d.n_store) return;  // padded columns (bias / res have n_store entries)
   v *= d.acc_scale;
   if (d.bias) v += d.bias[n];
-  if (d.bias_b) v += d.bias_b[(size_t)(m / d.rows_per_batch) * d.N + n];
+  if (d.bias_b) v += d.bias_b[(size_t)(m / d.rows_per_batch) * d.ldbb + n];
   if (d.epi == MVD_EPI_QKV) {
     const int C = d.heads * d.dhead;
     const int which = n / C;
@@ -101,7 +101,7 @@ __device__ __forceinline__ void epi_store4(const mvd_gemm_desc& d, int m, int n,
     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
   }
   if (d.bias_b) {
-    const float4 b = *(const float4*)(d.bias_b + (size_t)(m / d.rows_per_batch) * d.N + n);
+    const float4 b = *(const float4*)(d.bias_b + (size_t)(m / d.rows_per_batch) * d.ldbb + n);
     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
   }
   if (d.act) {
@@ -427,7 +427,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   const int wm0 = m0 + wm * WTM, wn0 = n0 + wn * WTN;
   if (wn0 >= d.N) return;
 
-  if (p.splits > 1) {   // raw partial sums -> workspace slab
+  if (p.splits > 1) {   // raw partial sums -> workspace slab; splitk_reduce_kernel sums the slabs and applies the epilogue.
+    // (Reducing inside this kernel -- last-arriving workgroup per tile behind an agent-scope release/acquire -- was
+    //  built and measured: bit-identical, but 15 % slower per step.  A 128x128 tile has 64 KB slabs, far above the
+    //  few tens of KB where that hand-off pays, and its cache-wide write-back / invalidate disturbs the operand
+    //  streams of the other workgroups.)
     float* ws = d.workspace + (size_t)blockIdx.z * d.M * d.N;
 #pragma unroll
     for (int ps = 0; ps < WTM / 8; ++ps) {
@@ -653,7 +657,11 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   if (d.epi == MVD_EPI_STORE) {
     MVD_CHECK_ARG(d.out != nullptr || d.out_sp != nullptr, "mvd_gemm: no output");
     if (d.n_store <= 0 || d.n_store > d.N) d.n_store = d.N;
-    if (d.bias_b) MVD_CHECK_ARG(d.rows_per_batch > 0, "mvd_gemm: bias_b needs rows_per_batch");
+    if (d.bias_b) {
+      MVD_CHECK_ARG(d.rows_per_batch > 0, "mvd_gemm: bias_b needs rows_per_batch");
+      if (d.ldbb == 0) d.ldbb = d.N;
+      MVD_CHECK_ARG(d.ldbb % 4 == 0, "mvd_gemm: ldbb %% 4 != 0");
+    }
   } else if (d.epi == MVD_EPI_GEGLU) {
     MVD_CHECK_ARG((d.out != nullptr || d.out_sp != nullptr) && d.N % 32 == 0, "mvd_gemm: GEGLU needs an output and N %% 32 == 0");
     d.bias_b = nullptr;

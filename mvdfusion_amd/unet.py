@@ -210,6 +210,7 @@ class UNetModel(nn.Module):
         self.out = nn.Sequential(normalization(ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
         self._head = None
         self._temb = None
+        self._xattn = None
 
     # ------------------------------------------------------------------ reference API (unet.py:558-576)
     def get_cross_attn_parameters(self, finetune_cross_attn, finetune_view_attn):
@@ -251,11 +252,33 @@ class UNetModel(nn.Module):
         hip.gemv(w, bias, emb, out, act_in=hip.ACT_SILU)
         ctx.emb_bias = {b: out[0, lo:hi] for b, (lo, hi) in offs.items()}
 
+    def cross_attn_vectors(self, ctx):
+        """attn2 of every SpatialTransformer sees the length-1 CLIP context: softmax over one key is 1, so its output is
+        the per-view vector to_out(to_v(context)) (attention.py:170-193 with kv_len 1).  The two linear maps are composed
+        once (W = Wo Wv in fp64, rounded to fp32 -- weight preprocessing like packing) and all 16 layers are evaluated
+        by ONE GEMV per step over the row-concatenated W; each layer takes its column slice as the GEMM bias_b."""
+        if self._xattn is None:
+            sts = [m for m in self.modules() if isinstance(m, SpatialTransformer)]
+            ws, bs, offs, o = [], [], {}, 0
+            for st in sts:
+                a2 = st.transformer_blocks[0].attn2
+                wo, wv = a2.to_out[0].weight.detach().double(), a2.to_v.weight.detach().double()
+                ws.append((wo @ wv).float())
+                bs.append(a2.to_out[0].bias.detach().float())
+                offs[st] = (o, o + st.in_channels)
+                o += st.in_channels
+            self._xattn = (torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous(), offs, o)
+        w, bias, offs, total = self._xattn
+        out = ctx.ws.get("xattn.vec", (ctx.context.shape[0], total))
+        ctx.gemv_rows(w, bias, ctx.context, out)
+        ctx.xattn_vec = {st: out[:, lo:hi] for st, (lo, hi) in offs.items()}
+
     def run(self, ctx, x_in, t_sin, S):
         """x_in: split planes (B*S*S, 2*32) of the channels-last zero-padded input; t_sin: (1, model_channels) sinusoid; returns the
         (B*S*S, 8) head output (first out_channels columns valid)."""
         B = ctx.B
         self.time_biases(ctx, t_sin)
+        self.cross_attn_vectors(ctx)
         hs = []
         H = W = S
         h = x_in
