@@ -91,7 +91,7 @@ def profile_gemm_kernels(eng, cfg_scale):
         Kp = W.K
         c = (hip.LAST_CFG - 1) % 4 + 1 if hip.LAST_CFG else 0     # tuned kernel configuration of this call
         bm = {0: "auto", 1: 64, 2: 64, 3: 128, 4: 128}[c]
-        st = {0: "auto", 1: 3, 2: 2, 3: 2, 4: 3}[c]
+        st = {0: "auto", 1: 3, 2: 2, 3: 2, 4: 3}[c]      # 2 = plain two-buffer loop, 3 = register-pipelined loop
         tiles = -(-M // (bm if c else 64)) * -(-W.N // (bm if c else 64))
         split = kw.get("splitk", 0) == 0 and tiles <= 96 and Kp // 32 >= 64
         # template args: <BM, BN, WM, WN, NS, AMODE, STAGES> as in csrc/gemm.hip
@@ -246,7 +246,8 @@ def main():
                            "avg_launch_us": b["ms"] / b["n"] * 1e3, "achieved": ach / 1e12, "peak": MFMA_BF16_DENSE_PEAK / 1e12,
                            "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK, "traffic": None,
                            "note": "algorithmic FLOPs = 2*M*N*K of the fp32 problem against the dense 16-bit MFMA peak; the "
-                                   "x3 kernels issue 3 MFMA products per algorithmic MAC, so MFMA-pipe utilisation is 3x this",
+                                   "f16x4 kernels issue 4 MFMA products per algorithmic MAC (3 for x3), so MFMA-pipe "
+                                   "utilisation is that multiple of frac",
                            "gemm_share_of_step_ms": tot}
         if not a.no_cpu_baseline:
             cb, _ = cpu_baseline(sd, V, S, D, cfg_scale)

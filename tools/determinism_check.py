@@ -24,7 +24,7 @@ def gemm_runs():
             kw = {}
         R = torch.randn(M, N, generator=g).cuda()
         ref = None
-        for cfg in range(5, 13):
+        for cfg in range(5, 13):   # both tile sizes x both loops x both forced tile orders
             outs = []
             for rep in range(4):
                 out = torch.full((M, N), float("nan"), device="cuda")

@@ -24,6 +24,7 @@ def main():
     only = sys.argv[2] if len(sys.argv) > 2 else None
     ws = torch.empty(64 * 1024 * 1024, device="cuda")
     hip.AUTOTUNE = bool(os.environ.get("MVD_BENCH_TUNE"))
+    force = int(os.environ["MVD_BENCH_CFG"]) if os.environ.get("MVD_BENCH_CFG") else None   # explicit kernel configuration
     tot_ms, tot_fl = 0.0, 0.0
     for name, M, N, K, conv in SHAPES:
         if only and only not in name:
@@ -41,20 +42,20 @@ def main():
         out = torch.empty(M, N, device="cuda")
         R = torch.randn(M, N, generator=g).cuda()
         for _ in range(3):
-            hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, **kw)
+            hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, cfg=force, **kw)
         torch.cuda.synchronize()
         reps = 20
         class _Direct:                # MVD_BENCH_NOGRAPH=1: plain launches (for rocprofv3 counter passes)
             def launch(self):
                 for _ in range(reps):
-                    hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, **kw)
+                    hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, cfg=force, **kw)
         if os.environ.get("MVD_BENCH_NOGRAPH"):
             graph = _Direct()
         else:
             graph = hip.Graph()          # replayed graph: no host launch overhead between the kernels
             with graph:
                 for _ in range(reps):
-                    hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, **kw)
+                    hip.gemm(A, W, out, prec=prec, res=R, workspace=ws, cfg=force, **kw)
         graph.launch()
         torch.cuda.synchronize()
         e0, e1 = hip.Event(), hip.Event()
