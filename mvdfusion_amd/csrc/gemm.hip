@@ -161,7 +161,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   static_assert(A_GRAN % NW == 0 && B_GRAN % NW == 0, "granules must divide evenly over the waves");
   static_assert(WTN == 32, "epilogue assumes 32-column wave tiles (one GEGLU value/gate block, one QKV head-aligned block)");
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + (AMODE != MVD_A_DENSE ? BM * 9 * 4 : 0)];
 
   const mvd_gemm_desc& d = p.d;
   const int tid = threadIdx.x;
@@ -190,9 +190,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   const int gr = lane >> 3;
   const u16* zero = (const u16*)g_zero_page;
 
-  const u16* a_src[AI];     // per A granule: source row base (k = 0, + this lane's chunk) or zero page
-  int a_oy[AI], a_ox[AI];
+  const u16* a_src[AI];     // dense: per A granule source row base (k = 0, + this lane's chunk)
   bool a_ok[AI];
+  int a_tab[AI], a_chunk[AI];   // conv: LDS index of this lane's row in the tap table, chunk offset inside the 128-byte line
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int gi = wave + i * NW;            // A granule index = 8-row group of the block tile
@@ -200,19 +200,41 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const int gc = (lane & 7) ^ ((R >> 1) & 7);
     const int m = m0 + gi * 8 + gr;
     a_ok[i] = m < d.M;
-    const u16* base = (const u16*)d.A;
-    if (AMODE == MVD_A_DENSE) {
-      a_src[i] = base + (size_t)(a_ok[i] ? m : 0) * 2 * d.lda + gc * 8;
-      a_oy[i] = a_ox[i] = 0;
-    } else {
-      const int hw = d.Hout * d.Wout;
-      const int mm = a_ok[i] ? m : 0;
-      const int b = mm / hw;
-      const int rem = mm - b * hw;
-      a_oy[i] = rem / d.Wout;
-      a_ox[i] = rem - a_oy[i] * d.Wout;
-      a_src[i] = base + (size_t)b * d.Hin * d.Win * 2 * d.Cin + gc * 8;
+    a_src[i] = (const u16*)d.A + (size_t)(a_ok[i] ? m : 0) * 2 * d.lda + gc * 8;
+    a_tab[i] = (gi * 8 + gr) * 9;
+    a_chunk[i] = gc * 8;
+  }
+  // conv: source offset (u16 units from d.A, channel 0) of every (tile row, filter tap), -1 where the tap falls into
+  // the zero padding or the row is outside M.  Filled once per workgroup; the k loop reads one entry per granule.
+  int* s_tab = (int*)(smem + SMEM);
+  if (AMODE != MVD_A_DENSE) {
+    const int hw = d.Hout * d.Wout;
+    for (int e = tid; e < BM * 9; e += NW * 64) {
+      const int row = e / 9, tap = e - row * 9;
+      const int m = m0 + row;
+      int off = -1;
+      if (m < d.M) {
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        int iy, ix;
+        bool ok;
+        if (d.upsample) {
+          const int uy = oy + ky - 1, ux = ox + kx - 1;
+          ok = uy >= 0 && uy < d.Hout && ux >= 0 && ux < d.Wout;
+          iy = uy >> 1;
+          ix = ux >> 1;
+        } else {
+          iy = oy * d.stride + ky - 1;
+          ix = ox * d.stride + kx - 1;
+          ok = iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
+        }
+        if (ok) off = ((b * d.Hin + iy) * d.Win + ix) * 2 * d.Cin;
+      }
+      s_tab[e] = off;
     }
+    __syncthreads();
   }
   const u16* b_src[BI];     // per B granule: micro-tile rows at kt = 0 (+ this lane's chunk) or null (-> zero page)
 #pragma unroll
@@ -225,33 +247,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   }
   const size_t b_kstride = (size_t)p.nt16 * 1024;   // elements between consecutive k-tiles of the packed weight
 
-  // Running DMA source pointers: every stage() call moves each of them one k-tile forward, so that the steady-state
-  // loop carries no address arithmetic beyond one 64-bit add per granule.  Rows / weight tiles outside the problem
-  // (and conv taps that fall into the zero padding) point at the zero page with step 0.
+  // Running DMA sources: every stage() call moves one k-tile forward.  Dense A and the packed weights advance a
+  // pointer (rows / weight tiles outside the problem sit on the zero page with step 0).  Conv K order is
+  // (32-channel block, tap, channel): the 9 taps of one channel block are consecutive k-tiles, so the 3x3 neighbourhood
+  // re-reads of a 128-byte pixel line happen back to back and hit L2 (tap-major order re-fetched the whole image 9 times
+  // from the memory side: 9x the algorithmic A bytes in FETCH_SIZE).
   const u16* a_cur[AI];
   int a_step[AI];
-  int c_tap = 0, c_c0 = 0;                    // conv: current filter tap and channel offset (uniform)
-  auto set_tap = [&](int tap) {               // conv: per-lane source of this tap (called once per Cin/32 k-tiles)
-    const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      int iy, ix;
-      bool ok = a_ok[i];
-      if (d.upsample) {
-        const int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
-        ok = ok && uy >= 0 && uy < d.Hout && ux >= 0 && ux < d.Wout;
-        iy = uy >> 1;
-        ix = ux >> 1;
-      } else {
-        iy = a_oy[i] * d.stride + ky - 1;
-        ix = a_ox[i] * d.stride + kx - 1;
-        ok = ok && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
-      }
-      const int off = ok ? (iy * d.Win + ix) * 2 * d.Cin + c_c0 * 2 : 0;
-      a_cur[i] = ok ? a_src[i] + off : zero;
-      a_step[i] = ok ? 64 : 0;
-    }
-  };
+  int a_off[AI];                              // conv: table entry of the tap staged next
+  int c_tap = 0, c_cb = 0;                    // conv: tap and channel block of the k-tile staged next (uniform)
   if (AMODE == MVD_A_DENSE) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
@@ -259,10 +263,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       a_step[i] = a_ok[i] ? 64 : 0;
     }
   } else {
-    const int k0 = kt0 * 32;
-    c_tap = k0 / d.Cin;
-    c_c0 = k0 - c_tap * d.Cin;
-    set_tap(c_tap);
+    c_cb = kt0 / 9;
+    c_tap = kt0 - c_cb * 9;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_off[i] = s_tab[a_tab[i] + c_tap];
   }
   const u16* b_cur[BI];
   size_t b_step[BI];
@@ -276,9 +280,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     unsigned char* sbase = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_cur[i],
+      const u16* src;
+      if (AMODE == MVD_A_DENSE) {
+        src = a_cur[i];
+        a_cur[i] += a_step[i];
+      } else {
+        src = a_off[i] >= 0 ? (const u16*)d.A + (unsigned)(a_off[i] + c_cb * 64 + a_chunk[i]) : zero;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sbase + (wave + i * NW) * 1024), 16, 0, 0);
-      a_cur[i] += a_step[i];
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -288,13 +298,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       b_cur[i] += b_step[i];
     }
   };
-  auto advance_tap = [&]() {                  // conv bookkeeping after each stage(): uniform branch, taken every Cin/32 tiles
+  auto advance_tap = [&]() {                  // conv bookkeeping after each stage(): next tap, prefetch its table entries
     if (AMODE != MVD_A_DENSE) {
-      c_c0 += 32;
-      if (c_c0 == d.Cin) {
-        c_c0 = 0;
-        if (++c_tap < 9) set_tap(c_tap);
+      if (++c_tap == 9) {
+        c_tap = 0;
+        ++c_cb;
       }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) a_off[i] = s_tab[a_tab[i] + c_tap];
     }
   };
 
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       mfma_tile(fah[P], fal[P], fbh[P], fbl[P]);
       if (FULL) {
         constexpr int NM = TM * TN * NS, NR = (TM + TN) * (NS >= 3 ? 2 : 1);
-        sched_pattern<0, LPS + NR, NM, LPS>();
+        sched_pattern<0, LPS + NR, NM, LPS>();     // (the conv table reads of advance_tap() follow the pattern)
       }
       if (FULL || it + 2 < nkt) advance_tap();
     };
@@ -386,12 +397,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       step(integral_constant<int, 0>{}, integral_constant<bool, true>{}, it);
       step(integral_constant<int, 1>{}, integral_constant<bool, true>{}, it + 1);
     }
-    for (; it < nkt; ++it) {
-      if (it & 1)
-        step(integral_constant<int, 1>{}, integral_constant<bool, false>{}, it);
-      else
-        step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, it);
-    }
+    // at most three k-tiles remain (`it` is even).  Straight-line on purpose: as a loop with a run-time parity switch
+    // the compiler carried the accumulators through AGPR copies on the back edge, and one of them (v_accvgpr_mov of the
+    // register the last MFMA had just written) read a stale value in the 64x64 conv instantiation -- every
+    // configuration is now cross-checked in tests/test_gpu_ops.py::test_gemm_configurations_agree.
+    if (it < nkt) step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, it);
+    if (it + 1 < nkt) step(integral_constant<int, 1>{}, integral_constant<bool, false>{}, it + 1);
+    if (it + 2 < nkt) step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, it + 2);
     __syncthreads();   // the epilogue reuses the stage buffers
   } else {
     // ---- plain two-buffer loop: DMA of k-tile t+1 in flight while tile t is read and multiplied
@@ -741,9 +753,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
     float v = 0.f;
     if (src_n < N) {
       if (conv_cin > 0) {
-        const int tap = k / conv_cin_pad;
-        const int ci = k - tap * conv_cin_pad;
-        if (ci < conv_cin && tap < 9) v = w[((size_t)src_n * conv_cin + ci) * 9 + tap];
+        const int blk = k >> 5;                      // K order: (32-channel block, tap, channel in block)
+        const int cb = blk / 9, tap = blk - cb * 9;
+        const int ci = cb * 32 + (k & 31);
+        if (ci < conv_cin) v = w[((size_t)src_n * conv_cin + ci) * 9 + tap];
       } else if (k < K) {
         v = w[(size_t)src_n * ldw + k];
       }

@@ -140,6 +140,42 @@ def test_conv3x3(hip, prec, case):
     assert rel_err(got, ref) < TOL[prec]
 
 
+@pytest.mark.parametrize("cfg", [5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("splitk", [0, 1, 3])
+def test_gemm_configurations_agree(hip, cfg, splitk):
+    """Every kernel configuration the autotuner may pick (tile x loop variant x tile order, include/mvd_hip.h `cfg`), with and
+    without split-K, on conv and dense problems with even and odd k-tile counts: all must match the fp32 reference AND be
+    repeatable bit for bit (a stale-accumulator miscompile of one instantiation showed up exactly here)."""
+    ws = torch.empty(16 * 1024 * 1024, device="cuda")
+    for B, H, Cin, Cout in [(2, 32, 64, 64), (2, 16, 96, 320), (1, 8, 320, 48)]:       # nk = 18, 27, 90
+        x = torch.randn(B, Cin, H, H, generator=g(40))
+        w = torch.randn(Cout, Cin, 3, 3, generator=g(41)) / math.sqrt(9 * Cin)
+        ref = F.conv2d(x, w, None, padding=1).permute(0, 2, 3, 1).reshape(B * H * H, Cout)
+        Wp = hip.pack_conv3x3(w.cuda(), None)
+        xp = hip.split_planes(x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda())
+        outs = []
+        for rep in range(3):
+            out = torch.full((B * H * H, Cout), float("nan"), device="cuda")
+            hip.gemm(xp, Wp, out, prec=4, workspace=ws, cfg=cfg, splitk=splitk,
+                     conv=dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, upsample=0))
+            outs.append(out.cpu())
+        assert rel_err(outs[0], ref) < TOL[4], (B, H, Cin, Cout)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for M, N, K in [(2048, 320, 320), (512, 640, 2592), (100, 48, 96)]:                   # nk = 10, 81, 3
+        a = torch.randn(M, K, generator=g(42))
+        w = torch.randn(N, K, generator=g(43)) / math.sqrt(K)
+        ref = a @ w.t()
+        Wp = hip.pack_linear(w.cuda(), None)
+        ap = hip.split_planes(a.cuda())
+        outs = []
+        for rep in range(3):
+            out = torch.full((M, N), float("nan"), device="cuda")
+            hip.gemm(ap, Wp, out, prec=4, workspace=ws, cfg=cfg, splitk=splitk)
+            outs.append(out.cpu())
+        assert rel_err(outs[0], ref) < TOL[4], (M, N, K)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("B,HW,C,silu,eps", [(4, 1024, 320, True, 1e-5), (2, 256, 1920, True, 1e-5), (3, 64, 1280, False, 1e-6),
                                              (2, 16, 2560, True, 1e-5), (2, 1024, 32, False, 1e-6)])

@@ -33,6 +33,9 @@ def gemm_runs():
                 outs.append(out)
             torch.cuda.synchronize()
             same = all(torch.equal(outs[0], o) for o in outs[1:])
+            if not same:
+                print("   per-rep max|diff vs rep 3|:", [f"{float((o - outs[3]).abs().max()):.2e}" for o in outs],
+                      "mismatching elements rep0:", int((outs[0] != outs[3]).sum()))
             fin = bool(torch.isfinite(outs[0]).all())
             if ref is None:
                 ref = outs[0]

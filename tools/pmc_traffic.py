@@ -1,0 +1,37 @@
+"""Summarise the two rocprofv3 --pmc passes of tools/pmc_traffic.sh: average FETCH_SIZE / WRITE_SIZE per launch and kernel.
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KiB, and on gfx950 FETCH_SIZE tallies the
+128-byte requests of wide coalesced reads (global_load_dwordx4 and LDS-DMA alike) at 64 bytes (MI355X_MICROARCH.md, HBM).
+"""
+import csv, glob, json, os, re, sys
+
+
+def load(d):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    assert f, f"no counter_collection.csv under {d}"
+    acc = {}
+    for row in csv.DictReader(open(f[0])):
+        k = re.sub(r"\(anonymous namespace\)::|void ", "", row["Kernel_Name"])
+        k = re.sub(r"\(.*$", "", k)
+        a = acc.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += float(row["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    res = {}
+    for k in fetch:
+        nf, sf = fetch[k]
+        nw, sw = write.get(k, [1, 0.0])
+        res[k] = {"launches_profiled": nf, "fetch_size_kib_per_launch": sf / nf, "write_size_kib_per_launch": sw / max(nw, 1),
+                  "hbm_bytes_per_launch": (2.0 * sf / nf + sw / max(nw, 1)) * 1024.0}
+    json.dump({"recipe": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 1 "
+                         "--no-cpu-baseline; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": res}, open(out, "w"), indent=1)
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"])[:12]:
+        print(f"{k[:60]:60s} n={v['launches_profiled']:5d}  {v['hbm_bytes_per_launch'] / 1e6:8.2f} MB/launch")
+
+
+if __name__ == "__main__":
+    main()
