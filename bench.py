@@ -96,8 +96,13 @@ def profile_gemm_kernels(eng, cfg_scale):
         split = kw.get("splitk", 0) == 0 and tiles <= 96 and Kp // 32 >= 64
         # template args: <BM, BN, WM, WN, NS, AMODE, STAGES> as in csrc/gemm.hip
         wmn = "2, 4" if bm == 128 else "2, 2"
+        rows_in = conv["B"] * conv["Hin"] * conv["Win"] if conv else M
+        k_in = conv["Cin"] if conv else Kp
+        n_out = 4.0 * M * N * ((out is not None) + (kw.get("out_planes") is not None) + (kw.get("res") is not None)) \
+            + (4.0 * M * N if kw.get("qkv") else 0.0)
+        abytes = 4.0 * rows_in * k_in + 4.0 * W.N * Kp + n_out      # A planes + packed W (hi+lo = 4 B/elem) + outputs / residual
         recs.append(dict(sym=f"gemm_kernel<{bm}, {bm}, {wmn}, {kw.get('prec', 3)}, {1 if conv else 0}, {st}>", M=M, N=N,
-                         K=Kp, flops=2.0 * M * N * Kp, split=split, ev=(e0, e1)))
+                         K=Kp, flops=2.0 * M * N * Kp, bytes=abytes, split=split, ev=(e0, e1)))
         return r
 
     hip.gemm = timed
@@ -113,10 +118,11 @@ def profile_gemm_kernels(eng, cfg_scale):
     by = {}
     for r in recs:
         ms = r["ev"][0].elapsed_ms(r["ev"][1])
-        b = by.setdefault(r["sym"], dict(n=0, ms=0.0, flops=0.0, n_split=0))
+        b = by.setdefault(r["sym"], dict(n=0, ms=0.0, flops=0.0, bytes=0.0, n_split=0))
         b["n"] += 1
         b["ms"] += ms
         b["flops"] += r["flops"]
+        b["bytes"] += r["bytes"]
         b["n_split"] += int(r["split"])
     return by
 
@@ -240,15 +246,41 @@ def main():
         for k, b in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
             log(f"[bench] {k:34s} launches {b['n']:4d} (split-K {b['n_split']:3d})  total {b['ms']:8.3f} ms  "
                 f"avg {b['ms'] / b['n'] * 1e3:8.1f} us  {b['flops'] / b['ms'] / 1e9:8.1f} TFLOP/s algorithmic")
-        dom, b = max(by.items(), key=lambda kv: kv[1]["ms"])
-        ach = b["flops"] / (b["ms"] * 1e-3)
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": b["n"],
-                           "avg_launch_us": b["ms"] / b["n"] * 1e3, "achieved": ach / 1e12, "peak": MFMA_BF16_DENSE_PEAK / 1e12,
-                           "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK, "traffic": None,
-                           "note": "algorithmic FLOPs = 2*M*N*K of the fp32 problem against the dense 16-bit MFMA peak; the "
-                                   "f16x4 kernels issue 4 MFMA products per algorithmic MAC (3 for x3), so MFMA-pipe "
-                                   "utilisation is that multiple of frac",
-                           "gemm_share_of_step_ms": tot}
+        # The dominant kernel is mvd_gemm's gemm_kernel (one source, csrc/gemm.hip; the template arguments are the
+        # tile / loop variants the autotuner picks per shape).  Headline = the whole family (every GEMM launch of the
+        # step); `variants` lists each instantiation under the symbol rocprofv3 reports, for cross-checking
+        # profiles/r01_bench_n1_kernel_stats.csv.
+        nprod = {"f16x4": 4, "f16x3": 3, "bf16x3": 3}.get(a.precision, 1)
+        n_all = sum(b["n"] for b in by.values())
+        fl_all = sum(b["flops"] for b in by.values())
+        by_all = sum(b["bytes"] for b in by.values())
+        ach = fl_all / (tot * 1e-3)
+        pmc, tsrc = {}, None
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tfile):        # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.sh), committed
+            pmc = json.load(open(tfile))["kernels"]
+            tsrc = ("profiles/r01_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
+                    "command, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch over the steady-state launches")
+        variants, tr_sum, tr_n = [], 0.0, 0
+        for k, b in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
+            t = pmc.get(k, {}).get("hbm_bytes_per_launch")
+            if t is not None:
+                tr_sum += t * b["n"]
+                tr_n += b["n"]
+            variants.append({"kernel": k, "launches_per_step": b["n"], "avg_launch_us": b["ms"] / b["n"] * 1e3,
+                             "achieved": b["flops"] / (b["ms"] * 1e-3) / 1e12, "frac": b["flops"] / (b["ms"] * 1e-3) / MFMA_BF16_DENSE_PEAK,
+                             "algorithmic_bytes_per_launch": b["bytes"] / b["n"], "traffic": t})
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<BM, BN, WM, WN, NS, AMODE, LOOP> (all instantiations)",
+                           "launches_per_step": n_all, "avg_launch_us": tot / n_all * 1e3, "achieved": ach / 1e12,
+                           "peak": MFMA_BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK,
+                           "traffic": tr_sum / tr_n if tr_n else None,
+                           "traffic_unit": "bytes per launch (memory-side requests, Infinity-Cache hits included)",
+                           "traffic_source": tsrc, "algorithmic_bytes_per_launch": by_all / n_all,
+                           "mfma_products_per_mac": nprod, "mfma_pipe_frac": nprod * ach / MFMA_BF16_DENSE_PEAK,
+                           "note": "achieved = algorithmic FLOPs (2*M*N*K of the fp32 problem) / HIP-event time of the eager "
+                                   "launches; the split-operand kernels issue `mfma_products_per_mac` MFMA products per "
+                                   "algorithmic MAC, so the MFMA pipe runs at mfma_pipe_frac of the dense 16-bit peak",
+                           "gemm_share_of_step_ms": tot, "variants": variants}
         if not a.no_cpu_baseline:
             cb, _ = cpu_baseline(sd, V, S, D, cfg_scale)
             out["cpu_baseline"] = cb
