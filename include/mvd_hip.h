@@ -140,13 +140,22 @@ int mvd_gemv(const float* W, const float* bias, const float* x, float* y, int M,
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation.
- * GroupNorm(32 groups) on channels-last data, optional fused SiLU (openaimodel.py:201-203,225-227 eps 1e-5;
+ * GroupNorm(32 groups) on channels-last data; `silu` bit 0 = fused SiLU, bit 1 = round the normalised value to fp16 first
+ * (the VAE decoder tail, diffusionmodules/model.py:564-570) (openaimodel.py:201-203,225-227 eps 1e-5;
  * attention.py:76,243,274 and mvdfusion/attention.py:92,132 eps 1e-6; unet.py:496-498).
  * ws: B * chunks * groups * 2 doubles with chunks = mvd_groupnorm_chunks(HW). */
 int mvd_groupnorm_chunks(int HW);
 /* y_sp: the normalised activations in split-planes format (B*HW, C), C % 32 == 0 -- GroupNorm only feeds GEMMs / convs. */
 int mvd_groupnorm_nhwc(const float* x, void* y_sp, const float* gamma, const float* beta, int B, int HW, int C,
                        int groups, float eps, int silu, double* ws, mvd_stream_t stream);
+/* Row softmax: y[r, :] = out_scale * softmax(scale * x[r, :]) of an fp32 (rows, cols) matrix (row stride ldx), written as
+ * split planes (rows, cols), cols % 32 == 0, cols <= 4096.  out_scale (a power of two, e.g. 1024) lifts the probabilities of
+ * wide rows out of the fp16 subnormal range; the consumer GEMM divides it out through its weight's acc_scale.  Replaces
+ * F.softmax in the VAE AttnBlock (external/sd1/ldm/modules/diffusionmodules/model.py:191-193), whose single 512-wide head is
+ * run as two GEMMs. */
+int mvd_softmax_rows(const float* x, void* y_sp, int rows, int cols, int ldx, float scale, float out_scale,
+                     mvd_stream_t stream);
+
 /* LayerNorm over the last dim.  w/b may be NULL (no affine).  w_plus_one: y = norm * (1 + w) + b
  * (adaLN "modulate", view_attn_efficient2.py:15-16,51,53,65-66); attention.py:211-213, mvdfusion/attention.py:35-37. */
 int mvd_layernorm(const float* x, void* y_sp, const float* w, const float* b, int rows, int C, float eps,

@@ -1,0 +1,246 @@
+"""VAE decode executed by HIP kernels -- mirror of ``external.sd1.ldm.models.autoencoder.AutoencoderKL`` (decode side).
+
+SURVEY.md section 8(f) rank 2: ``ViewFusion.decode`` (viewfusion_zero_depth_rgb.py:161-163) is the caller right after the
+sampling loop; ``demo.py:92-94`` runs it three times per scene.  Classes keep the reference's names and state_dict keys:
+
+  ``ResnetBlock`` / ``AttnBlock`` / ``Upsample``  external/sd1/ldm/modules/diffusionmodules/model.py:42-57,82-141,150-205
+  ``Decoder``                                     model.py:462-577
+  ``AutoencoderKL.decode``                        external/sd1/ldm/models/autoencoder.py:331-334
+
+so ``load_state_dict(ckpt, strict=False)`` of a reference VAE checkpoint fills ``decoder.*`` and ``post_quant_conv.*``
+(the encoder half, ``encoder.*`` / ``quant_conv.*``, is section 8(f) rank 3 and not built here: ``encode`` needs an injected
+module).  Everything runs through the same C ABI as the denoiser: implicit-GEMM 3x3 convs (nearest-2x upsample fused
+into the address generator), GroupNorm(+SiLU) producing the GEMM operand directly, and the single 512-wide attention head of
+the mid block as two GEMMs around ``mvd_softmax_rows``.  Activations are fp32 channels-last (B*H*W, C).
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .engine import Ctx
+
+
+def Normalize(in_channels, num_groups=32):
+    return nn.GroupNorm(num_groups=num_groups, num_channels=in_channels, eps=1e-6, affine=True)   # model.py:37-38
+
+
+class Upsample(nn.Module):
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self._p = None
+
+    def run(self, ctx, x, B, H, W):
+        C = self.conv.in_channels
+        if self._p is None:
+            self._p = hip.pack_conv3x3(self.conv.weight, self.conv.bias)
+        xp = hip.split_planes(x, ctx.ws.planes("vae.up.x", B * H * W, C))
+        out = ctx.act((B * 4 * H * W, C))
+        ctx.gemm(xp, self._p, out, conv=dict(B=B, Hin=H, Win=W, Cin=C, Hout=2 * H, Wout=2 * W, stride=1, upsample=1))
+        return out
+
+
+class ResnetBlock(nn.Module):
+    """GN+swish -> conv3x3 -> GN+swish -> (dropout 0) -> conv3x3, + x (1x1 nin_shortcut when widths differ); temb is None
+    in the decoder (temb_channels=0, model.py:471)."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0):
+        super().__init__()
+        assert not conv_shortcut and temb_channels == 0
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.norm2 = Normalize(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if in_channels != out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+        self._p = None
+
+    def packed(self):
+        if self._p is None:
+            sk = hip.pack_linear(self.nin_shortcut.weight, self.nin_shortcut.bias) if hasattr(self, "nin_shortcut") else None
+            self._p = (hip.pack_conv3x3(self.conv1.weight, self.conv1.bias), hip.pack_conv3x3(self.conv2.weight, self.conv2.bias), sk)
+        return self._p
+
+    def run(self, ctx, x, B, H, W):
+        Ci, Co, M = self.in_channels, self.out_channels, B * H * W
+        w1, w2, wsk = self.packed()
+        geo = dict(B=B, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
+        a = ctx.ws.planes("vae.res.a", M, Ci)
+        ctx.groupnorm(x, a, self.norm1, B, H * W, Ci, silu=True)
+        h = ctx.ws.get("vae.res.h", (M, Co))
+        ctx.gemm(a, w1, h, conv=dict(Cin=Ci, **geo))
+        a2 = ctx.ws.planes("vae.res.a2", M, Co)
+        ctx.groupnorm(h, a2, self.norm2, B, H * W, Co, silu=True)
+        skip = x
+        if wsk is not None:
+            skip = ctx.ws.get("vae.res.skip", (M, Co))
+            ctx.gemm(hip.split_planes(x, ctx.ws.planes("vae.res.xp", M, Ci)), wsk, skip)
+        out = ctx.act((M, Co))
+        ctx.gemm(a2, w2, out, conv=dict(Cin=Co, **geo), res=skip)
+        return out
+
+
+class AttnBlock(nn.Module):
+    """Single-head attention over the h*w positions, width C = 512, scale C^-0.5 (model.py:178-205)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.k = nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.v = nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.proj_out = nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self._p = None
+
+    def packed(self):
+        if self._p is None:
+            w = torch.cat([m.weight.detach().reshape(self.in_channels, -1) for m in (self.q, self.k, self.v)], 0)
+            b = torch.cat([m.bias.detach() for m in (self.q, self.k, self.v)], 0)
+            self._p = (hip.pack_linear(w, b), hip.pack_linear(self.proj_out.weight, self.proj_out.bias))
+        return self._p
+
+    def run(self, ctx, x, B, H, W):
+        C, L = self.in_channels, H * W
+        M = B * L
+        assert L % 32 == 0 and L <= 4096, "mvd_softmax_rows holds one row of <= 4096 keys"
+        w_qkv, w_out = self.packed()
+        n = ctx.ws.planes("vae.attn.n", M, C)
+        ctx.groupnorm(x, n, self.norm, B, L, C, silu=False)
+        qkv = ctx.ws.get("vae.attn.qkv", (M, 3 * C))
+        ctx.gemm(n, w_qkv, qkv)
+        o = ctx.ws.planes("vae.attn.o", M, C)
+        qp = ctx.ws.planes("vae.attn.q", L, C)
+        logits = ctx.ws.get("vae.attn.logits", (L, L))
+        prob = ctx.ws.planes("vae.attn.p", L, L)
+        for b in range(B):       # the (L, L) score matrix of one image at a time: K_b and V_b^T take the weight role
+            rows = qkv[b * L:(b + 1) * L]
+            hip.split_planes(rows[:, :C].contiguous(), qp)
+            ctx.gemm(qp, hip.pack_linear(rows[:, C:2 * C].contiguous()), logits, bias=False)
+            hip.softmax_rows(logits, prob, scale=float(C) ** -0.5, out_scale=1024.0)   # p ~ 1/L would sit in fp16 subnormals
+            wv = hip.pack_linear(rows[:, 2 * C:].t().contiguous())
+            wv.acc_scale /= 1024.0
+            ctx.gemm(prob, wv, None, bias=False, out_planes=o[b * L:(b + 1) * L])
+        out = ctx.act((M, C))
+        ctx.gemm(o, w_out, out, res=x)
+        return out
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False,
+                 use_linear_attn=False, attn_type="vanilla", **ignorekwargs):
+        super().__init__()
+        assert not use_linear_attn and attn_type == "vanilla" and not give_pre_end and not tanh_out
+        assert len(attn_resolutions) == 0, "the shipped VAE config has attn_resolutions: [] (configs/mvd_gso.yaml:71)"
+        self.ch, self.num_resolutions, self.num_res_blocks, self.resolution = ch, len(ch_mult), num_res_blocks, resolution
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        self.z_channels, self.out_ch = z_channels, out_ch
+        self.conv_in = nn.Conv2d(z_channels, block_in, kernel_size=3, stride=1, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block = nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, dropout=dropout))
+                block_in = block_out
+            up = nn.Module()
+            up.block = block
+            up.attn = nn.ModuleList()
+            if i_level != 0:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+            self.up.insert(0, up)      # prepend: index = resolution level, as in the reference (model.py:523)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+        self._p = None
+
+    def run(self, ctx, zp, B, S):
+        """zp: split planes (B*S*S, 2*32) of the post_quant_conv output (channels >= z_channels zero) -> (B*H*W, 4) fp32, H = 8S
+        for the 4-level config; the first out_ch columns are the image."""
+        if self._p is None:
+            self._p = (hip.pack_conv3x3(self.conv_in.weight, self.conv_in.bias),
+                       hip.pack_conv3x3(self.conv_out.weight, self.conv_out.bias))
+        w_in, w_out = self._p
+        H = W = S
+        h = ctx.act((B * H * W, self.conv_in.out_channels))
+        ctx.gemm(zp, w_in, h, conv=dict(B=B, Hin=H, Win=W, Cin=w_in.conv_cin, Hout=H, Wout=W, stride=1, upsample=0))
+        h = self.mid.block_1.run(ctx, h, B, H, W)
+        h = self.mid.attn_1.run(ctx, h, B, H, W)
+        h = self.mid.block_2.run(ctx, h, B, H, W)
+        for i_level in reversed(range(self.num_resolutions)):
+            for blk in self.up[i_level].block:
+                h = blk.run(ctx, h, B, H, W)
+            if i_level != 0:
+                h = self.up[i_level].upsample.run(ctx, h, B, H, W)
+                H, W = 2 * H, 2 * W
+        # tail (model.py:564-574): in the forward pass `h + (h_fake - h).detach()` IS h_fake = norm_out(h) rounded to fp16
+        C = self.norm_out.num_channels
+        a = ctx.ws.planes("vae.out.a", B * H * W, C)
+        ctx.groupnorm(h, a, self.norm_out, B, H * W, C, silu=3)       # bit 1: keep the fp16 rounding, bit 0: swish
+        out = ctx.ws.get("vae.out.img", (B * H * W, 4))
+        ctx.gemm(a, w_out, out, ldo=4, conv=dict(B=B, Hin=H, Win=W, Cin=C, Hout=H, Wout=W, stride=1, upsample=0))
+        return out, H, W
+
+
+class AutoencoderKL(nn.Module):
+    """``decode`` on the HIP path; constructor signature of the reference (autoencoder.py:287-296)."""
+
+    def __init__(self, ddconfig, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=(), image_key="image",
+                 colorize_nlabels=None, monitor=None, encoder=None, precision="f16x4"):
+        super().__init__()
+        assert ddconfig["double_z"]
+        self.image_key, self.embed_dim = image_key, embed_dim
+        self.decoder = Decoder(**ddconfig)
+        self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        if encoder is not None:          # host module providing .encode(x) (section 8(f) rank 3, not part of this path)
+            self.encoder_module = encoder
+        hip.set_operand_format("bf16" if precision.startswith("bf16") else "f16")
+        self.precision = {"x3": hip.PREC_BF16X3, "x4": hip.PREC_X4}.get(precision[-2:], hip.PREC_BF16)
+        self._ctx, self._pq, self._tuned = None, None, set()
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+
+    def init_from_ckpt(self, path, ignore_keys=()):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
+        self.load_state_dict(sd, strict=False)
+
+    def encode(self, x):
+        if not hasattr(self, "encoder_module"):
+            raise NotImplementedError("AutoencoderKL.encode: the encoder half is not on the HIP path yet; pass encoder=<module "
+                                      "with .encode(x)> (e.g. the reference VAE on PyTorch-ROCm)")
+        return self.encoder_module.encode(x)
+
+    @torch.no_grad()
+    def decode(self, z):
+        """z (B, z_channels, S, S) fp32 on the GPU -> (B, out_ch, 8S, 8S) fp32 (autoencoder.py:331-334)."""
+        if not z.is_cuda:
+            raise RuntimeError("AutoencoderKL.decode runs on the HIP path only (no CPU fallback)")
+        B, Cz, S, _ = z.shape
+        if self._ctx is None:
+            self._ctx = Ctx(z.device, self.precision)
+            self._pq = hip.pack_linear(self.post_quant_conv.weight, self.post_quant_conv.bias)
+        ctx = self._ctx
+        zin = ctx.ws.get("vae.z", (B * S * S, 32), zero=True)
+        zin[:, :Cz] = z.permute(0, 2, 3, 1).reshape(B * S * S, Cz)
+        zp = hip.split_planes(zin, ctx.ws.planes("vae.zp", B * S * S, 32))
+        pq = ctx.ws.get("vae.pq", (B * S * S, 2 * 32), torch.int16, zero=True)   # columns >= z_channels stay zero planes
+        first = (B, S) not in self._tuned
+        hip.AUTOTUNE = first            # pick the GEMM configuration per problem shape on the first decode of a shape
+        try:
+            ctx.gemm(zp, self._pq, None, out_planes=pq)
+            out, H, W = self.decoder.run(ctx, pq, B, S)
+        finally:
+            hip.AUTOTUNE = False
+        self._tuned.add((B, S))
+        return out[:, :self.decoder.out_ch].reshape(B, H, W, self.decoder.out_ch).permute(0, 3, 1, 2).contiguous()
+
+    def forward(self, input, sample_posterior=True):
+        raise NotImplementedError("training the VAE is out of scope (SURVEY.md section 8)")

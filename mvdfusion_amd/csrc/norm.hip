@@ -137,13 +137,59 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     v.y = v.y * s_a[c + 1] + s_b[c + 1];
     v.z = v.z * s_a[c + 2] + s_b[c + 2];
     v.w = v.w * s_a[c + 3] + s_b[c + 3];
-    if (silu) {
+    if (silu & 2) {   // the VAE decoder tail keeps the GroupNorm output as fp16 (model.py:564-570)
+      v.x = (float)(_Float16)v.x;
+      v.y = (float)(_Float16)v.y;
+      v.z = (float)(_Float16)v.z;
+      v.w = (float)(_Float16)v.w;
+    }
+    if (silu & 1) {
       v.x = silu_f(v.x);
       v.y = silu_f(v.y);
       v.z = silu_f(v.z);
       v.w = silu_f(v.w);
     }
     store_sp4(y_sp, row0 + r, C, c, v.x, v.y, v.z, v.w);
+  }
+}
+
+// Row softmax of a (rows, cols) fp32 logit matrix, scaled first; probabilities written as split planes (the A operand of
+// the P*V GEMM).  One wave per row, cols <= 4096 held in registers (the VAE AttnBlock has one head over h*w <= 4096 keys).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, u16* __restrict__ y_sp, int rows, int cols,
+                                                           int ldx, float scale, float out_scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = (const float4*)(x + (size_t)row * ldx);
+  const int n4 = cols >> 2;
+  float4 v[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < n4) {
+      v[i] = xr[idx];
+      v[i].x *= scale; v[i].y *= scale; v[i].z *= scale; v[i].w *= scale;
+      mx = fmaxf(fmaxf(fmaxf(mx, v[i].x), fmaxf(v[i].y, v[i].z)), v[i].w);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < n4) {
+      v[i].x = expf(v[i].x - mx); v[i].y = expf(v[i].y - mx); v[i].z = expf(v[i].z - mx); v[i].w = expf(v[i].w - mx);
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  sum = wave_sum(sum);
+  const float inv = out_scale / sum;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < n4) store_sp4(y_sp, (size_t)row, cols, idx * 4, v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
   }
 }
 
@@ -231,6 +277,16 @@ extern "C" int mvd_groupnorm_nhwc(const float* x, void* y_sp, const float* gamma
   hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, B), dim3(256), 0, s, x, (u16*)y_sp, gamma, beta, ws, HW, C, groups, chunks,
                      eps, silu);
   MVD_CHECK_LAUNCH("mvd_groupnorm_nhwc/apply");
+  return 0;
+}
+
+extern "C" int mvd_softmax_rows(const float* x, void* y_sp, int rows, int cols, int ldx, float scale, float out_scale,
+                                mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && y_sp && rows > 0 && cols > 0, "mvd_softmax_rows: bad arguments");
+  MVD_CHECK_ARG(cols % 32 == 0 && cols <= 4096 && ldx % 4 == 0 && ldx >= cols, "mvd_softmax_rows: cols=%d must be a multiple of 32, <= 4096", cols);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, (u16*)y_sp, rows, cols, ldx, scale,
+                     out_scale);
+  MVD_CHECK_LAUNCH("mvd_softmax_rows");
   return 0;
 }
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mvd_groupnorm_chunks": (_i, [_i]),
     "mvd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "mvd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "mvd_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "mvd_attn_qk_plane_elems": (_sz, [_i, _i, _i, _i]),
     "mvd_attn_vt_plane_elems": (_sz, [_i, _i, _i, _i]),
     "mvd_attn_lpad": (_i, [_i]),
@@ -326,6 +327,13 @@ def groupnorm(x, y, gamma, beta, B, HW, Cc, eps, silu, ws):
 def layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False):
     """y: split planes (rows, 2*C)."""
     check(lib().mvd_layernorm(ptr(x), ptr(y), ptr(w), ptr(b), rows, Cc, eps, int(w_plus_one), stream()))
+    return y
+
+
+def softmax_rows(x, y, scale=1.0, out_scale=1.0):
+    """y (rows, 2*cols) split planes = out_scale * softmax(scale * x) along the last dim of the fp32 matrix x (rows, cols)."""
+    rows, cols = x.shape
+    check(lib().mvd_softmax_rows(ptr(x), ptr(y), rows, cols, x.stride(0), float(scale), float(out_scale), stream()))
     return y
 
 

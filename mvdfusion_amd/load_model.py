@@ -14,6 +14,7 @@ TARGET_MAP = {
     "mvdfusion.view_attn_efficient2.GridAttn": "mvdfusion_amd.view_attn_efficient2.GridAttn",
     "mvdfusion.unet.UNetModel": "mvdfusion_amd.unet.UNetModel",
     "mvdfusion.scheduler.DDPMScheduler": "mvdfusion_amd.scheduler.DDPMScheduler",
+    "external.sd1.ldm.models.autoencoder.AutoencoderKL": "mvdfusion_amd.autoencoder.AutoencoderKL",   # decode side on HIP
 }
 IGNORED = {"__is_first_stage__", "__is_unconditional__", "dataset", "trainer", "saver"}
 

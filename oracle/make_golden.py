@@ -373,6 +373,43 @@ def gold_spec(model_channels):
           f"{sum(int(np.prod(s)) for _, s in spec) / 1e6:.1f} M params)")
 
 
+
+VAE_DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                    num_res_blocks=2, attn_resolutions=[], dropout=0.0)          # configs/mvd_gso.yaml:53-74
+
+
+def gold_vae_decode(ch, B, zs, tag, full=True):
+    """The REAL AutoencoderKL.decode (+ ViewFusion.decode's unnormalize/clip) on seeded latents; decoder weights from the
+    name-keyed fill.  The decoder is fully convolutional, so small latent sides exercise the identical code."""
+    from external.sd1.ldm.models.autoencoder import AutoencoderKL
+    from utils.common_utils import unnormalize
+    dd = dict(VAE_DDCONFIG)
+    dd["ch"] = ch
+    vae = AutoencoderKL(ddconfig=dd, lossconfig=dict(target="torch.nn.Identity"), embed_dim=4)
+    fill_ref(vae, "vae.")
+    vae.eval()
+    sd = {k: v for k, v in sd_of(vae, "vae.").items() if ".encoder." not in k and not k.startswith("vae.quant_conv")}
+    g = torch.Generator().manual_seed(700 + ch + zs)
+    z = torch.randn(B, 4, zs, zs, generator=g) * 0.18215 * 4.0        # ~ the scale of sampled latents
+    t0 = time.time()
+    with torch.no_grad():
+        raw = vae.decode(z * 1 / 0.18215)
+        ref = unnormalize(raw).clip(0.0, 1.0)                         # viewfusion_zero_depth_rgb.py:161-163
+    dt = time.time() - t0
+    with torch.no_grad():
+        mine_raw = O.vae_decode(sd, "vae.", z * 1 / 0.18215, ch=ch)
+        mine = O.viewfusion_decode(sd, z, ch=ch)
+    e_raw, e = rel_err(mine_raw, raw), float((mine - ref).abs().max())
+    print(f"  vae decode ch={ch} z={zs}: ref {dt:.1f}s, oracle vs reference raw rel-max {e_raw:.2e}, image max-abs {e:.2e}; "
+          f"raw std {float(raw.std()):.3f}, clipped fraction {float(((raw < -1) | (raw > 1)).float().mean()):.3f}")
+    assert e_raw < 2e-5 and e < 2e-5, (e_raw, e)
+    spec = json.dumps([[k, list(v.shape)] for k, v in sd.items()])
+    if full:
+        save(tag, z=z, raw=raw, image=ref, spec=spec)
+    else:
+        save(tag, z=z, raw_strided=raw[:, :, ::7, ::5].contiguous(), raw_std=raw.std(), raw_l2=raw.norm(),
+             image_view0_sub=ref[0, :, ::4, ::4].contiguous(), spec=spec)
+
 ALL = {
     "schedule": gold_schedule,
     "cameras": gold_cameras,
@@ -389,6 +426,9 @@ ALL = {
     "traj32": lambda: gold_trajectory(32, 4, 1, "traj_mc32_v4_d1", steps=5),
     "traj320": lambda: gold_trajectory(320, 4, 1, "traj_mc320_v4_d1_50steps", steps=50),
     "traj320_f64": lambda: gold_trajectory_f64(320, 4, 1, "traj_mc320_v4_d1_50steps_f64", steps=50),
+    "vae32": lambda: gold_vae_decode(32, 2, 8, "vae_dec_ch32_z8"),
+    "vae128": lambda: gold_vae_decode(128, 2, 8, "vae_dec_ch128_z8"),
+    "vae128_z32": lambda: gold_vae_decode(128, 1, 32, "vae_dec_ch128_z32", full=False),
 }
 
 if __name__ == "__main__":

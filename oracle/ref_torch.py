@@ -442,3 +442,82 @@ def denoise_step(sd, x, cams, input_latents, in_cam, clip_v_embed, tables, ddim,
     eps = apply_model(sd, x, cams, input_latents, in_cam, clip_v_embed, t, tables, depth_noise,
                       cfg_scale=cfg_scale, n_pts_per_ray=n_pts_per_ray, unet_kw=unet_kw)
     return ddim_update(x, eps, ddim, index, step_noise if index > 0 else None)
+
+
+# ---------------------------------------------------------------------------------------------
+# VAE decode (the caller right after the sampling loop)
+# external/sd1/ldm/models/autoencoder.py:331-334, external/sd1/ldm/modules/diffusionmodules/model.py:462-577
+# ---------------------------------------------------------------------------------------------
+
+
+def _vae_norm(sd, name, x):
+    """Normalize = GroupNorm(32, C, eps=1e-6, affine) model.py:37-38."""
+    return F.group_norm(x, 32, sd[name + ".weight"], sd[name + ".bias"], eps=1e-6)
+
+
+def _swish(x):
+    """nonlinearity model.py:31-33 -- spelled x*sigmoid(x) as the reference does (F.silu rounds differently by an ulp,
+    enough to flip fp16 roundings in the decoder tail)."""
+    return x * torch.sigmoid(x)
+
+
+def _vae_resnet(sd, pre, x):
+    """ResnetBlock.forward with temb=None, dropout 0 (model.py:121-141); 1x1 nin_shortcut when the width changes."""
+    h = _conv(sd, pre + "conv1", _swish(_vae_norm(sd, pre + "norm1", x)))
+    h = _conv(sd, pre + "conv2", _swish(_vae_norm(sd, pre + "norm2", h)))
+    if pre + "nin_shortcut.weight" in sd:
+        x = _conv(sd, pre + "nin_shortcut", x, padding=0)
+    return x + h
+
+
+def _vae_attn(sd, pre, x):
+    """AttnBlock.forward model.py:178-205: single-head attention over the h*w positions, scale c^-0.5."""
+    h = _vae_norm(sd, pre + "norm", x)
+    q, k, v = (_conv(sd, pre + n, h, padding=0) for n in ("q", "k", "v"))
+    b, c, hh, ww = q.shape
+    q = q.reshape(b, c, hh * ww).permute(0, 2, 1)            # (b, i, c)
+    k = k.reshape(b, c, hh * ww)                             # (b, c, j)
+    w = torch.softmax(torch.bmm(q, k) * (int(c) ** -0.5), dim=2)
+    o = torch.bmm(v.reshape(b, c, hh * ww), w.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return x + _conv(sd, pre + "proj_out", o, padding=0)
+
+
+def vae_decoder_layout(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
+    """[(level, [(block index, cin, cout)], has_upsample)] in execution order (Decoder.__init__ model.py:473-525)."""
+    block_in = ch * ch_mult[-1]
+    out = []
+    for lvl in reversed(range(len(ch_mult))):
+        blocks = []
+        for i in range(num_res_blocks + 1):
+            blocks.append((i, block_in, ch * ch_mult[lvl]))
+            block_in = ch * ch_mult[lvl]
+        out.append((lvl, blocks, lvl != 0))
+    return out
+
+
+def vae_decode(sd, pre, z, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
+    """AutoencoderKL.decode autoencoder.py:331-334 -> Decoder.forward model.py:535-577 (attn_resolutions=[], tanh_out False).
+
+    The tail of the reference is `h_fake = norm_out(h).half(); h = (h-mean)/std; h = h + (h_fake-h).detach()`
+    (model.py:564-570): in the forward pass that is the GroupNorm output ROUNDED TO fp16, re-expressed in fp32 through the
+    instance-normalised tensor (the two roundings of the add are kept)."""
+    d = pre + "decoder."
+    h = _conv(sd, pre + "post_quant_conv", z, padding=0)
+    h = _conv(sd, d + "conv_in", h)
+    h = _vae_resnet(sd, d + "mid.block_1.", h)
+    h = _vae_attn(sd, d + "mid.attn_1.", h)
+    h = _vae_resnet(sd, d + "mid.block_2.", h)
+    for lvl, blocks, up in vae_decoder_layout(ch, ch_mult, num_res_blocks):
+        for i, _, _ in blocks:
+            h = _vae_resnet(sd, f"{d}up.{lvl}.block.{i}.", h)
+        if up:
+            h = _conv(sd, f"{d}up.{lvl}.upsample.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))
+    h_fake = _vae_norm(sd, d + "norm_out", h).to(torch.float16)
+    hn = (h - h.mean([2, 3], keepdim=True)) / h.std([2, 3], keepdim=True)
+    h = hn + (h_fake - hn)
+    return _conv(sd, d + "conv_out", _swish(h))
+
+
+def viewfusion_decode(sd, z, z_scale_factor=0.18215, **kw):
+    """ViewFusion.decode viewfusion_zero_depth_rgb.py:161-163: unnormalize(vae.decode(z / scale)).clip(0, 1)."""
+    return ((vae_decode(sd, "vae.", z * 1 / z_scale_factor, **kw) + 1.0) / 2.0).clip(0.0, 1.0)

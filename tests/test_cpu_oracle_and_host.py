@@ -218,6 +218,42 @@ def test_product_fails_loudly_without_gpu():
                       torch.full((2,), 981))
 
 
+# ------------------------------------------------------------------------------------------------ VAE decode (section 8(f) rank 2)
+@pytest.mark.parametrize("name,ch", [("vae_dec_ch32_z8", 32), ("vae_dec_ch128_z8", 128)])
+def test_oracle_vae_decode_vs_reference(name, ch):
+    """oracle.vae_decode / viewfusion_decode against the REAL AutoencoderKL.decode + ViewFusion.decode (bit-exact where
+    generated; 3e-4 here because another host's conv kernels may flip one of the decoder tail's fp16 roundings)."""
+    import json
+    gd = load_golden(name)
+    sd = syn.det_fill_state_dict(json.loads(str(gd["spec"])))
+    with torch.no_grad():
+        raw = O.vae_decode(sd, "vae.", gd["z"] * 1 / 0.18215, ch=ch)
+        img = O.viewfusion_decode(sd, gd["z"], ch=ch)
+    assert rel_err(raw, gd["raw"]) < 3e-4
+    assert float((img - gd["image"]).abs().max()) < 1e-3
+    assert float(img.min()) == 0.0 and float(img.max()) == 1.0          # the clip is exercised
+
+
+def test_vae_mirror_keys_and_guards():
+    """The HIP decode mirror exposes exactly the reference's decoder / post_quant_conv keys, is what the yaml target
+    resolves to, and has no CPU path."""
+    import json
+    from mvdfusion_amd.autoencoder import AutoencoderKL
+    from mvdfusion_amd.load_model import get_obj_from_str
+    assert get_obj_from_str("external.sd1.ldm.models.autoencoder.AutoencoderKL") is AutoencoderKL
+    spec = json.loads(str(load_golden("vae_dec_ch128_z8")["spec"]))
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    vae = AutoencoderKL(ddconfig=dd, lossconfig=dict(target="torch.nn.Identity"), embed_dim=4, monitor="val/rec_loss")
+    mine = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    ref = {k[len("vae."):]: tuple(s) for k, s in spec}
+    assert mine == ref and len(ref) == 140
+    with pytest.raises(RuntimeError):
+        vae.decode(torch.zeros(1, 4, 8, 8))
+    with pytest.raises(NotImplementedError):
+        vae.encode(torch.zeros(1, 3, 64, 64))
+
+
 def test_det_fill_is_stable_and_nonzero():
     a = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))
     b = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))

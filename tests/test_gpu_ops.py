@@ -192,6 +192,35 @@ def test_groupnorm(hip, B, HW, C, silu, eps):
     assert rel_err(planes_to_float(y).view(B, HW, C), ref) < PL + 3e-6
 
 
+def test_groupnorm_fp16_kept_output(hip):
+    """silu flag bit 1: the GroupNorm result is rounded to fp16 before the swish (VAE decoder tail, model.py:564-570)."""
+    B, HW, C = 2, 4096, 128
+    x = torch.randn(B, HW, C, generator=g(33)) * 3 + 0.2
+    gm, bt = torch.randn(C, generator=g(34)), torch.randn(C, generator=g(35))
+    y = F.group_norm(x.permute(0, 2, 1), 32, gm, bt, eps=1e-6).permute(0, 2, 1)
+    ref = y.half().float()
+    ref = ref * torch.sigmoid(ref)
+    yp = hip.planes_like(B * HW, C, "cuda")
+    ws = torch.empty(B * hip.lib().mvd_groupnorm_chunks(HW) * 32 * 2, dtype=torch.float64, device="cuda")
+    xd, gd_, bd = x.cuda(), gm.cuda(), bt.cuda()           # keep the device tensors alive across the async launch
+    hip.groupnorm(xd, yp, gd_, bd, B, HW, C, 1e-6, 3, ws)
+    got = planes_to_float(yp).view(B, HW, C)
+    # a value within an fp32 ulp of an fp16 rounding boundary may round the other way: allow 2^-11 relative on <0.1 % of them
+    d = (got - ref).abs()
+    assert float((d > 2e-6 * (1 + ref.abs())).float().mean()) < 1e-3
+    assert float((d / (1e-3 + ref.abs())).max()) < 2.5e-3      # one flipped fp16 ulp (2^-10 at the bottom of a binade) through the swish
+
+
+@pytest.mark.parametrize("rows,cols,scale", [(1024, 1024, 512 ** -0.5), (64, 64, 1.0), (100, 4096, 0.05), (7, 32, 3.0)])
+def test_softmax_rows(hip, rows, cols, scale):
+    x = torch.randn(rows, cols, generator=g(36)) * 8
+    ref = torch.softmax(x * scale, dim=1)
+    yp = hip.planes_like(rows, cols, "cuda")
+    xd = x.cuda()
+    hip.softmax_rows(xd, yp, scale, out_scale=1024.0)
+    assert rel_err(planes_to_float(yp) / 1024.0, ref) < 2e-6 + PL
+
+
 @pytest.mark.parametrize("rows,C", [(1000, 320), (64, 1280), (4096, 256), (37, 640), (16, 32)])
 def test_layernorm(hip, rows, C):
     x = torch.randn(rows, C, generator=g(33)) * 3 + 1
