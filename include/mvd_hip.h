@@ -86,6 +86,8 @@ typedef struct mvd_gemm_desc {
   int a_mode;       /* MVD_A_* */
   /* conv geometry (a_mode == MVD_A_CONV3X3) */
   int B, Hin, Win, Cin, Hout, Wout, stride, upsample; /* upsample: input is nearest-2x upsampled before the conv */
+  int no_pad_tl;         /* 1: no zero padding on the top / left edge, i.e. F.pad(x, (0,1,0,1)) + conv(stride 2, padding 0) of
+                            the VAE Downsample (diffusionmodules/model.py:72-76); taps past the bottom / right edge read zeros */
   const void* Wp;   /* packed weight (mvd_pack_*) */
   float acc_scale;  /* accumulator scale = 1 / (pack scale); 0 is treated as 1 */
   int prec;         /* MVD_PREC_* */

@@ -1,15 +1,15 @@
-"""VAE decode executed by HIP kernels -- mirror of ``external.sd1.ldm.models.autoencoder.AutoencoderKL`` (decode side).
+"""VAE encode / decode executed by HIP kernels -- mirror of ``external.sd1.ldm.models.autoencoder.AutoencoderKL``.
 
-SURVEY.md section 8(f) rank 2: ``ViewFusion.decode`` (viewfusion_zero_depth_rgb.py:161-163) is the caller right after the
-sampling loop; ``demo.py:92-94`` runs it three times per scene.  Classes keep the reference's names and state_dict keys:
+SURVEY.md section 8(f) ranks 2-3: ``ViewFusion.decode`` (viewfusion_zero_depth_rgb.py:161-163) is the caller right after the
+sampling loop (``demo.py:92-94`` runs it three times per scene); ``ViewFusion.encode`` (:158-159) feeds it in
+``prepare_batch`` (:204-205).  Classes keep the reference's names and state_dict keys:
 
-  ``ResnetBlock`` / ``AttnBlock`` / ``Upsample``  external/sd1/ldm/modules/diffusionmodules/model.py:42-57,82-141,150-205
-  ``Decoder``                                     model.py:462-577
-  ``AutoencoderKL.decode``                        external/sd1/ldm/models/autoencoder.py:331-334
+  ``ResnetBlock`` / ``AttnBlock`` / ``Upsample`` / ``Downsample``  external/sd1/ldm/modules/diffusionmodules/model.py:42-141,150-205
+  ``Encoder`` / ``Decoder``                                         model.py:368-459, 462-577
+  ``AutoencoderKL.encode / .decode``                                external/sd1/ldm/models/autoencoder.py:325-334
 
-so ``load_state_dict(ckpt, strict=False)`` of a reference VAE checkpoint fills ``decoder.*`` and ``post_quant_conv.*``
-(the encoder half, ``encoder.*`` / ``quant_conv.*``, is section 8(f) rank 3 and not built here: ``encode`` needs an injected
-module).  Everything runs through the same C ABI as the denoiser: implicit-GEMM 3x3 convs (nearest-2x upsample fused
+so ``load_state_dict`` of a reference VAE checkpoint fills every parameter (``encoder.*``, ``decoder.*``, ``quant_conv.*``,
+``post_quant_conv.*``).  Everything runs through the same C ABI as the denoiser: implicit-GEMM 3x3 convs (nearest-2x upsample fused
 into the address generator), GroupNorm(+SiLU) producing the GEMM operand directly, and the single 512-wide attention head of
 the mid block as two GEMMs around ``mvd_softmax_rows``.  Activations are fp32 channels-last (B*H*W, C).
 """
@@ -189,21 +189,117 @@ class Decoder(nn.Module):
         return out, H, W
 
 
+class Downsample(nn.Module):
+    """F.pad(x, (0,1,0,1)) + conv3x3 stride 2 padding 0 (model.py:60-79): the implicit GEMM reads the taps at 2*o + k with no
+    top/left padding; taps past the bottom/right edge are the zero padding."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+        self._p = None
+
+    def run(self, ctx, x, B, H, W):
+        C = self.conv.in_channels
+        if self._p is None:
+            self._p = hip.pack_conv3x3(self.conv.weight, self.conv.bias)
+        xp = hip.split_planes(x, ctx.ws.planes("vae.down.x", B * H * W, C))
+        Ho, Wo = H // 2, W // 2
+        out = ctx.act((B * Ho * Wo, C))
+        ctx.gemm(xp, self._p, out, conv=dict(B=B, Hin=H, Win=W, Cin=C, Hout=Ho, Wout=Wo, stride=2, upsample=0, no_pad_tl=1))
+        return out
+
+
+class Encoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, use_linear_attn=False,
+                 attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        assert not use_linear_attn and attn_type == "vanilla" and len(attn_resolutions) == 0
+        self.ch, self.num_resolutions, self.num_res_blocks, self.in_channels = ch, len(ch_mult), num_res_blocks, in_channels
+        self.conv_in = nn.Conv2d(in_channels, ch, kernel_size=3, stride=1, padding=1)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block = nn.ModuleList()
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, dropout=dropout))
+                block_in = block_out
+            down = nn.Module()
+            down.block = block
+            down.attn = nn.ModuleList()
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.out_channels = 2 * z_channels if double_z else z_channels
+        self.conv_out = nn.Conv2d(block_in, self.out_channels, kernel_size=3, stride=1, padding=1)
+        self._p = None
+
+    def run(self, ctx, xp, B, R):
+        """xp: split planes (B*R*R, 2*32) of the channels-last image (channels >= 3 zero) -> split planes (B*r*r, 2*32) of the
+        conv_out output (r = R / 2^(levels-1)), i.e. the quant_conv operand."""
+        if self._p is None:
+            self._p = (hip.pack_conv3x3(self.conv_in.weight, self.conv_in.bias),
+                       hip.pack_conv3x3(self.conv_out.weight, self.conv_out.bias))
+        w_in, w_out = self._p
+        H = W = R
+        h = ctx.act((B * H * W, self.ch))
+        ctx.gemm(xp, w_in, h, conv=dict(B=B, Hin=H, Win=W, Cin=w_in.conv_cin, Hout=H, Wout=W, stride=1, upsample=0))
+        for i_level in range(self.num_resolutions):
+            for blk in self.down[i_level].block:
+                h = blk.run(ctx, h, B, H, W)
+            if i_level != self.num_resolutions - 1:
+                h = self.down[i_level].downsample.run(ctx, h, B, H, W)
+                H, W = H // 2, W // 2
+        h = self.mid.block_1.run(ctx, h, B, H, W)
+        h = self.mid.attn_1.run(ctx, h, B, H, W)
+        h = self.mid.block_2.run(ctx, h, B, H, W)
+        C = self.norm_out.num_channels
+        a = ctx.ws.planes("vae.enc.a", B * H * W, C)
+        ctx.groupnorm(h, a, self.norm_out, B, H * W, C, silu=True)
+        mo = ctx.ws.get("vae.enc.mo", (B * H * W, 2 * 32), torch.int16, zero=True)     # columns >= out_channels stay zero
+        ctx.gemm(a, w_out, None, out_planes=mo, conv=dict(B=B, Hin=H, Win=W, Cin=C, Hout=H, Wout=W, stride=1, upsample=0))
+        return mo, H, W
+
+
+class DiagonalGaussianDistribution:
+    """external/sd1/ldm/modules/distributions/distributions.py:24-62 (the part the path uses)."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std, self.var = torch.exp(0.5 * self.logvar), torch.exp(self.logvar)
+
+    def sample(self):
+        return self.mean + self.std * torch.randn(self.mean.shape).to(device=self.parameters.device)
+
+    def mode(self):
+        return self.mean
+
+
 class AutoencoderKL(nn.Module):
     """``decode`` on the HIP path; constructor signature of the reference (autoencoder.py:287-296)."""
 
     def __init__(self, ddconfig, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=(), image_key="image",
-                 colorize_nlabels=None, monitor=None, encoder=None, precision="f16x4"):
+                 colorize_nlabels=None, monitor=None, precision="f16x4"):
         super().__init__()
         assert ddconfig["double_z"]
         self.image_key, self.embed_dim = image_key, embed_dim
+        self.encoder = Encoder(**ddconfig)
         self.decoder = Decoder(**ddconfig)
+        self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
-        if encoder is not None:          # host module providing .encode(x) (section 8(f) rank 3, not part of this path)
-            self.encoder_module = encoder
         hip.set_operand_format("bf16" if precision.startswith("bf16") else "f16")
         self.precision = {"x3": hip.PREC_BF16X3, "x4": hip.PREC_X4}.get(precision[-2:], hip.PREC_BF16)
-        self._ctx, self._pq, self._tuned = None, None, set()
+        self._ctx, self._pq, self._q, self._tuned = None, None, None, set()
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
 
@@ -212,11 +308,35 @@ class AutoencoderKL(nn.Module):
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
         self.load_state_dict(sd, strict=False)
 
+    def _context(self, device):
+        if self._ctx is None:
+            self._ctx = Ctx(device, self.precision)
+            self._pq = hip.pack_linear(self.post_quant_conv.weight, self.post_quant_conv.bias)
+            self._q = hip.pack_linear(self.quant_conv.weight, self.quant_conv.bias)
+        return self._ctx
+
+    @torch.no_grad()
     def encode(self, x):
-        if not hasattr(self, "encoder_module"):
-            raise NotImplementedError("AutoencoderKL.encode: the encoder half is not on the HIP path yet; pass encoder=<module "
-                                      "with .encode(x)> (e.g. the reference VAE on PyTorch-ROCm)")
-        return self.encoder_module.encode(x)
+        """x (B, 3, R, R) fp32 in [-1, 1] on the GPU -> DiagonalGaussianDistribution over (B, 4, R/8, R/8) latents
+        (autoencoder.py:325-329)."""
+        if not x.is_cuda:
+            raise RuntimeError("AutoencoderKL.encode runs on the HIP path only (no CPU fallback)")
+        B, Cx, R, _ = x.shape
+        ctx = self._context(x.device)
+        xin = ctx.ws.get("vae.x", (B * R * R, 32), zero=True)
+        xin[:, :Cx] = x.permute(0, 2, 3, 1).reshape(B * R * R, Cx)
+        xp = hip.split_planes(xin, ctx.ws.planes("vae.xp", B * R * R, 32))
+        first = ("enc", B, R) not in self._tuned
+        hip.AUTOTUNE = first
+        try:
+            mo, H, W = self.encoder.run(ctx, xp, B, R)
+            C2 = self.quant_conv.out_channels
+            moments = ctx.ws.get("vae.moments", (B * H * W, 8 if C2 <= 8 else C2))
+            ctx.gemm(mo, self._q, moments, ldo=moments.shape[1])
+        finally:
+            hip.AUTOTUNE = False
+        self._tuned.add(("enc", B, R))
+        return DiagonalGaussianDistribution(moments[:, :C2].reshape(B, H, W, C2).permute(0, 3, 1, 2).contiguous())
 
     @torch.no_grad()
     def decode(self, z):
@@ -224,10 +344,7 @@ class AutoencoderKL(nn.Module):
         if not z.is_cuda:
             raise RuntimeError("AutoencoderKL.decode runs on the HIP path only (no CPU fallback)")
         B, Cz, S, _ = z.shape
-        if self._ctx is None:
-            self._ctx = Ctx(z.device, self.precision)
-            self._pq = hip.pack_linear(self.post_quant_conv.weight, self.post_quant_conv.bias)
-        ctx = self._ctx
+        ctx = self._context(z.device)
         zin = ctx.ws.get("vae.z", (B * S * S, 32), zero=True)
         zin[:, :Cz] = z.permute(0, 2, 3, 1).reshape(B * S * S, Cz)
         zp = hip.split_planes(zin, ctx.ws.planes("vae.zp", B * S * S, 32))

@@ -226,8 +226,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
           iy = uy >> 1;
           ix = ux >> 1;
         } else {
-          iy = oy * d.stride + ky - 1;
-          ix = ox * d.stride + kx - 1;
+          iy = oy * d.stride + ky - (d.no_pad_tl ? 0 : 1);
+          ix = ox * d.stride + kx - (d.no_pad_tl ? 0 : 1);
           ok = iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
         }
         if (ok) off = ((b * d.Hin + iy) * d.Win + ix) * 2 * d.Cin;

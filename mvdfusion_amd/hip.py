@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
     _fields_ = [
         ("M", _i), ("N", _i), ("K", _i),
         ("A", _vp), ("lda", _i), ("a_mode", _i),
-        ("B", _i), ("Hin", _i), ("Win", _i), ("Cin", _i), ("Hout", _i), ("Wout", _i), ("stride", _i), ("upsample", _i),
+        ("B", _i), ("Hin", _i), ("Win", _i), ("Cin", _i), ("Hout", _i), ("Wout", _i), ("stride", _i), ("upsample", _i), ("no_pad_tl", _i),
         ("Wp", _vp), ("acc_scale", _f), ("prec", _i),
         ("epi", _i), ("act", _i), ("out", _vp), ("ldo", _i), ("out_sp", _vp), ("ldp", _i),
         ("n_store", _i),
@@ -234,6 +234,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.a_mode = A_CONV3X3
         for k in ("B", "Hin", "Win", "Cin", "Hout", "Wout", "stride", "upsample"):
             setattr(d, k, int(conv[k]))
+        d.no_pad_tl = int(conv.get("no_pad_tl", 0))
         d.M = conv["B"] * conv["Hout"] * conv["Wout"]
         assert conv["Cin"] * 9 == W.K, (conv["Cin"], W.K)
     else:
@@ -270,7 +271,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     if workspace is not None:
         d.workspace = workspace.data_ptr()
         d.workspace_elems = workspace.numel()
-    key = (d.M, d.N, d.K, d.a_mode, d.Cin, d.stride, d.upsample, d.epi, d.prec, res is not None, out is not None,
+    key = (d.M, d.N, d.K, d.a_mode, d.Cin, d.stride, d.upsample, d.no_pad_tl, d.epi, d.prec, res is not None, out is not None,
            out_planes is not None, splitk)
     if cfg is None:
         cfg = _TUNED.get(key)

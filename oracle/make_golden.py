@@ -410,6 +410,35 @@ def gold_vae_decode(ch, B, zs, tag, full=True):
         save(tag, z=z, raw_strided=raw[:, :, ::7, ::5].contiguous(), raw_std=raw.std(), raw_l2=raw.norm(),
              image_view0_sub=ref[0, :, ::4, ::4].contiguous(), spec=spec)
 
+
+def gold_vae_encode(ch, B, res, tag, full=True):
+    """The REAL AutoencoderKL.encode(normalize(x)).mode() * 0.18215 (ViewFusion.encode) on seeded images in [0,1]."""
+    from external.sd1.ldm.models.autoencoder import AutoencoderKL
+    from utils.common_utils import normalize
+    dd = dict(VAE_DDCONFIG)
+    dd["ch"] = ch
+    vae = AutoencoderKL(ddconfig=dd, lossconfig=dict(target="torch.nn.Identity"), embed_dim=4)
+    fill_ref(vae, "vae.")
+    vae.eval()
+    sd = {k: v for k, v in sd_of(vae, "vae.").items() if ".decoder." not in k and not k.startswith("vae.post_quant_conv")}
+    g = torch.Generator().manual_seed(800 + ch + res)
+    x = torch.rand(B, 3, res, res, generator=g) * 1.2 - 0.1            # a few values outside [0,1]: normalize() clips them
+    t0 = time.time()
+    with torch.no_grad():
+        post = vae.encode(normalize(x))
+        ref = post.mode() * 0.18215                                    # viewfusion_zero_depth_rgb.py:158-159
+    dt = time.time() - t0
+    with torch.no_grad():
+        mine = O.viewfusion_encode(sd, x, ch=ch)
+    e = rel_err(mine, ref)
+    print(f"  vae encode ch={ch} res={res}: ref {dt:.1f}s, oracle vs reference rel-max {e:.2e}; latent std {float(ref.std()):.4f}")
+    assert e < 2e-6, e
+    spec = json.dumps([[k, list(v.shape)] for k, v in sd.items()])
+    if full:
+        save(tag, x=x, z=ref, logvar=post.logvar, spec=spec)
+    else:
+        save(tag, x_seed=np.int64(800 + ch + res), z=ref, spec=spec)
+
 ALL = {
     "schedule": gold_schedule,
     "cameras": gold_cameras,
@@ -429,6 +458,9 @@ ALL = {
     "vae32": lambda: gold_vae_decode(32, 2, 8, "vae_dec_ch32_z8"),
     "vae128": lambda: gold_vae_decode(128, 2, 8, "vae_dec_ch128_z8"),
     "vae128_z32": lambda: gold_vae_decode(128, 1, 32, "vae_dec_ch128_z32", full=False),
+    "vaeenc32": lambda: gold_vae_encode(32, 2, 64, "vae_enc_ch32_r64"),
+    "vaeenc128": lambda: gold_vae_encode(128, 2, 64, "vae_enc_ch128_r64"),
+    "vaeenc128_r256": lambda: gold_vae_encode(128, 1, 256, "vae_enc_ch128_r256", full=False),
 }
 
 if __name__ == "__main__":

@@ -521,3 +521,46 @@ def vae_decode(sd, pre, z, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
 def viewfusion_decode(sd, z, z_scale_factor=0.18215, **kw):
     """ViewFusion.decode viewfusion_zero_depth_rgb.py:161-163: unnormalize(vae.decode(z / scale)).clip(0, 1)."""
     return ((vae_decode(sd, "vae.", z * 1 / z_scale_factor, **kw) + 1.0) / 2.0).clip(0.0, 1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# VAE encode (SURVEY.md section 8(f) rank 3, the VAE half): autoencoder.py:325-329, model.py:60-79,368-459
+# ---------------------------------------------------------------------------------------------
+
+
+def vae_encoder_layout(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
+    """[(level, [(block index, cin, cout)], has_downsample)] in execution order (Encoder.__init__ model.py:391-412)."""
+    in_mult = (1,) + tuple(ch_mult)
+    out = []
+    for lvl in range(len(ch_mult)):
+        cin, blocks = ch * in_mult[lvl], []
+        for i in range(num_res_blocks):
+            blocks.append((i, cin, ch * ch_mult[lvl]))
+            cin = ch * ch_mult[lvl]
+        out.append((lvl, blocks, lvl != len(ch_mult) - 1))
+    return out
+
+
+def vae_encode_moments(sd, pre, x, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
+    """Encoder.forward model.py:434-459 + quant_conv (autoencoder.py:326-327): (B,3,H,W) in [-1,1] -> moments (B,8,H/8,W/8).
+    Downsample = F.pad(x, (0,1,0,1)) + conv3x3 stride 2 padding 0 (model.py:72-76)."""
+    e = pre + "encoder."
+    h = _conv(sd, e + "conv_in", x)
+    for lvl, blocks, down in vae_encoder_layout(ch, ch_mult, num_res_blocks):
+        for i, _, _ in blocks:
+            h = _vae_resnet(sd, f"{e}down.{lvl}.block.{i}.", h)
+        if down:
+            h = _conv(sd, f"{e}down.{lvl}.downsample.conv", F.pad(h, (0, 1, 0, 1), mode="constant", value=0), stride=2, padding=0)
+    h = _vae_resnet(sd, e + "mid.block_1.", h)
+    h = _vae_attn(sd, e + "mid.attn_1.", h)
+    h = _vae_resnet(sd, e + "mid.block_2.", h)
+    h = _conv(sd, e + "conv_out", _swish(_vae_norm(sd, e + "norm_out", h)))
+    return _conv(sd, pre + "quant_conv", h, padding=0)
+
+
+def viewfusion_encode(sd, images, z_scale_factor=0.18215, **kw):
+    """ViewFusion.encode viewfusion_zero_depth_rgb.py:158-159: vae.encode(normalize(x)).mode() * scale, with
+    normalize = clip(2x-1, -1, 1) (utils/common_utils.py:60-64) and mode() = the mean half of the moments
+    (distributions.py:27,61-62)."""
+    m = vae_encode_moments(sd, "vae.", torch.clip(images * 2 - 1.0, -1.0, 1.0), **kw)
+    return torch.chunk(m, 2, dim=1)[0] * z_scale_factor

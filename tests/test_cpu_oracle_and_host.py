@@ -234,23 +234,32 @@ def test_oracle_vae_decode_vs_reference(name, ch):
     assert float(img.min()) == 0.0 and float(img.max()) == 1.0          # the clip is exercised
 
 
+@pytest.mark.parametrize("name,ch", [("vae_enc_ch32_r64", 32), ("vae_enc_ch128_r64", 128)])
+def test_oracle_vae_encode_vs_reference(name, ch):
+    import json
+    gd = load_golden(name)
+    sd = syn.det_fill_state_dict(json.loads(str(gd["spec"])))
+    with torch.no_grad():
+        z = O.viewfusion_encode(sd, gd["x"], ch=ch)
+    assert rel_err(z, gd["z"]) < 2e-5
+
+
 def test_vae_mirror_keys_and_guards():
-    """The HIP decode mirror exposes exactly the reference's decoder / post_quant_conv keys, is what the yaml target
-    resolves to, and has no CPU path."""
+    """The HIP VAE mirror exposes exactly the reference's keys, is what the yaml target resolves to, and has no CPU path."""
     import json
     from mvdfusion_amd.autoencoder import AutoencoderKL
     from mvdfusion_amd.load_model import get_obj_from_str
     assert get_obj_from_str("external.sd1.ldm.models.autoencoder.AutoencoderKL") is AutoencoderKL
-    spec = json.loads(str(load_golden("vae_dec_ch128_z8")["spec"]))
+    spec = json.loads(str(load_golden("vae_dec_ch128_z8")["spec"])) + json.loads(str(load_golden("vae_enc_ch128_r64")["spec"]))
     dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
               num_res_blocks=2, attn_resolutions=[], dropout=0.0)
     vae = AutoencoderKL(ddconfig=dd, lossconfig=dict(target="torch.nn.Identity"), embed_dim=4, monitor="val/rec_loss")
     mine = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
     ref = {k[len("vae."):]: tuple(s) for k, s in spec}
-    assert mine == ref and len(ref) == 140
+    assert mine == ref and len(ref) == 248           # encoder.*, quant_conv.*, decoder.*, post_quant_conv.*
     with pytest.raises(RuntimeError):
         vae.decode(torch.zeros(1, 4, 8, 8))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):
         vae.encode(torch.zeros(1, 3, 64, 64))
 
 

@@ -14,7 +14,7 @@ from conftest import load_golden, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _vae(ch, spec):
+def _vae(ch, spec=None):
     from mvdfusion_amd import synthetic as syn
     from mvdfusion_amd.load_model import instantiate_from_config
     dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=ch, ch_mult=[1, 2, 4, 4],
@@ -22,8 +22,10 @@ def _vae(ch, spec):
     vae = instantiate_from_config(dict(target="external.sd1.ldm.models.autoencoder.AutoencoderKL",       # the yaml's own target
                                        params=dict(embed_dim=4, monitor="val/rec_loss", ddconfig=dd,
                                                    lossconfig=dict(target="torch.nn.Identity"))))
-    sd = {k[len("vae."):]: v for k, v in syn.det_fill_state_dict(spec).items()}
-    vae.load_state_dict(sd, strict=True)      # every decoder / post_quant_conv key of the reference, nothing else
+    syn.fill_module_(vae, "vae.")             # the same name-keyed fill the goldens were generated with
+    if spec is not None:                      # the golden's key list is a subset of ours with identical shapes
+        mine = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+        assert all(mine[k[len("vae."):]] == tuple(shp) for k, shp in spec)
     return vae.cuda().eval()
 
 
@@ -70,9 +72,43 @@ def test_viewfusion_decode_uses_the_hip_vae():
                              params=dict(embed_dim=4, ddconfig=dd, lossconfig=dict(target="torch.nn.Identity")))
     m = ViewFusion(**cfg)
     assert isinstance(m.vae, AutoencoderKL)
-    m.vae.load_state_dict({k[len("vae."):]: v for k, v in syn.det_fill_state_dict(json.loads(str(gd["spec"]))).items()})
+    syn.fill_module_(m.vae, "vae.")
     m = m.cuda().eval()
     img = m.decode(gd["z"].cuda()).cpu()
     assert float((img - gd["image"]).abs().max()) < 1e-3
-    with pytest.raises(NotImplementedError):
-        m.vae.encode(torch.zeros(1, 3, 64, 64))
+    ge = load_golden("vae_enc_ch32_r64")
+    z = m.encode(ge["x"].cuda()).cpu()                    # ViewFusion.encode: normalize -> vae.encode -> mode * 0.18215
+    assert rel_err(z, ge["z"]) < 2e-4
+
+
+@pytest.mark.parametrize("name,ch", [("vae_enc_ch32_r64", 32), ("vae_enc_ch128_r64", 128)])
+def test_vae_encode_vs_reference_golden(name, ch):
+    gd = load_golden(name)
+    vae = _vae(ch, json.loads(str(gd["spec"])))
+    post = vae.encode(torch.clip(gd["x"] * 2 - 1.0, -1.0, 1.0).cuda())
+    z = (post.mode() * 0.18215).cpu()
+    e = rel_err(z, gd["z"])
+    print(f"{name}: latent rel-max err {e:.2e}")
+    assert z.shape == gd["z"].shape and e < 2e-4, e
+    assert rel_err(post.logvar.cpu(), gd["logvar"]) < 2e-4
+    assert post.sample().shape == z.shape
+
+
+def test_vae_encode_full_size_image():
+    """One 256x256 image at full encoder width (the prepare_batch shape) -> (1, 4, 32, 32)."""
+    gd = load_golden("vae_enc_ch128_r256")
+    vae = _vae(128, json.loads(str(gd["spec"])))
+    g = torch.Generator().manual_seed(int(gd["x_seed"]))
+    x = torch.rand(1, 3, 256, 256, generator=g) * 1.2 - 0.1
+    z = (vae.encode(torch.clip(x * 2 - 1.0, -1.0, 1.0).cuda()).mode() * 0.18215).cpu()
+    assert z.shape == (1, 4, 32, 32) and rel_err(z, gd["z"]) < 2e-4
+
+
+def test_vae_roundtrip_shapes_and_determinism():
+    vae = _vae(32)
+    x = torch.rand(3, 3, 128, 128, generator=torch.Generator().manual_seed(5)).cuda() * 2 - 1
+    z1 = vae.encode(x).mode()
+    z2 = vae.encode(x).mode()
+    assert torch.equal(z1, z2) and z1.shape == (3, 4, 16, 16)
+    y = vae.decode(z1)
+    assert y.shape == (3, 3, 128, 128) and bool(torch.isfinite(y).all())
