@@ -123,3 +123,16 @@ def step_noise(V, S, D, num_steps, seed=0):
         depth.append(torch.randn(V, D, S, S, generator=g))
         ddim.append(torch.randn(V, 5, S, S, generator=g) if i < num_steps - 1 else torch.zeros(V, 5, S, S))
     return torch.stack(depth), torch.stack(ddim)
+
+
+class StubClipImageEncoder(torch.nn.Module):
+    """Deterministic stand-in for FrozenCLIPImageEmbedder (encoders/modules.py:402-441) in prepare_batch parity tests: the
+    per-channel image mean through a fixed name-keyed 3x768 map -> (n, 1, 768).  CLIP weights are not available offline and
+    CLIP is not on the HIP path; the stub only has to be the SAME function on the reference side and on this side."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("proj", det_fill("stub_clip.proj.weight", (3, 768)) * math.sqrt(3.0), persistent=False)
+
+    def encode(self, x):
+        return (x.float().mean((2, 3)) @ self.proj.to(x.device))[:, None, :]

@@ -439,6 +439,43 @@ def gold_vae_encode(ch, B, res, tag, full=True):
     else:
         save(tag, x_seed=np.int64(800 + ch + res), z=ref, spec=spec)
 
+
+def gold_prepare_batch(tag, random_views, with_depths, seed):
+    """The REAL ViewFusion.prepare_batch (viewfusion_zero_depth_rgb.py:165-273) on a 16-view GSO-rig batch of seeded 64x64
+    images, with the reference VAE (ch=32, name-keyed fill) and the stub CLIP encoder on both sides."""
+    import torch.nn as nn
+    from external.sd1.ldm.models.autoencoder import AutoencoderKL
+    from mvdfusion.viewfusion_zero_depth_rgb import ViewFusion
+
+    class Facade(nn.Module):
+        prepare_batch = ViewFusion.prepare_batch
+        encode = ViewFusion.encode
+        encode_clip = ViewFusion.encode_clip
+
+        def __init__(self):
+            super().__init__()
+            dd = dict(VAE_DDCONFIG)
+            dd["ch"] = 32
+            self.vae = AutoencoderKL(ddconfig=dd, lossconfig=dict(target="torch.nn.Identity"), embed_dim=4)
+            fill_ref(self.vae, "vae.")
+            self.clip_image_encoder = syn.StubClipImageEncoder()
+            self.z_scale_factor, self.embed_camera_pose = 0.18215, True
+
+    m = Facade().eval()
+    rig = syn.gso_rig()
+    g = torch.Generator().manual_seed(seed)
+    batch = dict(images=torch.rand(16, 3, 64, 64, generator=g), R=rig.R, T=rig.T, f=rig.focal_length, c=rig.principal_point)
+    if with_depths:
+        batch["depths"] = torch.rand(16, 1, 64, 64, generator=g)
+    cfg = dict(input_batch_size=1, train_batch_size=4, random_views=random_views)
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        bl, bc, il, ic, cv = m.prepare_batch(batch, cfg, generator=gen)
+    print(f"  prepare_batch random_views={random_views} depths={with_depths}: batch_latents {tuple(bl.shape)} std {float(bl.std()):.3f}, "
+          f"clip_v_embed {tuple(cv.shape)}")
+    save(tag, seed=np.int64(seed), batch_latents=bl, input_latents=il, clip_v_embed=cv, bc_R=bc.R, bc_T=bc.T,
+         bc_f=bc.focal_length, bc_p=bc.principal_point, ic_R=ic.R, ic_T=ic.T, ic_f=ic.focal_length, ic_p=ic.principal_point)
+
 ALL = {
     "schedule": gold_schedule,
     "cameras": gold_cameras,
@@ -461,6 +498,8 @@ ALL = {
     "vaeenc32": lambda: gold_vae_encode(32, 2, 64, "vae_enc_ch32_r64"),
     "vaeenc128": lambda: gold_vae_encode(128, 2, 64, "vae_enc_ch128_r64"),
     "vaeenc128_r256": lambda: gold_vae_encode(128, 1, 256, "vae_enc_ch128_r256", full=False),
+    "prep": lambda: gold_prepare_batch("prepare_batch_fixed", False, False, 21),
+    "prep_rand": lambda: gold_prepare_batch("prepare_batch_random_depths", True, True, 22),
 }
 
 if __name__ == "__main__":

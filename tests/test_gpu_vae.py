@@ -112,3 +112,36 @@ def test_vae_roundtrip_shapes_and_determinism():
     assert torch.equal(z1, z2) and z1.shape == (3, 4, 16, 16)
     y = vae.decode(z1)
     assert y.shape == (3, 3, 128, 128) and bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("name,random_views,with_depths", [("prepare_batch_fixed", False, False),
+                                                           ("prepare_batch_random_depths", True, True)])
+def test_prepare_batch_vs_reference_golden(name, random_views, with_depths):
+    """ViewFusion.prepare_batch end to end (view pick, HIP VAE encode x0.18215, depth area-pooling, camera re-basing, camera
+    scalars appended to the CLIP vector) against the REAL reference's prepare_batch (viewfusion_zero_depth_rgb.py:165-273)
+    with the same stub CLIP encoder on both sides (oracle/make_golden.py: prep / prep_rand)."""
+    from conftest import model_config
+    from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
+    gd = load_golden(name)
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    cfg = model_config(32)
+    cfg["vae_config"] = dict(target="external.sd1.ldm.models.autoencoder.AutoencoderKL",
+                             params=dict(embed_dim=4, ddconfig=dd, lossconfig=dict(target="torch.nn.Identity")))
+    m = ViewFusion(clip_image_encoder=syn.StubClipImageEncoder(), **cfg)
+    syn.fill_module_(m.vae, "vae.")
+    m = m.cuda().eval()
+    seed = int(gd["seed"])
+    rig = syn.gso_rig()
+    g = torch.Generator().manual_seed(seed)
+    batch = dict(images=torch.rand(16, 3, 64, 64, generator=g).cuda(), R=rig.R, T=rig.T, f=rig.focal_length, c=rig.principal_point)
+    if with_depths:
+        batch["depths"] = torch.rand(16, 1, 64, 64, generator=g).cuda()
+    tc = dict(input_batch_size=1, train_batch_size=4, random_views=random_views)
+    bl, bc, il, ic, cv = m.prepare_batch(batch, tc, generator=torch.Generator().manual_seed(seed + 1))
+    assert rel_err(bl.cpu(), gd["batch_latents"]) < 2e-4 and rel_err(il.cpu(), gd["input_latents"]) < 2e-4
+    assert rel_err(cv.cpu(), gd["clip_v_embed"]) < 1e-5
+    for mine, ref in ((bc.R, gd["bc_R"]), (bc.T, gd["bc_T"]), (bc.focal_length, gd["bc_f"]), (bc.principal_point, gd["bc_p"]),
+                      (ic.R, gd["ic_R"]), (ic.T, gd["ic_T"]), (ic.focal_length, gd["ic_f"]), (ic.principal_point, gd["ic_p"])):
+        assert mine.shape == ref.shape and float((mine.cpu() - ref).abs().max()) < 1e-5
