@@ -296,7 +296,11 @@ def main():
             torch.cuda.synchronize()
             v1 = a.steps / (time.perf_counter() - t1)
             out["view_parallel"] = {"views": V, "single_gpu_same_workload_steps_per_s": v1,
-                                    "speedup_over_single_gpu": out["value"] / v1}
+                                    "speedup_over_single_gpu": out["value"] / v1,
+                                    "note": "strong scaling over BASELINE configs[2] (V=8 views shared by the N GPUs); the N=1 "
+                                            "default run is configs[1] (V=4), a different workload -- divide by "
+                                            "single_gpu_same_workload_steps_per_s (= `bench.py --views 8` on one GPU), not by "
+                                            "the N=1 headline value, for the scaling efficiency"}
         dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
