@@ -109,7 +109,8 @@ typedef struct mvd_gemm_desc {
   /* MVD_EPI_QKV */
   void *q_hi, *q_lo, *k_hi, *k_lo, *vt_hi, *vt_lo;
   int heads, dhead, L, Lpad; /* rows m = b*L + token */
-  float qscale;              /* dhead^-0.5, applied to q in fp32 before the split */
+  float qscale;              /* dhead^-0.5 * log2(e), applied to q in fp32 before the split: mvd_attention computes its
+                                softmax with exp2 on the raw q.k products */
   /* split-K: 1 = none; >1 = that many K slices; 0 = choose automatically (fills the 256 CUs when the tile grid
    * is small or divides badly over them -- a small time model, gemm.hip: choose_splits).  Partial fp32 slabs
    * (splitk*M*N) go to `workspace`; a second kernel sums them in slice order 0..splitk-1 and applies the
@@ -166,8 +167,9 @@ int mvd_layernorm(const float* x, void* y_sp, const float* w, const float* b, in
 /* ------------------------------------------------------------------------------------------------
  * Self-attention over the tokens of one view (CrossAttention with context=None, attention.py:170-193).
  * Operand planes are written by mvd_gemm(MVD_EPI_QKV):
- *   q/k : [B][heads][Lpad][dq]   bf16, dq  = roundup(dhead, 32), zero padded, q pre-scaled by dhead^-0.5
- *   vt  : [B][heads][dv][Lpad]   bf16, dv  = roundup(dhead, 16)   (V transposed: keys contiguous)
+ *   q/k : [B][heads][Lpad][dq]   16-bit hi/lo planes, dq = roundup(dhead, 32), zero padded, q pre-scaled by
+ *                                dhead^-0.5 * log2(e) (mvd_gemm_desc.qscale): the softmax is evaluated with exp2
+ *   vt  : [B][heads][dv][Lpad]   16-bit hi/lo planes, dv = roundup(dhead, 16)   (V transposed: keys contiguous)
  * out : (B*L, ldo) split planes, head-major channels ('b n (h d)'): feeds the to_out GEMM. */
 size_t mvd_attn_qk_plane_elems(int B, int heads, int L, int dhead);
 size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead);

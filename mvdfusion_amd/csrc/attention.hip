@@ -100,26 +100,30 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
       }
     }
     // ---- online softmax (per query column c; keys are spread over registers and the 4 lane groups)
+    // (q carries dhead^-0.5 * log2(e) from the QKV epilogue, so the scores are base-2 logits: exp2 below is a bare v_exp_f32)
+    if (kv0 + KV_TILE > L) {      // ragged last tile only (uniform branch): keys past L do not take part
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kv0 + kt * 16 + g * 4 + r >= L) s[kt][r] = -INFINITY;
+    }
     float mt = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kv0 + kt * 16 + g * 4 + r;
-        if (key >= L) s[kt][r] = -INFINITY;
-        mt = fmaxf(mt, s[kt][r]);
-      }
+      for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kt][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s[kt][r] = __expf(s[kt][r] - m_new);
+        s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
         psum += s[kt][r];
       }
     l_run = l_run * alpha + psum;

@@ -266,7 +266,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.q_hi, d.q_lo, d.k_hi, d.k_lo, d.vt_hi, d.vt_lo = (t.data_ptr() for t in (qh, ql, kh, kl, vh, vl))
         d.heads, d.dhead, d.L = qkv["heads"], qkv["dhead"], qkv["L"]
         d.Lpad = lib().mvd_attn_lpad(qkv["L"])
-        d.qscale = float(qkv["dhead"]) ** -0.5
+        d.qscale = float(qkv["dhead"]) ** -0.5 * 1.4426950408889634      # * log2(e): mvd_attention works in base 2
     d.splitk = splitk
     if workspace is not None:
         d.workspace = workspace.data_ptr()
