@@ -145,3 +145,31 @@ def test_prepare_batch_vs_reference_golden(name, random_views, with_depths):
     for mine, ref in ((bc.R, gd["bc_R"]), (bc.T, gd["bc_T"]), (bc.focal_length, gd["bc_f"]), (bc.principal_point, gd["bc_p"]),
                       (ic.R, gd["ic_R"]), (ic.T, gd["ic_T"]), (ic.focal_length, gd["ic_f"]), (ic.principal_point, gd["ic_p"])):
         assert mine.shape == ref.shape and float((mine.cpu() - ref).abs().max()) < 1e-5
+
+
+def test_sample_then_decode_end_to_end():
+    """The demo.py flow (demo.py:85-94) on the HIP path end to end at reduced width: batch -> prepare_batch (HIP VAE encode, stub
+    CLIP) -> 50-step DDIM sample with classifier-free guidance (one hipGraph per step) -> decode of the 4 latent channels."""
+    from conftest import model_config
+    from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    cfg = model_config(32)
+    cfg["vae_config"] = dict(target="external.sd1.ldm.models.autoencoder.AutoencoderKL",
+                             params=dict(embed_dim=4, ddconfig=dd, lossconfig=dict(target="torch.nn.Identity")))
+    m = ViewFusion(clip_image_encoder=syn.StubClipImageEncoder(), **cfg)
+    syn.fill_module_(m)
+    m = m.cuda().eval()
+    rig = syn.gso_rig()
+    batch = dict(images=torch.rand(16, 3, 256, 256, generator=torch.Generator().manual_seed(3)).cuda(), R=rig.R, T=rig.T,
+                 f=rig.focal_length, c=rig.principal_point)
+    tc = dict(input_batch_size=1, train_batch_size=4, random_views=False)
+    torch.manual_seed(0)
+    x, batch_latents, input_latents, batch_cameras, inter = m.sample(batch, tc, cfg_scale=2.5, return_input=True, depth=True,
+                                                                     verbose=False)
+    assert x.shape == (4, 5, 32, 32) and batch_latents.shape == (4, 5, 32, 32) and input_latents.shape == (1, 5, 32, 32)
+    assert len(inter) == 50 and len(batch_cameras) == 4 and bool(torch.isfinite(x).all())
+    img = m.decode(x[:, :4])
+    assert img.shape == (4, 3, 256, 256) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+    assert bool(torch.isfinite(img).all())
