@@ -207,7 +207,7 @@ def test_groupnorm_fp16_kept_output(hip):
     got = planes_to_float(yp).view(B, HW, C)
     # a value within an fp32 ulp of an fp16 rounding boundary may round the other way: allow 2^-11 relative on <0.1 % of them
     d = (got - ref).abs()
-    assert float((d > 2e-6 * (1 + ref.abs())).float().mean()) < 1e-3
+    assert float((d > (2e-6 + 2 * PL) * (1 + ref.abs())).float().mean()) < 1e-3        # PL: split-plane representation error
     assert float((d / (1e-3 + ref.abs())).max()) < 2.5e-3      # one flipped fp16 ulp (2^-10 at the bottom of a binade) through the swish
 
 
