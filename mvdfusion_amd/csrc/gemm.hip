@@ -1,19 +1,26 @@
-// GEMM / implicit-GEMM 3x3 convolution on bf16 MFMA (gfx950): both operands arrive as split-bf16 planes and are
-// DMA'd straight into LDS; fused epilogues.  See include/mvd_hip.h (mvd_gemm) for the contract.
+// GEMM / implicit-GEMM 3x3 convolution on 16-bit MFMA (gfx950): both operands arrive as split planes (hi + lo in the
+// MFMA operand type, fp16 by default) and are DMA'd straight into LDS; fused epilogues.  See include/mvd_hip.h (mvd_gemm)
+// for the contract.
 //
 // Operands
-//   A : activations in the "split planes" format (common.hpp): x ~= hi + lo as bf16, per row and 32-element k-block
+//   A : activations in the "split planes" format (common.hpp): x ~= hi + lo, per row and 32-element k-block
 //       [32 hi | 32 lo] = one 128-byte line, written by the PRODUCING kernel (norms, attention, previous GEMM
-//       epilogue, ...) -- same bytes as fp32, no conversion work inside the GEMM.
-//   B : weights packed once at load time into 2 KiB micro-tiles [K/32][N/16][16 n][32 hi | 32 lo].
-// Structure (per workgroup): block tile BM x BN, BK = 32, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile of
-// 16x16x32 MFMAs.  A k-tile of both operands is a set of 1 KiB granules (8 rows x one full 128-byte line each); every
-// wave instruction of `global_load_lds_dwordx4` moves one granule global -> LDS with no VGPR round trip (the LDS
-// destination is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and to the
-// fragment reads: 16-byte chunk cc (0-3 hi, 4-7 lo) of row r of a 16-row block lives at slot (r&7)*8 + (cc ^ (r>>1)),
-// which is conflict-free for the 16-lane ds_read_b128 groups).
-// 2-3 LDS stages: DMA of later k-tiles is in flight while the MFMAs of k-tile t run; rows/columns outside the problem
-// (M/N edges, conv zero padding) source a 16-byte zero page.
+//       epilogue, ...) -- same bytes as fp32, no conversion work inside the GEMM.  Conv: the NHWC image rows; the K order
+//       is (32-channel block, tap, channel) so the nine taps of a pixel line are consecutive k-tiles (L2 hits), and a
+//       per-workgroup LDS table holds the source offset of every (tile row, tap).
+//   B : weights packed once at load time into 2 KiB micro-tiles [K/32][N/16][16 n][32 hi | 32 lo], pre-scaled by a power
+//       of two (acc_scale undoes it).
+// Structure (per workgroup): block tile BM x BN (128x128 / 8 waves or 64x64 / 4 waves), BK = 32, WM x WN waves, each wave a
+// (BM/WM) x (BN/WN) sub-tile of 16x16x32 MFMAs.  A k-tile of both operands is a set of 1 KiB granules (8 rows x one
+// full 128-byte line each); every wave instruction of `global_load_lds_dwordx4` moves one granule global -> LDS with no
+// VGPR round trip (the LDS destination is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
+// address and to the fragment reads: 16-byte chunk cc (0-3 hi, 4-7 lo) of row r of a 16-row block lives at slot
+// (r&7)*8 + (cc ^ (r>>1)), which is conflict-free for the 16-lane ds_read_b128 groups).  Running source pointers: the
+// k loop carries no address arithmetic beyond one add per granule; rows/columns outside the problem (M/N edges, conv
+// zero padding) source a 16-byte zero page.
+// Two LDS buffers and two loop variants (template STAGES): 2 = plain (DMA of k-tile t+1 in flight under the MFMAs of t;
+// two co-resident workgroups per CU hide each other's waits), 3 = register-pipelined (fragments of t+1 read and DMA of
+// t+2 issued under the MFMAs of t).  One `s_waitcnt vmcnt lgkmcnt` + raw `s_barrier` per k-tile.
 // NS = 1: acc += A_hi*B_hi.  NS = 3: acc += A_lo*B_hi + A_hi*B_lo + A_hi*B_hi.  NS = 4: + A_lo*B_lo first (the kernel is
 // operand-delivery bound, not MFMA bound, so the 4th product is almost free and removes the 2^-22 truncation term).
 #include <stdlib.h>
