@@ -6,12 +6,16 @@ the classifier-free-guidance pair of view-conditioned UNet passes (batched as 2V
 one replay of the captured hipGraph (DDIMSampler.sample's loop body, mvdfusion/sampler.py:119-142).
 
   N=1  : BASELINE.json configs[1] -- V=4 views x 256^2 images (32x32 latents), D=1, cfg 2.5, full-width SD1.x UNet.
+         (--views 8 = configs[2]'s workload on one GPU; --views 8 --latent 64 = configs[3].)
   N>1  : BASELINE.json configs[2] -- V=8 views sharded by view over the N ranks (one process per GPU), one RCCL
          all-gather of the updated latent rows per step (mvdfusion_amd/parallel.py).  Total work is fixed => "strong".
+  --shard-emulate r/N : ONE GPU runs the shard rank r of an N-way view-parallel job would run (its Vq query views against
+         all V references) and reports the projected view-parallel speed-up bound t(unsharded) / t(shard).
 
 Weights: deterministic non-zero synthetic fill of the real architecture (no checkpoints offline); data: synthetic GSO rig.
-Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel, HIP-event timed, algorithmic FLOPs against
-the dense bf16 MFMA peak) and `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
+Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel family, HIP-event timed, algorithmic FLOPs
+against the dense 16-bit MFMA peak), `roofline_groups` (attention, GroupNorm, LayerNorm, GridAttn aggregation) and
+`cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
 """
 import argparse
 import json
@@ -26,7 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-MFMA_BF16_DENSE_PEAK = 2.5e15  # FLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (dense; not the 2:1-sparse figure)
+MFMA_16BIT_DENSE_PEAK = 2.5e15  # FLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (dense; not the 2:1-sparse figure)
+HBM_PEAK = 8.0e12               # B/s (spec; ~6.3 TB/s achievable), same guide
+ROUND = "r02"
 
 
 def log(*a):
@@ -63,77 +69,115 @@ def prepare(m, V, S, D, cfg_scale, q0=0, Vq=None, seed=0):
 
 def run_steps(eng, n, cfg_scale, exchange=None, use_graph=True):
     """n DDIM iterations (wrapping to a fresh sample every 50)."""
-    done = int(eng.iter.item())
     for _ in range(n):
-        if done == 50:
-            eng.iter.zero_()
-            done = 0
+        if eng.done == eng.n_rows:
+            eng.rewind()
         eng.step(cfg_scale, do_update=True, use_graph=use_graph)
         if exchange is not None:
             exchange.gather(eng.x)
-        done += 1
 
 
-def profile_gemm_kernels(eng, cfg_scale):
-    """One eager (non-graph) step with HIP events around every mvd_gemm launch on the launch stream."""
+def profile_kernel_groups(m, eng, cfg_scale):
+    """One eager (non-graph) step with HIP events on the launch stream around every mvd_gemm launch and around the other
+    kernel groups (attention, GroupNorm, LayerNorm, the whole GridAttn block)."""
     from mvdfusion_amd import hip
-    recs = []
-    real = hip.gemm
+    from mvdfusion_amd.view_attn_efficient2 import GridAttn
+    recs, groups = [], {"attention": [], "groupnorm": [], "layernorm": [], "gridattn": []}
+    real = dict(gemm=hip.gemm, attention=hip.attention, groupnorm=hip.groupnorm, layernorm=hip.layernorm, ga=GridAttn.run)
 
-    def timed(A, W, out=None, **kw):
-        e0, e1 = hip.Event(), hip.Event()
+    def ev_pair():
+        return hip.Event(), hip.Event()
+
+    def timed_gemm(A, W, out=None, **kw):
+        e0, e1 = ev_pair()
         e0.record()
-        r = real(A, W, out, **kw)
+        r = real["gemm"](A, W, out, **kw)
         e1.record()
         conv = kw.get("conv")
         M = conv["B"] * conv["Hout"] * conv["Wout"] if conv else int(kw.get("M") or A.numel() // A.shape[-1])
-        N = W.n_real
-        Kp = W.K
-        c = (hip.LAST_CFG - 1) % 4 + 1 if hip.LAST_CFG else 0     # tuned kernel configuration of this call
-        bm = {0: "auto", 1: 64, 2: 64, 3: 128, 4: 128}[c]
-        st = {0: "auto", 1: 3, 2: 2, 3: 2, 4: 3}[c]      # 2 = plain two-buffer loop, 3 = register-pipelined loop
-        tiles = -(-M // (bm if c else 64)) * -(-W.N // (bm if c else 64))
-        split = kw.get("splitk", 0) == 0 and tiles <= 96 and Kp // 32 >= 64
-        # template args: <BM, BN, WM, WN, NS, AMODE, STAGES> as in csrc/gemm.hip
-        wmn = "2, 4" if bm == 128 else "2, 2"
+        N, Kp = W.n_real, W.K
         rows_in = conv["B"] * conv["Hin"] * conv["Win"] if conv else M
         k_in = conv["Cin"] if conv else Kp
         n_out = 4.0 * M * N * ((out is not None) + (kw.get("out_planes") is not None) + (kw.get("res") is not None)) \
             + (4.0 * M * N if kw.get("qkv") else 0.0)
         abytes = 4.0 * rows_in * k_in + 4.0 * W.N * Kp + n_out      # A planes + packed W (hi+lo = 4 B/elem) + outputs / residual
-        recs.append(dict(sym=f"gemm_kernel<{bm}, {bm}, {wmn}, {kw.get('prec', 3)}, {1 if conv else 0}, {st}>", M=M, N=N,
-                         K=Kp, flops=2.0 * M * N * Kp, bytes=abytes, split=split, ev=(e0, e1)))
+        recs.append(dict(sym=hip.kernel_symbol(hip.LAST_CFG, kw.get("prec", 4), bool(conv)), M=M, N=N, K=Kp,
+                         flops=2.0 * M * N * Kp, bytes=abytes, ev=(e0, e1)))
         return r
 
-    hip.gemm = timed
+    def timed_attention(planes, out, B, heads, L, dhead, prec=hip.PREC_X4):
+        e0, e1 = ev_pair()
+        e0.record()
+        r = real["attention"](planes, out, B, heads, L, dhead, prec=prec)
+        e1.record()
+        groups["attention"].append(dict(flops=4.0 * B * heads * L * L * dhead, bytes=0.0, ev=(e0, e1)))
+        return r
+
+    def timed_groupnorm(x, y, gamma, beta, B, HW, Cc, eps, silu, ws):
+        e0, e1 = ev_pair()
+        e0.record()
+        r = real["groupnorm"](x, y, gamma, beta, B, HW, Cc, eps, silu, ws)
+        e1.record()
+        groups["groupnorm"].append(dict(flops=0.0, bytes=12.0 * B * HW * Cc, ev=(e0, e1)))   # read x twice, write planes
+        return r
+
+    def timed_layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False):
+        e0, e1 = ev_pair()
+        e0.record()
+        r = real["layernorm"](x, y, w, b, rows, Cc, eps, w_plus_one)
+        e1.record()
+        groups["layernorm"].append(dict(flops=0.0, bytes=8.0 * rows * Cc, ev=(e0, e1)))
+        return r
+
+    def timed_ga(self, ctx, x, *a, **kw):
+        e0, e1 = ev_pair()
+        e0.record()
+        r = real["ga"](self, ctx, x, *a, **kw)
+        e1.record()
+        V, S, D = a[8], a[9], a[10]
+        Vq = kw.get("Vq") or V
+        T = Vq * S * S * D * V
+        # SURVEY.md section 8(d): the aggregation tail (723->256, 3 DiT blocks over V, pool, 256->768) per token
+        groups["gridattn"].append(dict(flops=T * (3516416.0 + 3072.0 * V), bytes=0.0, ev=(e0, e1)))
+        return r
+
+    hip.gemm, hip.attention, hip.groupnorm, hip.layernorm, GridAttn.run = timed_gemm, timed_attention, timed_groupnorm, \
+        timed_layernorm, timed_ga
     try:
-        it = eng.iter.clone()
-        x = eng.x.clone()
+        it, x = eng.done, eng.x.clone()
+        if it == eng.n_rows:
+            it = 0
+        eng.rewind(it)
         eng.step(cfg_scale, do_update=True, use_graph=False)
         torch.cuda.synchronize()
-        eng.iter.copy_(it)
+        eng.rewind(it)
         eng.x.copy_(x)
     finally:
-        hip.gemm = real
+        hip.gemm, hip.attention, hip.groupnorm, hip.layernorm, GridAttn.run = real["gemm"], real["attention"], \
+            real["groupnorm"], real["layernorm"], real["ga"]
     by = {}
     for r in recs:
         ms = r["ev"][0].elapsed_ms(r["ev"][1])
-        b = by.setdefault(r["sym"], dict(n=0, ms=0.0, flops=0.0, bytes=0.0, n_split=0))
+        b = by.setdefault(r["sym"], dict(n=0, ms=0.0, flops=0.0, bytes=0.0))
         b["n"] += 1
         b["ms"] += ms
         b["flops"] += r["flops"]
         b["bytes"] += r["bytes"]
-        b["n_split"] += int(r["split"])
-    return by
+    gsum = {}
+    for k, lst in groups.items():
+        ms = sum(r["ev"][0].elapsed_ms(r["ev"][1]) for r in lst)
+        gsum[k] = dict(n=len(lst), ms=ms, flops=sum(r["flops"] for r in lst), bytes=sum(r["bytes"] for r in lst))
+    return by, gsum
 
 
-def cpu_baseline(sd, V, S, D, cfg_scale, n_timed=1):
+def cpu_baseline(sd, V, S, D, cfg_scale, n_timed=3, threads=16):
     """The CPU oracle (port of the reference path, pinned to it by tests/golden) on this host's cores."""
     from mvdfusion_amd import synthetic as syn
     from oracle import ref_torch as O
     # PyTorch eager on "all host cores" collapses on a 256-core box (415 s/step measured: thread oversubscription on
-    # ~3000 small ops); 16 threads is near the sweet spot and is what `cores` reports.
-    torch.set_num_threads(min(16, os.cpu_count()))
+    # ~3000 small ops); 16 threads is near the sweet spot and is what `cores` reports (the all-core figure is recorded by
+    # `--cpu-threads 0` runs, profiles/r02_cpu_allcores.json).
+    torch.set_num_threads(min(threads, os.cpu_count()) if threads > 0 else os.cpu_count())
     inp = syn.make_inputs(V, S, seed=0)
     dn, sn = syn.step_noise(V, S, D, 50, seed=0)
     tab = O.ddpm_tables()
@@ -145,12 +189,27 @@ def cpu_baseline(sd, V, S, D, cfg_scale, n_timed=1):
         for i in range(1 + n_timed):
             t0 = time.time()
             x, _ = O.denoise_step(sd, x, cams(inp["batch_cameras"]), inp["input_latents"], cams(inp["input_cameras"]),
-                                  inp["clip_v_embed"], tab, dd, 49 - i, dn[i], sn[i], cfg_scale=cfg_scale, n_pts_per_ray=D)
+                                  inp["clip_v_embed"], tab, dd, 49 - i, dn[i], sn[i], cfg_scale=cfg_scale, n_pts_per_ray=D,
+                                  unet_kw=dict(image_size=S))
             times.append(time.time() - t0)
     dt = sum(times[1:]) / n_timed
-    return {"value": 1.0 / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_timed} timed DDIM steps (+1 warm-up) of the same V={V} workload, fp32 PyTorch eager, "
-                      f"{dt:.2f} s/step"}, x
+    out = {"value": 1.0 / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n_timed} timed DDIM steps (+1 warm-up) of the same V={V} S={S} workload, fp32 PyTorch eager, "
+                     f"{dt:.2f} s/step (min {min(times[1:]):.2f}, max {max(times[1:]):.2f}); extrapolated 50-step sample "
+                     f"{50 * dt:.0f} s"}
+    f = os.path.join(ROOT, "profiles", f"{ROUND}_cpu_allcores.json")
+    if os.path.exists(f):
+        out["all_host_cores"] = json.load(open(f))
+    return out, x
+
+
+def workload_label(V, S, D, N, cfg_scale):
+    idx = {(4, 32): 1, (8, 32): 2, (8, 64): 3}.get((V, S))
+    if N > 1:
+        idx = 2 if (V, S) == (8, 32) else idx
+    head = f"BASELINE.json configs[{idx}]" if idx is not None and D == 1 else "off-BASELINE workload"
+    return (f"{head}: V={V} views x {8 * S}^2 images ({S}x{S} latents), D={D}, 50-step DDIM (eta 1), cfg {cfg_scale}, "
+            "SD1.x UNet 320ch + 10 view-aligned transformers + GridAttn, random-init (deterministic fill) weights")
 
 
 def main():
@@ -163,13 +222,17 @@ def main():
     ap.add_argument("--depth-samples", type=int, default=1)
     ap.add_argument("--precision", default="f16x4", choices=["f16x4", "f16x3", "bf16x3", "f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (0 = all host cores)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--shard-emulate", default=None, metavar="r/N",
+                    help="single GPU: also time the work of rank r of an N-way view-parallel job (Vq = V/N query views)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % torch.cuda.device_count()       # (functional testing of the N>1 path on one GPU with gloo)
+    local = local % torch.cuda.device_count()       # (functional testing of the N>1 path on one GPU)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -196,25 +259,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run_steps(eng, a.warmup, cfg_scale, ex, graph)
-    sync()
-    ev0, ev1 = hip.Event(), hip.Event()
-    t0 = time.perf_counter()
-    ev0.record()
-    run_steps(eng, a.steps, cfg_scale, ex, graph)
-    ev1.record()
-    sync()
-    dt = time.perf_counter() - t0
+    def timed_run(e, exch):
+        run_steps(e, a.warmup, cfg_scale, exch, graph)
+        sync()
+        ev0, ev1 = hip.Event(), hip.Event()
+        t0 = time.perf_counter()
+        ev0.record()
+        run_steps(e, a.steps, cfg_scale, exch, graph)
+        ev1.record()
+        sync()
+        return time.perf_counter() - t0, ev0.elapsed_ms(ev1) / a.steps
+
+    dt, gpu_ms = timed_run(eng, ex)
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_step = dt * 1e3 / a.steps
-    gpu_ms = ev0.elapsed_ms(ev1) / a.steps
 
     out = None
     if rank == 0:
-        from mvdfusion_amd.hip import PREC_BF16X3
         f_unet = {32: 225.09e9, 64: 1047.09e9}.get(S, 225.09e9 * (S / 32) ** 2) if D == 1 else 235.81e9
         T = V * V * S * S * D
         f_grid = T * (3516416 + 3072 * V) + V * S * S * D * 393216 + (V + 1) * S * S * 2560
@@ -228,9 +292,7 @@ def main():
                       "bf16x3": "bf16x3 (bf16 MFMA operands split hi+lo, 3 products, fp32 accumulate)",
                       "f16": "f16 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)"}[a.precision],
             "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[{1 if N == 1 else 2}]: V={V} views x {8 * S}^2 images "
-                                    f"({S}x{S} latents), D={D}, 50-step DDIM (eta 1), cfg {cfg_scale}, SD1.x UNet 320ch "
-                                    "+ 10 view-aligned transformers + GridAttn, random-init (deterministic fill) weights"),
+            "config": {"workload": workload_label(V, S, D, N, cfg_scale),
                        "views": V, "latent": S, "depth_samples": D, "cfg_scale": cfg_scale,
                        "parallelism": "single GPU, CFG pair batched as 2V" if N == 1 else
                        f"view-parallel: {V} views over {N} GPUs, 1 RCCL all-gather of latent rows per step",
@@ -239,28 +301,29 @@ def main():
             "algorithmic_tflop_per_step": step_flops / 1e12,
             "algorithmic_tflops": step_flops / (dt / a.steps) / 1e12,
         }
-    # ---- roofline of the dominant kernel (N == 1 only; HIP events around each launch on the launch stream)
+    # ---- roofline of the dominant kernel family + per-group rooflines (N == 1 only; HIP events on the launch stream)
     if world == 1:
-        by = profile_gemm_kernels(eng, cfg_scale)
+        by, gsum = profile_kernel_groups(m, eng, cfg_scale)
         tot = sum(b["ms"] for b in by.values())
         for k, b in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
-            log(f"[bench] {k:34s} launches {b['n']:4d} (split-K {b['n_split']:3d})  total {b['ms']:8.3f} ms  "
-                f"avg {b['ms'] / b['n'] * 1e3:8.1f} us  {b['flops'] / b['ms'] / 1e9:8.1f} TFLOP/s algorithmic")
+            log(f"[bench] {k:40s} launches {b['n']:4d}  total {b['ms']:8.3f} ms  avg {b['ms'] / b['n'] * 1e3:8.1f} us  "
+                f"{b['flops'] / b['ms'] / 1e9:8.1f} TFLOP/s algorithmic")
         # The dominant kernel is mvd_gemm's gemm_kernel (one source, csrc/gemm.hip; the template arguments are the
         # tile / loop variants the autotuner picks per shape).  Headline = the whole family (every GEMM launch of the
         # step); `variants` lists each instantiation under the symbol rocprofv3 reports, for cross-checking
-        # profiles/r01_bench_n1_kernel_stats.csv.
+        # profiles/<round>_bench_n1_kernel_stats.csv.
         nprod = {"f16x4": 4, "f16x3": 3, "bf16x3": 3}.get(a.precision, 1)
         n_all = sum(b["n"] for b in by.values())
         fl_all = sum(b["flops"] for b in by.values())
         by_all = sum(b["bytes"] for b in by.values())
         ach = fl_all / (tot * 1e-3)
+        # HBM traffic: only from PMC passes of THIS workload (tools/pmc_traffic.sh <tag> --views V --latent S ...), else null
         pmc, tsrc = {}, None
-        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile):        # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.sh), committed
+        tfile = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic_v{V}_s{S}_d{D}.json")
+        if os.path.exists(tfile) and a.precision == "f16x4":
             pmc = json.load(open(tfile))["kernels"]
-            tsrc = ("profiles/r01_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
-                    "command, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch over the steady-state launches")
+            tsrc = (f"profiles/{os.path.basename(tfile)}: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
+                    "command and workload, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch over the graph-replayed steps only")
         variants, tr_sum, tr_n = [], 0.0, 0
         for k, b in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
             t = pmc.get(k, {}).get("hbm_bytes_per_launch")
@@ -268,21 +331,52 @@ def main():
                 tr_sum += t * b["n"]
                 tr_n += b["n"]
             variants.append({"kernel": k, "launches_per_step": b["n"], "avg_launch_us": b["ms"] / b["n"] * 1e3,
-                             "achieved": b["flops"] / (b["ms"] * 1e-3) / 1e12, "frac": b["flops"] / (b["ms"] * 1e-3) / MFMA_BF16_DENSE_PEAK,
+                             "achieved": b["flops"] / (b["ms"] * 1e-3) / 1e12,
+                             "frac": b["flops"] / (b["ms"] * 1e-3) / MFMA_16BIT_DENSE_PEAK,
                              "algorithmic_bytes_per_launch": b["bytes"] / b["n"], "traffic": t})
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<BM, BN, WM, WN, NS, AMODE, LOOP> (all instantiations)",
                            "launches_per_step": n_all, "avg_launch_us": tot / n_all * 1e3, "achieved": ach / 1e12,
-                           "peak": MFMA_BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK,
-                           "traffic": tr_sum / tr_n if tr_n else None,
+                           "peak": MFMA_16BIT_DENSE_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_16BIT_DENSE_PEAK,
+                           "traffic": tr_sum / tr_n if tr_n == n_all and tr_n else None,
                            "traffic_unit": "bytes per launch (memory-side requests, Infinity-Cache hits included)",
                            "traffic_source": tsrc, "algorithmic_bytes_per_launch": by_all / n_all,
-                           "mfma_products_per_mac": nprod, "mfma_pipe_frac": nprod * ach / MFMA_BF16_DENSE_PEAK,
+                           "mfma_products_per_mac": nprod, "mfma_pipe_frac": nprod * ach / MFMA_16BIT_DENSE_PEAK,
                            "note": "achieved = algorithmic FLOPs (2*M*N*K of the fp32 problem) / HIP-event time of the eager "
                                    "launches; the split-operand kernels issue `mfma_products_per_mac` MFMA products per "
                                    "algorithmic MAC, so the MFMA pipe runs at mfma_pipe_frac of the dense 16-bit peak",
                            "gemm_share_of_step_ms": tot, "variants": variants}
+        rg = {}
+        for k, g in gsum.items():
+            if not g["n"] or g["ms"] <= 0:
+                continue
+            e = {"launches_per_step": g["n"], "ms_per_step": g["ms"]}
+            if g["flops"]:
+                e.update(bound="mfma", achieved=g["flops"] / (g["ms"] * 1e-3) / 1e12, peak=MFMA_16BIT_DENSE_PEAK / 1e12,
+                         unit="TFLOP/s", frac=g["flops"] / (g["ms"] * 1e-3) / MFMA_16BIT_DENSE_PEAK,
+                         mfma_pipe_frac=nprod * g["flops"] / (g["ms"] * 1e-3) / MFMA_16BIT_DENSE_PEAK)
+            else:
+                e.update(bound="hbm", achieved=g["bytes"] / (g["ms"] * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                         frac=g["bytes"] / (g["ms"] * 1e-3) / HBM_PEAK)
+            rg[k] = e
+        if "gridattn" in rg:
+            rg["gridattn"]["note"] = ("whole GridAttn block (z-embed, token generation, aggregation transformer, pooling, 256->768); "
+                                      "FLOPs = T*(3516416 + 3072*V), the aggregation tail SURVEY.md section 8(d) puts the >=40% "
+                                      "MFMA target on")
+        out["roofline_groups"] = rg
+        if a.shard_emulate:
+            r_, n_ = (int(t) for t in a.shard_emulate.split("/"))
+            from mvdfusion_amd.parallel import view_range
+            sq0, sVq = view_range(V, r_, n_)
+            eng_s, *_ = prepare(m, V, S, D, cfg_scale, q0=sq0, Vq=sVq)
+            dts, gms = timed_run(eng_s, None)
+            out["shard_emulate"] = {"rank": r_, "world": n_, "q0": sq0, "Vq": sVq, "ms_per_step": dts * 1e3 / a.steps,
+                                    "gpu_ms_per_step_hip_events": gms,
+                                    "projected_speedup": dt / dts,
+                                    "note": "time of ONE rank's share (its Vq query views against all V references, CFG batch "
+                                            "2*Vq) on one GPU; projected_speedup = t(V views unsharded) / t(shard) bounds the "
+                                            "N-GPU strong-scaling result (the all-gather of 20 KB latent rows is not included)"}
         if not a.no_cpu_baseline:
-            cb, _ = cpu_baseline(sd, V, S, D, cfg_scale)
+            cb, _ = cpu_baseline(sd, V, S, D, cfg_scale, n_timed=a.cpu_steps, threads=a.cpu_threads)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
     else:

@@ -18,6 +18,13 @@
  *     x = hi + lo, three products hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2^-22 (fp16) / ~2^-17 (bf16) relative
  *     operand error; the 50-step stochastic trajectory amplifies operand error by ~10^3, so the split is what keeps it
  *     within the 1e-3 latent-RMSE budget).
+ *   - Operand range (fp16 flavour): every GEMM / attention operand is stored as x ~= hi + lo in fp16.  For
+ *     6e-5 <= |x| < 65504 the relative operand error is <= 2^-22; below that the ABSOLUTE resolution is 2^-25 (fp16
+ *     subnormals), i.e. a tensor whose values are all << 1e-3 loses relative precision; |x| >= 65504 overflows to inf and
+ *     the outputs become non-finite (no silent saturation).  Weights are pre-scaled by a power of two at pack time
+ *     (mvd_pack_*, undone exactly through acc_scale) so they always sit in the normal range.  The host mirrors check the
+ *     final latents / images once per sample (mvdfusion_amd/hip.py: check_finite) and raise FloatingPointError; the bf16
+ *     flavour (libmvd_hip_bf16.so, precision "bf16x3") has fp32's exponent range at ~2^-16 relative operand error.
  *   - one host thread per process / GPU (matches the reference's mp.spawn model, demo.py:208).
  */
 #ifndef MVD_HIP_H
@@ -146,11 +153,11 @@ int mvd_gemv(const float* W, const float* bias, const float* x, float* y, int M,
  * GroupNorm(32 groups) on channels-last data; `silu` bit 0 = fused SiLU, bit 1 = round the normalised value to fp16 first
  * (the VAE decoder tail, diffusionmodules/model.py:564-570) (openaimodel.py:201-203,225-227 eps 1e-5;
  * attention.py:76,243,274 and mvdfusion/attention.py:92,132 eps 1e-6; unet.py:496-498).
- * ws: B * chunks * groups * 2 doubles with chunks = mvd_groupnorm_chunks(HW). */
+ * ws: B * chunks * groups * 2 doubles with chunks = mvd_groupnorm_chunks(HW); ws_elems = its capacity in doubles (checked). */
 int mvd_groupnorm_chunks(int HW);
 /* y_sp: the normalised activations in split-planes format (B*HW, C), C % 32 == 0 -- GroupNorm only feeds GEMMs / convs. */
 int mvd_groupnorm_nhwc(const float* x, void* y_sp, const float* gamma, const float* beta, int B, int HW, int C,
-                       int groups, float eps, int silu, double* ws, mvd_stream_t stream);
+                       int groups, float eps, int silu, double* ws, size_t ws_elems, mvd_stream_t stream);
 /* Row softmax: y[r, :] = out_scale * softmax(scale * x[r, :]) of an fp32 (rows, cols) matrix (row stride ldx), written as
  * split planes (rows, cols), cols % 32 == 0, cols <= 4096.  out_scale (a power of two, e.g. 1024) lifts the probabilities of
  * wide rows out of the fp16 subnormal range; the consumer GEMM divides it out through its weight's acc_scale.  Replaces

@@ -299,7 +299,7 @@ class AutoencoderKL(nn.Module):
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         hip.set_operand_format("bf16" if precision.startswith("bf16") else "f16")
         self.precision = {"x3": hip.PREC_BF16X3, "x4": hip.PREC_X4}.get(precision[-2:], hip.PREC_BF16)
-        self._ctx, self._pq, self._q, self._tuned = None, None, None, set()
+        self._ctx, self._pq, self._q, self._tuned, self._packed_sig = None, None, None, set(), None
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
 
@@ -309,8 +309,14 @@ class AutoencoderKL(nn.Module):
         self.load_state_dict(sd, strict=False)
 
     def _context(self, device):
+        sig = hip.params_signature(self)
+        if sig != self._packed_sig:      # weights changed (load_state_dict, .cuda(), ...) since they were packed
+            if self._packed_sig is not None:
+                hip.drop_packed_caches(self)
+            self._packed_sig = sig
         if self._ctx is None:
             self._ctx = Ctx(device, self.precision)
+        if self._pq is None:
             self._pq = hip.pack_linear(self.post_quant_conv.weight, self.post_quant_conv.bias)
             self._q = hip.pack_linear(self.quant_conv.weight, self.quant_conv.bias)
         return self._ctx

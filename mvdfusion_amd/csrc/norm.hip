@@ -265,12 +265,15 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, u1
 extern "C" int mvd_groupnorm_chunks(int HW) { return gn_chunks(HW); }
 
 extern "C" int mvd_groupnorm_nhwc(const float* x, void* y_sp, const float* gamma, const float* beta, int B, int HW, int C,
-                                  int groups, float eps, int silu, double* ws, mvd_stream_t stream) {
+                                  int groups, float eps, int silu, double* ws, size_t ws_elems, mvd_stream_t stream) {
   MVD_CHECK_ARG(x && y_sp && gamma && beta && ws, "mvd_groupnorm_nhwc: null pointer");
   MVD_CHECK_ARG(C % 32 == 0, "mvd_groupnorm_nhwc: split-planes output needs C %% 32 == 0 (C=%d)", C);
   MVD_CHECK_ARG(B > 0 && HW > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0, "mvd_groupnorm_nhwc: bad shape");
   MVD_CHECK_ARG(C <= GN_MAX_C && C % 4 == 0, "mvd_groupnorm_nhwc: C=%d must be <= %d and a multiple of 4", C, GN_MAX_C);
   const int chunks = gn_chunks(HW);
+  MVD_CHECK_ARG((size_t)B * chunks * groups * 2 <= ws_elems,
+                "mvd_groupnorm_nhwc: workspace holds %zu doubles, B*chunks*groups*2 = %zu needed (B=%d, chunks=%d, groups=%d)", ws_elems,
+                (size_t)B * chunks * groups * 2, B, chunks, groups);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B), dim3(256), 0, s, x, ws, HW, C, groups, chunks);
   MVD_CHECK_LAUNCH("mvd_groupnorm_nhwc/stats");

@@ -18,11 +18,14 @@ class Workspace:
     def __init__(self, device):
         self.device = torch.device(device)
         self.bufs = {}
+        self.frozen = False         # True while a hipGraph is being captured
 
     def get(self, tag, shape, dtype=torch.float32, zero=False):
         key = (tag, tuple(int(s) for s in shape), dtype)
         t = self.bufs.get(key)
         if t is None:
+            assert not self.frozen, f"workspace buffer {key} requested during graph capture (the eager warm-up step must " \
+                                    "allocate every buffer the captured step uses)"
             t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
             self.bufs[key] = t
         return t
@@ -36,6 +39,7 @@ class Workspace:
         key = ("attn_planes", B, heads, L, dhead)
         t = self.bufs.get(key)
         if t is None:
+            assert not self.frozen, f"attention planes {key} requested during graph capture"
             t = hip.alloc_attn_planes(B, heads, L, dhead, self.device)
             self.bufs[key] = t
         return t
@@ -61,8 +65,13 @@ class Ctx:
         self.vol_levels = None      # list of (B*h*w*D, 768)
         self.emb_bias = None        # dict: ResBlock -> (Cout,) slice of the per-step time-embedding biases
         self._rot = {}
-        self.gn_ws = torch.empty(64 * 64 * 32 * 2, dtype=torch.float64, device=self.device)
+        self.capturing = False      # set by StepEngine around graph capture: no new workspace buffer may appear then
         self.gemm_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 256 MB split-K slabs
+
+    def begin_step(self):
+        """Reset the rotation of the layer-output buffers: the eager warm-up step and the captured step then walk the
+        SAME act{i} slots in the same order (capture never meets a slot the warm-up did not allocate)."""
+        self._rot.clear()
 
     def act(self, shape):
         """Rotating layer-output buffers (3 per shape): a layer's input stays valid while it writes its output."""
@@ -78,7 +87,9 @@ class Ctx:
         return hip.gemm(A, W, out, **kw)
 
     def groupnorm(self, x, y, norm, B, HW, C, silu):
-        return hip.groupnorm(x, y, norm.weight, norm.bias, B, HW, C, norm.eps, silu, self.gn_ws)
+        # partial-sum workspace sized for THIS call (B * chunks(HW) * groups * 2 doubles); the ABI checks the size
+        ws = self.ws.get("gn_ws", (B * hip.lib().mvd_groupnorm_chunks(HW) * 32 * 2,), torch.float64)
+        return hip.groupnorm(x, y, norm.weight, norm.bias, B, HW, C, norm.eps, silu, ws)
 
     def layernorm(self, x, y, norm, rows, C):
         return hip.layernorm(x, y, norm.weight, norm.bias, rows, C, norm.eps)

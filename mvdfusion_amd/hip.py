@@ -53,7 +53,7 @@ SIGNATURES = {
     "mvd_split_planes": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp]),
     "mvd_gemv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_groupnorm_chunks": (_i, [_i]),
-    "mvd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "mvd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "mvd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "mvd_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "mvd_attn_qk_plane_elems": (_sz, [_i, _i, _i, _i]),
@@ -193,6 +193,47 @@ def pack_conv3x3(weight, bias=None):
 
 
 # ---------------------------------------------------------------------------------------------
+# packed-weight cache invalidation
+# ---------------------------------------------------------------------------------------------
+_CACHE_ATTRS = ("_p", "_temb", "_xattn", "_head", "_pq", "_q", "_fused")
+
+
+def params_signature(module):
+    """Cheap fingerprint of a module's parameters: changes when any parameter is updated in place (load_state_dict,
+    optimizer step, fill) or re-allocated (.cuda() / .to()).  The packed MFMA operand images are derived from the
+    fp32 parameters; the owners compare this before (re)using them."""
+    ver, ptr_ = 0, 0
+    for p in module.parameters():
+        ver += p._version
+        ptr_ ^= p.data_ptr()
+    for b in module.buffers():
+        ptr_ ^= b.data_ptr()
+    return ver, ptr_
+
+
+def drop_packed_caches(module):
+    """Forget every lazily packed weight image under `module` (they are re-packed from the live parameters on next use)."""
+    for m in module.modules():
+        for name in _CACHE_ATTRS:
+            if name in m.__dict__:
+                cur = m.__dict__[name]
+                if isinstance(cur, dict):
+                    m.__dict__[name] = {}
+                elif cur is not None:
+                    m.__dict__[name] = None
+
+
+def check_finite(t, what):
+    """The 16-bit MFMA operand split has fp16's range (include/mvd_hip.h, "Operand range"): an activation beyond
+    +-65504 becomes inf and surfaces as non-finite outputs.  Called once per sample / decode on the final tensor."""
+    if not bool(torch.isfinite(t).all()):
+        raise FloatingPointError(
+            f"{what}: non-finite values. mvd_hip splits GEMM operands into fp16 hi + lo (range +-65504); an activation or "
+            "weight outside that range overflowed. Use precision='bf16x3' (bf16 operands, fp32 range) for such weights.")
+    return t
+
+
+# ---------------------------------------------------------------------------------------------
 # ops (thin wrappers; all outputs are caller-provided tensors)
 # ---------------------------------------------------------------------------------------------
 def planes_like(rows, cols, device):
@@ -285,6 +326,15 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     return out
 
 
+def kernel_symbol(cfg, prec, conv):
+    """The gemm_kernel<BM, BN, WM, WN, NS, AMODE, LOOP> instantiation (as rocprofv3 prints it) that `cfg` selects."""
+    c = (cfg - 1) % 4 + 1 if cfg else 0
+    bm = {0: "auto", 1: 64, 2: 64, 3: 128, 4: 128}[c]
+    st = {0: "auto", 1: 3, 2: 2, 3: 2, 4: 3}[c]      # 2 = plain two-buffer loop, 3 = register-pipelined loop
+    wmn = "2, 4" if bm == 128 else "2, 2"
+    return f"gemm_kernel<{bm}, {bm}, {wmn}, {prec}, {1 if conv else 0}, {st}>"
+
+
 LAST_CFG = 0
 AUTOTUNE = False          # set by the step engine around its eager warm-up step (never during graph capture)
 _TUNED = {}
@@ -321,7 +371,8 @@ def gemv(W, bias, x, y, act_in=ACT_NONE, act_out=ACT_NONE):
 
 def groupnorm(x, y, gamma, beta, B, HW, Cc, eps, silu, ws):
     """y: split planes (B*HW, 2*C)."""
-    check(lib().mvd_groupnorm_nhwc(ptr(x), ptr(y), ptr(gamma), ptr(beta), B, HW, Cc, 32, eps, int(silu), ptr(ws), stream()))
+    check(lib().mvd_groupnorm_nhwc(ptr(x), ptr(y), ptr(gamma), ptr(beta), B, HW, Cc, 32, eps, int(silu), ptr(ws), ws.numel(),
+                                   stream()))
     return y
 
 

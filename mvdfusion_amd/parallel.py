@@ -30,6 +30,9 @@ class ViewExchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.ranges = [view_range(V, r, self.world) for r in range(self.world)]
         self.q0, self.Vq = self.ranges[self.rank]
+        if self.Vq == 0:
+            raise ValueError(f"view-parallel sharding needs world_size <= V (world {self.world}, V {V}): rank {self.rank} "
+                             "would own no view")
         self.uniform = len({n for _, n in self.ranges}) == 1
 
     def gather(self, x_full):

@@ -104,5 +104,6 @@ class DDIMSampler:
             eng.step(unconditional_scale, do_update=True, use_graph=use_graph)
             if return_intermediates:
                 inter.append({"t": int(self.ddim_timesteps[total - i - 1]), "xt": eng.x.clone(), "x0": eng.x0.clone()})
-        out = eng.x.clone()
+        from . import hip
+        out = hip.check_finite(eng.x.clone(), "DDIMSampler.sample")
         return (out, inter) if return_intermediates else out

@@ -101,6 +101,7 @@ class GridAttn(nn.Module):
         super().__init__()
         assert not keep_top_k_views, "top-k view selection is dead code in the reference configs"
         assert hidden_size == 256, "the token kernel is specialised for 256-channel feature maps"
+        assert in_channels == 5, "mvd_zembed reads 4 VAE + 1 depth latent channels (configs/*.yaml: in_channels: 5)"
         self.input_size, self.hidden_size, self.output_dim = input_size, hidden_size, output_dim
         self.depth_scale, self.depth_shift, self.n_pts_per_ray = depth_scale, depth_shift, n_pts_per_ray
         self.z_near_far_scale = z_near_far_scale

@@ -61,6 +61,8 @@ class StepEngine:
         self.f256 = _sinusoid_freqs(256).to(dev)
         self.funet = _sinusoid_freqs(model.unet_model.unet_model.model_channels).to(dev)
         self.graphs = {}
+        self.n_rows = 1            # rows of the device step table; the kernels index steps[iter], noise[iter] unchecked
+        self.done = 0              # host mirror of the device iteration counter
 
     # -- host-side inputs ----------------------------------------------------------------------------
     def set_conditioning(self, batch_cameras, input_latents, input_cameras, clip_v_embed):
@@ -80,13 +82,21 @@ class StepEngine:
             self.steps.copy_(steps_table)
             self.depth_noise.copy_(depth_noise)
             self.ddim_noise.copy_(ddim_noise)
-        self.iter.zero_()
+        self.n_rows = int(steps_table.shape[0])
+        self.rewind()
+
+    def rewind(self, it=0):
+        """Reset the device iteration counter (and its host mirror) to row `it` of the step table."""
+        assert 0 <= it < self.n_rows
+        self.iter.fill_(it)
+        self.done = it
 
     # -- one iteration -------------------------------------------------------------------------------
     def enqueue(self, cfg_scale, do_update):
         m, ctx, L = self.m, self.ctx, hip.lib()
         V, S, D, B, q0, Vq = self.V, self.S, self.D, self.B, self.q0, self.Vq
         ctx.B, ctx.D = B, D
+        ctx.begin_step()           # eager warm-up and graph capture walk the same rotating buffers
         st = hip.stream
         # embed_time (:276-279): sinusoid(256) -> Linear -> SiLU -> Linear; only row 0 is used downstream (t[:1])
         ts = ctx.ws.get("vf.tsin", (1, 256))
@@ -124,6 +134,11 @@ class StepEngine:
 
     def step(self, cfg_scale, do_update, use_graph=True):
         key = (float(cfg_scale), bool(do_update))
+        if self.done >= self.n_rows:
+            raise IndexError(f"StepEngine.step: iteration {self.done} is past the {self.n_rows}-row step table "
+                             "(set_schedule() / rewind() before stepping again)")
+        if do_update:
+            self.done += 1
         if not use_graph:
             return self.enqueue(cfg_scale, do_update)
         g = self.graphs.get(key)
@@ -140,8 +155,12 @@ class StepEngine:
             self.iter.copy_(it0)
             self.x.copy_(x_keep)
             g = hip.Graph()
-            with g:
-                self.enqueue(cfg_scale, do_update)
+            self.ctx.ws.frozen = True      # capture must not allocate: every buffer exists after the eager step
+            try:
+                with g:
+                    self.enqueue(cfg_scale, do_update)
+            finally:
+                self.ctx.ws.frozen = False
             self.graphs[key] = g
         g.launch()
 
@@ -203,10 +222,23 @@ class ViewFusion(nn.Module):
         self.ddim = DDIMSampler(self, ddim_num_steps=50, ddim_discretize="uniform", ddim_eta=1.0,
                                 latent_size=self.latent_size, z_dim=4, feed_prev_depth=feed_prev_depth)
         self._engines = {}
+        self._packed_sig = None
         assert self.finetune_view_attn is True, "must finetune new view attention layers"
 
     # ------------------------------------------------------------------------------------------------
+    def invalidate_packed(self):
+        """Drop every packed weight image, captured graph and engine: they are rebuilt from the live fp32 parameters."""
+        hip.drop_packed_caches(self)
+        self._engines.clear()
+
     def engine(self, V, S, D, cfg, q0=0, Vq=None):
+        sig = hip.params_signature(self)
+        if sig != self._packed_sig:      # load_state_dict / optimizer step / .cuda() since the weights were packed
+            if self._packed_sig is not None:
+                self.invalidate_packed()
+            self._packed_sig = sig
+        if Vq is not None and Vq <= 0:
+            raise ValueError(f"engine(V={V}, q0={q0}, Vq={Vq}): a rank must own at least one query view")
         key = (V, S, D, bool(cfg), q0, Vq)
         e = self._engines.get(key)
         if e is None:
@@ -304,7 +336,7 @@ class ViewFusion(nn.Module):
         eng.set_schedule(table, depth_noise.reshape(1, V, D, S, S), torch.zeros(1, V, 5, S, S))
         eng.x.copy_(noisy_latents)
         eng.step(cfg_scale, do_update=False)
-        return eng.eps.clone()
+        return hip.check_finite(eng.eps.clone(), "ViewFusion.apply_model")
 
     def sample(self, batch, trainer_config, cfg_scale, return_input=False, depth=False, verbose=True):
         """viewfusion_zero_depth_rgb.py:348-359."""

@@ -33,7 +33,8 @@ def test_oracle_schedule_bit_exact():
         assert torch.equal(xp, gd[f"x_prev_{index}"]) and torch.equal(x0, gd[f"x0_{index}"])
 
 
-@pytest.mark.parametrize("name,V,D,seed,tval", [("gridattn_v4_d1", 4, 1, 0, 981), ("gridattn_v3_d3", 3, 3, 1, 501)])
+@pytest.mark.parametrize("name,V,D,seed,tval", [("gridattn_v4_d1", 4, 1, 0, 981), ("gridattn_v3_d3", 3, 3, 1, 501),
+                                                ("gridattn_v15_d1", 15, 1, 3, 741)])
 def test_oracle_gridattn_vs_reference(name, V, D, seed, tval):
     gd = load_golden(name)
     sd = {k: v for k, v in syn.det_fill_state_dict(load_spec(32)).items() if k.startswith("view_attn.")}
@@ -47,7 +48,7 @@ def test_oracle_gridattn_vs_reference(name, V, D, seed, tval):
 
 
 @pytest.mark.parametrize("name,mc,V,D,tval", [("unet_mc32_v4_d1", 32, 4, 1, 981), ("unet_mc32_v2_d3", 32, 2, 3, 501),
-                                              ("unet_mc64_v2_d1", 64, 2, 1, 21)])
+                                              ("unet_mc64_v2_d1", 64, 2, 1, 21), ("unet_mc320_v2_d3", 320, 2, 3, 501)])
 def test_oracle_unet_vs_reference(name, mc, V, D, tval):
     import json
     gd = load_golden(name)
@@ -104,6 +105,70 @@ def test_kat_project_unproject_roundtrip():
         back = O.project_ndc(R[i:i + 1], T[i:i + 1], f[i:i + 1], p[i:i + 1], w[i])[0]
         assert torch.allclose(back[:, :2], xy_d[i, :, :2], atol=2e-5)
         assert torch.allclose(back[:, 2], 1.0 / xy_d[i, :, 2], atol=2e-5)
+
+
+def test_kat_hand_computed_camera_conventions():
+    """Independent of oracle/shims.py: numbers worked out BY HAND from PyTorch3D's published conventions (row vectors,
+    X_view = X_world R + T; NDC projection u = f x/z + p with 1/z as the third component; C = -T R^T;
+    look_at_view_transform axes as columns).  Checks the oracle, the product's host camera algebra and the device record."""
+    # (1) R = I, T = (0,0,2), f = 2, p = 0:  X = (0.5,-0.25,1) -> X_view = (0.5,-0.25,3) -> ndc = (1/3, -1/6, 1/3)
+    R, T = torch.eye(3)[None], torch.tensor([[0.0, 0.0, 2.0]])
+    f, p0 = torch.tensor([[2.0, 2.0]]), torch.zeros(1, 2)
+    ndc = O.project_ndc(R, T, f, p0, torch.tensor([[0.5, -0.25, 1.0]]))[0, 0]
+    assert torch.allclose(ndc, torch.tensor([1.0 / 3.0, -1.0 / 6.0, 1.0 / 3.0]), atol=1e-6)
+    w = O.unproject_ndc(R, T, f, p0, torch.tensor([[[1.0 / 3.0, -1.0 / 6.0]]]), torch.tensor([[3.0]]))[0, 0]
+    assert torch.allclose(w, torch.tensor([0.5, -0.25, 1.0]), atol=1e-6)
+    # principal point shifts NDC additively: p = (0.1, -0.2)
+    ndc = O.project_ndc(R, T, f, torch.tensor([[0.1, -0.2]]), torch.tensor([[0.5, -0.25, 1.0]]))[0, 0]
+    assert torch.allclose(ndc[:2], torch.tensor([1.0 / 3.0 + 0.1, -1.0 / 6.0 - 0.2]), atol=1e-6)
+    # (2) quarter turn about y, row-vector convention: rows of R are the images of the world axes.
+    #     X = (1,0,0) -> X R = row 0 = (0,0,-1);  T = (0,0,2)  =>  X_view = (0,0,1);  C = -T R^T = (2,0,0)
+    R2 = torch.tensor([[[0.0, 0.0, -1.0], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0]]])
+    C = O.camera_center(R2, T)[0]
+    assert torch.allclose(C, torch.tensor([2.0, 0.0, 0.0]), atol=1e-6)
+    assert torch.allclose(cam.Cameras(R2, T, f, p0).get_camera_center()[0], C, atol=1e-6)
+    assert torch.allclose(cam.pack_cameras(cam.Cameras(R2, T, f, p0))[0, 16:19], C, atol=1e-6)
+    # a point one unit in front of that camera along its optical axis: world (1,0,0) -> view (0,0,1) -> ndc (0,0,1)
+    ndc = O.project_ndc(R2, T, f, p0, torch.tensor([[1.0, 0.0, 0.0]]))[0, 0]
+    assert torch.allclose(ndc, torch.tensor([0.0, 0.0, 1.0]), atol=1e-6)
+    # world (1, 0.5, 0.25): view = 1*(0,0,-1) + 0.5*(0,1,0) + 0.25*(1,0,0) + (0,0,2) = (0.25, 0.5, 1) -> ndc (0.5, 1.0, 1)
+    ndc = O.project_ndc(R2, T, f, p0, torch.tensor([[1.0, 0.5, 0.25]]))[0, 0]
+    assert torch.allclose(ndc, torch.tensor([0.5, 1.0, 1.0]), atol=1e-6)
+    # (3) look_at_view_transform(dist 1.5, elev 0, azim 0, up y): C = (0,0,1.5), z = (0,0,-1), x = up x z = (-1,0,0),
+    #     y = z x x = (0,1,0)  =>  R = diag(-1, 1, -1) (axes as columns), T = -R^T C = (0,0,1.5)
+    Rl, Tl = cam.look_at_view_transform(1.5, 0.0, 0.0)
+    assert torch.allclose(Rl[0], torch.diag(torch.tensor([-1.0, 1.0, -1.0])), atol=1e-6)
+    assert torch.allclose(Tl[0], torch.tensor([0.0, 0.0, 1.5]), atol=1e-6)
+    # azim 90 deg: C = (1.5,0,0), z = (-1,0,0), x = (0,1,0) x (-1,0,0) = (0,0,1), y = z x x = (0,1,0)
+    Rl, Tl = cam.look_at_view_transform(1.5, 0.0, 90.0)
+    assert torch.allclose(Rl[0], torch.tensor([[0.0, 0.0, -1.0], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0]]), atol=1e-6)
+    assert torch.allclose(Tl[0], torch.tensor([0.0, 0.0, 1.5]), atol=1e-6)
+    # (4) re-basing with center_at_origin=False: R'_i = R_q^T R_i, T'_i = T_i  (hand: R_q = R2 => R'_q = I)
+    rel = cam.get_relative_camera(cam.Cameras(torch.cat([R2, torch.eye(3)[None]]), torch.cat([T, T]), f.expand(2, 2), p0.expand(2, 2)), [0])
+    assert torch.allclose(rel.R[0], torch.eye(3), atol=1e-6) and torch.allclose(rel.T, torch.cat([T, T]), atol=1e-6)
+    assert torch.allclose(rel.R[1], R2[0].t(), atol=1e-6)
+
+
+def test_kat_timm_head_layout_and_harmonic_order():
+    """timm Attention splits qkv(x) as reshape(B, N, 3, heads, hd): channel c of the 3C output is (which = c // C,
+    head = (c % C) // hd, d = c % hd); hand-built 2-token example through the oracle's DiT block attention core."""
+    import torch.nn.functional as F
+    Cc, H = 8, 2
+    x = torch.tensor([[[1.0] * Cc, [2.0] * Cc]])                           # (1, 2 tokens, 8)
+    Wqkv = torch.zeros(3 * Cc, Cc)
+    Wqkv[2 * Cc + 0, 0] = 1.0                                              # v of head 0, d 0 reads channel 0
+    Wqkv[2 * Cc + 4, 1] = 3.0                                              # v of head 1, d 0 reads channel 1 (x3)
+    qkv = F.linear(x, Wqkv).reshape(1, 2, 3, H, Cc // H).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.unbind(0)
+    out = ((q * (Cc // H) ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v   # q = k = 0: uniform attention
+    out = out.transpose(1, 2).reshape(1, 2, Cc)
+    assert torch.allclose(out[0, :, 0], torch.tensor([1.5, 1.5])) and torch.allclose(out[0, :, 4], torch.tensor([4.5, 4.5]))
+    # harmonic embedding order: [sin(dim-major, k-minor) | cos | x], omega_k = 0.1 * 2^k
+    e = O.harmonic_embedding(torch.tensor([[1.0, 10.0]]))
+    assert e.shape == (1, 30)
+    assert float(e[0, 0]) == pytest.approx(float(torch.sin(torch.tensor(0.1)))) and \
+        float(e[0, 7]) == pytest.approx(float(torch.sin(torch.tensor(1.0)))) and \
+        float(e[0, 14 + 6]) == pytest.approx(float(torch.cos(torch.tensor(6.4)))) and float(e[0, 29]) == 10.0
 
 
 def test_kat_own_view_gather_coordinates():

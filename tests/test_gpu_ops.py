@@ -68,6 +68,35 @@ def test_gemm_dense(hip, prec, M, N, K):
         assert rel_err(planes_to_float(op), ref) < TOL[prec] + PL
 
 
+@pytest.mark.skipif(_BF, reason="the bf16 flavour has fp32's exponent range")
+def test_gemm_operand_range_contract(hip):
+    """include/mvd_hip.h "Operand range": operands are fp16 hi + lo.  In range (|x| < 65504) the relative operand error
+    is ~2^-22 down to |x| ~ 6e-2 and the ABSOLUTE resolution is 2^-25 ~ 3e-8 below that; past 65504 the hi plane is inf and
+    the result is non-finite, which hip.check_finite turns into an error at the end of a sample."""
+    M, N, K = 256, 64, 320
+    W = torch.randn(N, K, generator=g(5)) / math.sqrt(K)
+    Wp = hip.pack_linear(W.cuda())
+    out = torch.empty(M, N, device="cuda")
+    base = torch.randn(M, K, generator=g(6))
+    for scale, tol in ((3.0e4 / 4.5, 3e-6), (1.0, 3e-6), (1e-2, 3e-6)):      # max |A| ~ 4.5 * scale: up to ~3e4, well in range
+        A = base * scale
+        hip.gemm(hip.split_planes(A.cuda()), Wp, out, prec=4)
+        assert rel_err(out, F.linear(A.double(), W.double()).float()) < tol, scale
+    # tiny activations: error bounded by the absolute resolution of the split (2^-25 per element, summed over K with |w| ~ K^-1/2)
+    A = base * 1e-6
+    hip.gemm(hip.split_planes(A.cuda()), Wp, out, prec=4)
+    ref = F.linear(A.double(), W.double())
+    assert float((out.double().cpu() - ref).abs().max()) < 2.0 ** -25 * math.sqrt(K) * 4, "absolute floor of the fp16 split"
+    # out of range: documented to overflow to non-finite, and detected
+    A = base.clone()
+    A[3, 7] = 1.0e5
+    hip.gemm(hip.split_planes(A.cuda()), Wp, out, prec=4)
+    assert not bool(torch.isfinite(out[3]).all())
+    with pytest.raises(FloatingPointError):
+        hip.check_finite(out, "range test")
+    assert bool(torch.isfinite(out[4:]).all())                                # other rows are unaffected
+
+
 def test_gemm_epilogues(hip):
     M, C = 512, 320
     A = torch.randn(M, C, generator=g(5))
@@ -291,7 +320,7 @@ def test_pixel_cross_attn(hip, D):
     assert rel_err(planes_to_float(out), ref) < PL + 2e-6
 
 
-@pytest.mark.parametrize("V", [4, 8, 3])
+@pytest.mark.parametrize("V", [4, 8, 3, 2, 5, 6, 7, 15, 16])      # 2/3/4/8: templated kernel; the rest: generic kernel
 def test_view_mha_and_pool(hip, V):
     N, H, d = 500, 8, 32
     C = H * d
