@@ -82,6 +82,8 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, floa
 #define MVD_ACT_GELU 1 /* exact erf GELU (nn.GELU(), F.gelu) */
 #define MVD_ACT_SILU 2
 
+#define MVD_GEMM_TILES 5 /* tile shapes of mvd_gemm_desc.cfg */
+
 typedef struct mvd_gemm_desc {
   int M, N, K;      /* logical sizes; N % 16 == 0 after padding of the packed weight, K as packed (multiple of 32) */
   /* A operand: activations in the SPLIT-PLANES format, produced by the previous kernel (mvd_groupnorm_nhwc,
@@ -125,11 +127,14 @@ typedef struct mvd_gemm_desc {
   int splitk;
   float* workspace;
   size_t workspace_elems;
-  /* kernel configuration: 0 = built-in heuristic; 1 = 64x64 tile / register-pipelined loop, 2 = 64x64 / plain loop,
-   * 3 = 128x128 / plain loop, 4 = 128x128 / register-pipelined loop (tile order across the 8 XCDs chosen by the
-   * byte-cost model); 5-8 = the same four with the n-fastest tile order forced, 9-12 = with the m-fastest order forced.
-   * Both loops keep two k-tiles in LDS; the pipelined one also double-buffers the MFMA fragments in registers.  The
-   * host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
+  /* kernel configuration: 0 = built-in heuristic; otherwise cfg = 1 + 4 * tile + 2 * loop + order with
+   *   tile : 0 = 64x64 (4 waves)  1 = 128x128 (8 waves)  2 = 128x80 (4 waves)  3 = 64x80 (4 waves)  4 = 128x160 (8 waves);
+   *          tiles >= 2 (the 80-column family for N = 320 * k: no N padding, 256 workgroups at M = 8192, N = 320) serve
+   *          MVD_EPI_STORE only
+   *   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop (both keep two k-tiles in LDS; the pipelined one also
+   *          double-buffers the MFMA fragments in registers)
+   *   order: 0 = n-fastest, 1 = m-fastest order of the output tiles over the 8 XCDs.
+   * The host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
    * winner from then on (mvdfusion_amd/hip.py: autotune). */
   int cfg;
 } mvd_gemm_desc;

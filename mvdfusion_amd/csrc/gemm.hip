@@ -10,8 +10,11 @@
 //       per-workgroup LDS table holds the source offset of every (tile row, tap).
 //   B : weights packed once at load time into 2 KiB micro-tiles [K/32][N/16][16 n][32 hi | 32 lo], pre-scaled by a power
 //       of two (acc_scale undoes it).
-// Structure (per workgroup): block tile BM x BN (128x128 / 8 waves or 64x64 / 4 waves), BK = 32, WM x WN waves, each wave a
-// (BM/WM) x (BN/WN) sub-tile of 16x16x32 MFMAs.  A k-tile of both operands is a set of 1 KiB granules (8 rows x one
+// Structure (per workgroup): block tile BM x BN, BK = 32, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile of 16x16x32
+// MFMAs.  Tiles: 64x64 (4 waves), 128x128 (8 waves), and the 80-column family 128x80 / 64x80 (4 waves) and 128x160 (8 waves)
+// for the N = 320 * k layers of the UNet: no N padding (320 = 4 x 80), exactly 256 workgroups for M = 8192, N = 320, and
+// fewer L2->LDS bytes per MFMA than 64x64 -- the kernel is bound by operand delivery (~25 B/clk/CU of LDS-DMA), so the tile
+// is chosen for bytes per MFMA and for how evenly the grid fills the 256 CUs.  A k-tile of both operands is a set of 1 KiB granules (8 rows x one
 // full 128-byte line each); every wave instruction of `global_load_lds_dwordx4` moves one granule global -> LDS with no
 // VGPR round trip (the LDS destination is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
 // address and to the fragment reads: 16-byte chunk cc (0-3 hi, 4-7 lo) of row r of a 16-row block lives at slot
@@ -158,15 +161,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int A_GRAN = BM / 8, B_GRAN = BN / 8;     // 1 KiB granules (8 rows x 128 B: hi and lo of one 32-k block)
-  constexpr int STAGE = (A_GRAN + B_GRAN) * 1024;
-  constexpr int AI = A_GRAN / NW, BI = B_GRAN / NW;   // granules per wave per k-tile
+  constexpr int AI = A_GRAN / NW, BI = (B_GRAN + NW - 1) / NW;   // granules per wave per k-tile
+  constexpr int B_GRAN_P = BI * NW;                   // B granules rounded up to a multiple of the wave count: every wave issues
+                                                      // the same number of DMAs (counted vmcnt); the extra ones copy the zero page
+  constexpr int STAGE = (A_GRAN + B_GRAN_P) * 1024;
   constexpr int LPS = AI + BI;                        // DMA instructions per wave per stage
   constexpr int LDW = WTN + 4;                        // fp32 pitch of the epilogue staging tile
+  constexpr int C4 = WTN / 4;                         // float4 columns of a wave tile row
   constexpr int EPI_BYTES = NW * WTM * LDW * 4;
   constexpr bool PIPE = STAGES == 3;                   // 3 = register-pipelined loop (still two LDS buffers)
   constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
-  static_assert(A_GRAN % NW == 0 && B_GRAN % NW == 0, "granules must divide evenly over the waves");
-  static_assert(WTN == 32, "epilogue assumes 32-column wave tiles (one GEGLU value/gate block, one QKV head-aligned block)");
+  static_assert(A_GRAN % NW == 0, "A granules must divide evenly over the waves");
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && B_GRAN % 2 == 0, "wave tiles are made of 16x16 MFMA tiles");
 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + (AMODE != MVD_A_DENSE ? BM * 9 * 4 : 0)];
 
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const int R = (gi & 1) * 8 + gr;
     const int gc = (lane & 7) ^ ((R >> 1) & 7);
     const int nt = (n0 >> 4) + (gi >> 1);
-    b_src[i] = nt < p.nt16 ? (const u16*)d.Wp + (size_t)nt * 1024 + R * 64 + gc * 8 : nullptr;
+    b_src[i] = (gi < B_GRAN && nt < p.nt16) ? (const u16*)d.Wp + (size_t)nt * 1024 + R * 64 + gc * 8 : nullptr;
   }
   const size_t b_kstride = (size_t)p.nt16 * 1024;   // elements between consecutive k-tiles of the packed weight
 
@@ -453,13 +459,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     //  streams of the other workgroups.)
     float* ws = d.workspace + (size_t)blockIdx.z * d.M * d.N;
 #pragma unroll
-    for (int ps = 0; ps < WTM / 8; ++ps) {
-      const int row = ps * 8 + (lane >> 3), col = (lane & 7) * 4;
+    for (int ps = 0; ps < (WTM * C4 + 63) / 64; ++ps) {
+      const int idx = ps * 64 + lane;
+      const int row = idx / C4, col = (idx - row * C4) * 4;
       const int m = wm0 + row, n = wn0 + col;
-      if (m < d.M && n < d.N) *(float4*)(ws + (size_t)m * d.N + n) = *(const float4*)(sC + row * LDW + col);
+      if (idx < WTM * C4 && m < d.M && n < d.N) *(float4*)(ws + (size_t)m * d.N + n) = *(const float4*)(sC + row * LDW + col);
     }
     return;
   }
+  if constexpr (WTN == 32) {      // GEGLU / QKV epilogues address 32-column blocks (one value|gate block, head-aligned q/k/v)
   if (d.epi == MVD_EPI_GEGLU) {   // wave tile = 16 value columns | 16 gate columns
     const int ocol0 = (wn0 >> 5) * 16;
     const int half = d.N >> 1;
@@ -522,12 +530,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     }
     return;
   }
+  }
   // MVD_EPI_STORE
 #pragma unroll
-  for (int ps = 0; ps < WTM / 8; ++ps) {
-    const int row = ps * 8 + (lane >> 3), col = (lane & 7) * 4;
+  for (int ps = 0; ps < (WTM * C4 + 63) / 64; ++ps) {
+    const int idx = ps * 64 + lane;
+    const int row = idx / C4, col = (idx - row * C4) * 4;
     const int m = wm0 + row, n = wn0 + col;
-    if (m >= d.M || n >= d.N) continue;
+    if (idx >= WTM * C4 || m >= d.M || n >= d.N) continue;
     const float4 v = *(const float4*)(sC + row * LDW + col);
     if (n + 3 < d.n_store) {
       epi_store4(d, m, n, v);
@@ -591,15 +601,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
+// Tile configurations (mvd_gemm_desc.cfg = 1 + 4 * tile + 2 * loop + order; 0 = built-in heuristic).
+//   tile : 0 = 64x64 (2x2 waves)  1 = 128x128 (2x4)  2 = 128x80 (4x1)  3 = 64x80 (4x1)  4 = 128x160 (4x2)
+//   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop      order : 0 = n-fastest tile order, 1 = m-fastest
+// The 80-column family serves MVD_EPI_STORE only (GEGLU / QKV epilogues address 32-column wave tiles).
+struct TileInfo {
+  int bm, bn;
+  int cores_plain, cores_pipe;   // workgroups that fit one CU (LDS / registers), per loop variant
+};
+static const TileInfo kTiles[MVD_GEMM_TILES] = {{64, 64, 5, 3}, {128, 128, 2, 1}, {128, 80, 2, 2}, {64, 80, 4, 3}, {128, 160, 1, 1}};
+
 // Split-K selection by a small time model (unit: 0.7 us ~ one DMA round trip).  What matters most is how evenly
 // tiles*splits workgroups divide over the 256 CUs (192 tiles: 1, 2 or 3 splits all leave a CU with 180 k-tiles, 4 splits
 // give every CU 3 x 45), then whether enough workgroups are co-resident to hide the per-k-tile DMA latency, then the cost
 // of the fp32 partial-sum round trip.
-static int choose_splits(long tiles, int nk, bool big, bool pipelined, size_t mn) {
-  const double t_mfma = big ? 0.75 : 0.19;          // MFMA-pipe time of one k-tile of one workgroup
-  const double t_lat = pipelined ? 0.4 : 1.0;       // exposed DMA latency per k-tile of a workgroup running alone
-  const double t_epi = big ? 2.0 : 0.7;
-  const int coresident = big ? (pipelined ? 1 : 2) : (pipelined ? 3 : 5);
+static int choose_splits(long tiles, int nk, const TileInfo& ti, bool pipelined, size_t mn) {
+  const double area = (double)ti.bm * ti.bn / (128.0 * 128.0);
+  const double t_mfma = 0.75 * area;                 // MFMA-pipe time of one k-tile of one workgroup
+  const double t_lat = pipelined ? 0.4 : 1.0;        // exposed DMA latency per k-tile of a workgroup running alone
+  const double t_epi = 0.27 + 1.73 * area;
+  const int coresident = pipelined ? ti.cores_pipe : ti.cores_plain;
   const double red_fixed = 6.0, red_per_split = (double)mn * 8.0 / 3.0e12 / 0.7e-6;
   int best = 1;
   double best_t = 1e30;
@@ -623,17 +644,6 @@ static int choose_splits(long tiles, int nk, bool big, bool pipelined, size_t mn
 
 template <int BM, int BN, int WM, int WN, int STAGES>
 void launch_cfg(GemmParams& p, hipStream_t s) {
-  p.tiles_n = cdiv(p.d.N, BN);
-  p.tiles_m = cdiv(p.d.M, BM);
-  {
-    // bytes each XCD pulls through its L2 under the two tile orders (8 XCDs, operands are 4 B per element)
-    const double W = (double)p.d.N * p.d.K * 4.0;
-    const double A = (double)p.d.M * p.d.K * 4.0 / (p.d.a_mode == MVD_A_CONV3X3 ? 9.0 : 1.0);
-    const double rep_m = p.tiles_m < 8 ? p.tiles_m : 8, rep_n = p.tiles_n < 8 ? p.tiles_n : 8;
-    const double cost_nfast = W * rep_m + A, cost_mfast = W + A * rep_n;
-    p.m_fastest = cost_mfast < cost_nfast;
-    if (p.d.cfg > 4) p.m_fastest = p.d.cfg > 8 ? 1 : 0;     // 5..8 force n-fastest, 9..12 force m-fastest (autotune)
-  }
   dim3 grid(p.tiles_n * p.tiles_m, 1, p.splits), block(WM * WN * 64);
   const bool conv = p.d.a_mode == MVD_A_CONV3X3;
   const int ns = p.d.prec;
@@ -695,22 +705,32 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   if (d.acc_scale == 0.f) d.acc_scale = 1.f;
   p.nk = d.K / 32;
   p.nt16 = d.N / 16;
-  // tile selection: 128x128 (8 waves, 2 workgroups / CU) once the grid fills the chip, else 64x64 (4 waves)
-  const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
-  bool big = tiles128 >= 128 && (d.N >= 512 || d.K >= 2048);
-  int stages = 2;        // 2 = plain two-buffer loop, 3 = register-pipelined loop
-  if (d.cfg >= 1 && d.cfg <= 12) {
-    const int c = (d.cfg - 1) % 4 + 1;
-    big = c >= 3;
-    stages = (c == 1 || c == 4) ? 3 : 2;
+  // ---- kernel configuration: explicit (cfg >= 1) or the built-in heuristic (128x128 once the grid fills the chip, else 64x64)
+  int tile, loop = 0, order = -1;
+  MVD_CHECK_ARG(d.cfg >= 0 && d.cfg <= 4 * MVD_GEMM_TILES, "mvd_gemm: bad cfg %d", d.cfg);
+  if (d.cfg >= 1) {
+    tile = (d.cfg - 1) >> 2;
+    loop = ((d.cfg - 1) >> 1) & 1;
+    order = (d.cfg - 1) & 1;
+    MVD_CHECK_ARG(tile < 2 || d.epi == MVD_EPI_STORE, "mvd_gemm: cfg %d (80-column tile) serves MVD_EPI_STORE only", d.cfg);
+  } else {
+    const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
+    tile = (tiles128 >= 128 && (d.N >= 512 || d.K >= 2048)) ? 1 : 0;
   }
-  if (const char* e = getenv("MVD_GEMM_TILE")) big = atoi(e) >= 128;
-  if (const char* e = getenv("MVD_GEMM_STAGES")) stages = atoi(e);
-  const int BM = big ? 128 : 64, BN = big ? 128 : 64;
+  const TileInfo& ti = kTiles[tile];
+  p.tiles_n = cdiv(d.N, ti.bn);
+  p.tiles_m = cdiv(d.M, ti.bm);
+  if (order < 0) {
+    // bytes each XCD pulls through its L2 under the two tile orders (8 XCDs, operands are 4 B per element)
+    const double W = (double)d.N * d.K * 4.0;
+    const double A = (double)d.M * d.K * 4.0 / (d.a_mode == MVD_A_CONV3X3 ? 9.0 : 1.0);
+    const double rep_m = p.tiles_m < 8 ? p.tiles_m : 8, rep_n = p.tiles_n < 8 ? p.tiles_n : 8;
+    order = (W + A * rep_n) < (W * rep_m + A) ? 1 : 0;
+  }
+  p.m_fastest = order;
   int splits = d.splitk;
-  const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
-  if (const char* e = getenv("MVD_GEMM_SPLITK")) splits = atoi(e);
-  if (splits == 0) splits = choose_splits(tiles, p.nk, big, stages == 3, (size_t)d.M * d.N);
+  const long tiles = (long)p.tiles_m * p.tiles_n;
+  if (splits == 0) splits = choose_splits(tiles, p.nk, ti, loop == 1, (size_t)d.M * d.N);
   if (splits < 1) splits = 1;
   if (splits > p.nk) splits = p.nk;
   if (splits > 1) {
@@ -723,14 +743,18 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   p.kt_per_split = cdiv(p.nk, splits);
   p.splits = cdiv(p.nk, p.kt_per_split);
   hipStream_t s = (hipStream_t)stream;
-  if (big && stages == 3)
-    launch_cfg<128, 128, 2, 4, 3>(p, s);
-  else if (big)
-    launch_cfg<128, 128, 2, 4, 2>(p, s);
-  else if (stages == 3)
-    launch_cfg<64, 64, 2, 2, 3>(p, s);
-  else
-    launch_cfg<64, 64, 2, 2, 2>(p, s);
+  switch (tile * 2 + loop) {
+    case 0: launch_cfg<64, 64, 2, 2, 2>(p, s); break;
+    case 1: launch_cfg<64, 64, 2, 2, 3>(p, s); break;
+    case 2: launch_cfg<128, 128, 2, 4, 2>(p, s); break;
+    case 3: launch_cfg<128, 128, 2, 4, 3>(p, s); break;
+    case 4: launch_cfg<128, 80, 4, 1, 2>(p, s); break;
+    case 5: launch_cfg<128, 80, 4, 1, 3>(p, s); break;
+    case 6: launch_cfg<64, 80, 4, 1, 2>(p, s); break;
+    case 7: launch_cfg<64, 80, 4, 1, 3>(p, s); break;
+    case 8: launch_cfg<128, 160, 4, 2, 2>(p, s); break;
+    default: launch_cfg<128, 160, 4, 2, 3>(p, s); break;
+  }
   MVD_CHECK_LAUNCH("mvd_gemm");
   if (p.splits > 1) {
     const size_t total = (size_t)d.M * d.N;

@@ -326,13 +326,23 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     return out
 
 
+# mvd_gemm_desc.cfg = 1 + 4 * tile + 2 * loop + order (include/mvd_hip.h)
+GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
+GEMM_CONFIGS = tuple(range(1, 4 * len(GEMM_TILES) + 1))
+
+
+def gemm_configs(epi=EPI_STORE):
+    """Kernel configurations valid for an epilogue (the 80-column tiles serve EPI_STORE only)."""
+    return GEMM_CONFIGS if epi == EPI_STORE else GEMM_CONFIGS[:8]
+
+
 def kernel_symbol(cfg, prec, conv):
     """The gemm_kernel<BM, BN, WM, WN, NS, AMODE, LOOP> instantiation (as rocprofv3 prints it) that `cfg` selects."""
-    c = (cfg - 1) % 4 + 1 if cfg else 0
-    bm = {0: "auto", 1: 64, 2: 64, 3: 128, 4: 128}[c]
-    st = {0: "auto", 1: 3, 2: 2, 3: 2, 4: 3}[c]      # 2 = plain two-buffer loop, 3 = register-pipelined loop
-    wmn = "2, 4" if bm == 128 else "2, 2"
-    return f"gemm_kernel<{bm}, {bm}, {wmn}, {prec}, {1 if conv else 0}, {st}>"
+    if not cfg:
+        return f"gemm_kernel<auto, {prec}, {1 if conv else 0}>"
+    bm, bn, wm, wn = GEMM_TILES[(cfg - 1) >> 2]
+    loop = 3 if ((cfg - 1) >> 1) & 1 else 2              # 2 = plain two-buffer loop, 3 = register-pipelined loop
+    return f"gemm_kernel<{bm}, {bn}, {wm}, {wn}, {prec}, {1 if conv else 0}, {loop}>"
 
 
 LAST_CFG = 0
@@ -346,7 +356,7 @@ def _autotune(d, reps=4, trials=3):
     launches: single bursts of 20-100 us kernels are too noisy to rank configurations that differ by a few percent."""
     best, best_ms = 0, float("inf")
     e0, e1 = Event(), Event()
-    for cfg in (5, 6, 7, 8, 9, 10, 11, 12):
+    for cfg in gemm_configs(d.epi):
         d.cfg = cfg
         check(lib().mvd_gemm(C.byref(d), stream()))
         ms = float("inf")

@@ -51,16 +51,11 @@ def test_gemm_dense(hip, prec, M, N, K):
         out.zero_()
         hip.gemm(Ap, Wp, out, prec=prec, res=Rc, workspace=ws, splitk=sk)
         assert rel_err(out, ref) < TOL[prec], sk
-    # both tile configurations
-    import os
-    for tile in ("64", "128"):
-        os.environ["MVD_GEMM_TILE"] = tile
-        try:
-            out.zero_()
-            hip.gemm(Ap, Wp, out, prec=prec, res=Rc, workspace=ws, splitk=1)
-            assert rel_err(out, ref) < TOL[prec], tile
-        finally:
-            del os.environ["MVD_GEMM_TILE"]
+    # every tile shape (plain loop, n-fastest order)
+    for cfg in hip.GEMM_CONFIGS[::4]:
+        out.zero_()
+        hip.gemm(Ap, Wp, out, prec=prec, res=Rc, workspace=ws, splitk=1, cfg=cfg)
+        assert rel_err(out, ref) < TOL[prec], cfg
     # plane output (feeds the next GEMM)
     if N % 32 == 0:
         op = hip.planes_like(M, N, "cuda")
@@ -169,7 +164,7 @@ def test_conv3x3(hip, prec, case):
     assert rel_err(got, ref) < TOL[prec]
 
 
-@pytest.mark.parametrize("cfg", [5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", list(_hip.GEMM_CONFIGS))
 @pytest.mark.parametrize("splitk", [0, 1, 3])
 def test_gemm_configurations_agree(hip, cfg, splitk):
     """Every kernel configuration the autotuner may pick (tile x loop variant x tile order, include/mvd_hip.h `cfg`), with and

@@ -44,7 +44,7 @@ def bench(fn, reps):
 
 def main():
     only = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("cfgs=") else None
-    cfgs = [0, 5, 6, 7, 8, 9, 10, 11, 12]
+    cfgs = [0] + list(hip.GEMM_CONFIGS)
     for a in sys.argv[1:]:
         if a.startswith("cfgs="):
             cfgs = [int(c) for c in a[5:].split(",")]
