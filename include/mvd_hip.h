@@ -205,9 +205,11 @@ int mvd_unet_input(const float* x, const float* input_latents, void* out_sp, int
 /* out[r, 0:Ca] = a[r], out[r, Ca:Ca+Cb] = b[r]  (torch.cat([h, hs.pop()], dim=1), unet.py:550) */
 int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_sp, int rows,
                         mvd_stream_t stream); /* out_sp optional: split planes for the 1x1 skip conv */
-/* area pooling by `factor` of vol (B, S, S, D, C) -> (B, S/f, S/f, D, C)  (unet.py:198-209) */
-int mvd_area_pool(const float* vol, void* out_sp, int B, int S, int D, int C, int factor,
-                  mvd_stream_t stream); /* output: split planes (the pooled levels only feed to_k / to_v GEMMs) */
+/* area pooling by `factor` of vol (B, S, S, D, C) -> (B, S/f, S/f, D, C)  (unet.py:198-209).  Output: split planes with
+ * ldp elements per row (0 = C): the pooled levels only feed GEMMs, and with D == 1 they are written straight into the
+ * [attention output | volume features] operand of the merged to_out / cross-attention GEMM (out_sp then points at the
+ * volume columns of that wider buffer). */
+int mvd_area_pool(const float* vol, void* out_sp, int B, int S, int D, int C, int factor, int ldp, mvd_stream_t stream);
 /* out[i] = 0 (memset as a kernel so it is graph-capturable on any stream) */
 int mvd_fill_zero(float* p, size_t n, mvd_stream_t stream);
 

@@ -10,10 +10,18 @@ names; ``run(ctx, x, H, W)`` is the forward pass on channels-last activations (a
 
   GroupNorm -> proj_in GEMM -> LN -> fused QKV GEMM (epilogue writes the split-bf16 attention operands) ->
   flash attention (MFMA) -> to_out GEMM (+bias +residual [+ per-view cross-attention vector]) -> LN ->
-  GEGLU GEMM (gate fused in the epilogue) -> ff-out GEMM (+residual) -> proj_out GEMM (+residual).
+  GEGLU GEMM (gate fused in the epilogue) -> ONE GEMM for ff-out (+residual) followed by proj_out (+residual).
 
 Cross-attention against a length-1 context (the CLIP vector; the D==1 depth sample) is softmax over one key == 1, so
 it reduces exactly to to_out(to_v(ctx)); to_q / to_k / norm2 are dead there and are skipped.
+
+Launch merging by operand concatenation along K (exact algebra; the composed weights are formed once in fp64 and rounded to
+fp32 -- weight preprocessing like packing):
+  * ff-out and proj_out have no nonlinearity between them:  out = (g W2^T + b2 + t) Wp^T + bp + x
+      = [g | t] [Wp W2 | Wp]^T + (Wp b2 + bp) + x      -- the GEGLU epilogue and the producer of t write their planes side by
+    side into one (M, 5C) operand buffer;
+  * ViewAlignedFeatureTransformer with D == 1:  t2b = o Wo^T + bo + t + to_out2(to_v(vol))
+      = [o | vol] [Wo | Wo2 Wv]^T + (bo + bo2) + t     -- the attention kernel writes o next to the level's volume features.
 """
 import torch
 import torch.nn as nn
@@ -63,10 +71,28 @@ class FeedForward(nn.Module):
         self._p = None
 
     def packed(self):
+        """(GEGLU weight, ff-out weight): the second is only used by callers that do not merge it with their proj_out."""
         if self._p is None:
             self._p = (hip.pack_linear(self.net[0].proj.weight, self.net[0].proj.bias, geglu=True),
                        hip.pack_linear(self.net[2].weight, self.net[2].bias))
         return self._p
+
+    def packed_geglu(self):
+        if self._p is not None:
+            return self._p[0]
+        if getattr(self, "_pg", None) is None:
+            self._pg = hip.pack_linear(self.net[0].proj.weight, self.net[0].proj.bias, geglu=True)
+        return self._pg
+
+
+def compose_ff_out_proj(ff, proj_w, proj_b):
+    """[Wp W2 | Wp] (C, 5C) and Wp b2 + bp: ff-out (attention.py:60) followed by proj_out (attention.py:259 /
+    mvdfusion/attention.py:114) as one Linear over the concatenated operand [g | t]."""
+    Wp = proj_w.detach().reshape(proj_w.shape[0], -1).double()
+    W2, b2 = ff.net[2].weight.detach().double(), ff.net[2].bias.detach().double()
+    Wm = torch.cat([Wp @ W2, Wp], dim=1).float().contiguous()
+    bm = (Wp @ b2 + proj_b.detach().double()).float().contiguous()
+    return hip.pack_linear(Wm, bm)
 
 
 class _TransformerCore(nn.Module):
@@ -83,28 +109,32 @@ class _TransformerCore(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.dim, self.n_heads, self.d_head = dim, n_heads, d_head
 
-    def self_attn(self, ctx, t, B, L, tag):
-        """returns t + attn1(norm1(t)) pieces: the attention output `o` (pre to_out)."""
+    def self_attn(self, ctx, t, B, L, tag, o=None):
+        """returns t + attn1(norm1(t)) pieces: the attention output `o` (pre to_out); `o` may be a wider planes buffer whose
+        first C columns receive it."""
         C, M = self.dim, B * L
         ln = ctx.ws.planes(tag + ".ln", M, C)
         ctx.layernorm(t, ln, self.norm1, M, C)
         planes = ctx.ws.attn_planes(B, self.n_heads, L, self.d_head)
         ctx.gemm(ln, self.attn1.packed("qkv"), None, epi=hip.EPI_QKV,
                  qkv=dict(planes=planes, heads=self.n_heads, dhead=self.d_head, L=L))
-        o = ctx.ws.planes(tag + ".o", M, C)
+        if o is None:
+            o = ctx.ws.planes(tag + ".o", M, C)
         hip.attention(planes, o, B, self.n_heads, L, self.d_head, prec=ctx.prec)
         return o
 
-    def feed_forward(self, ctx, t2, M, tag):
+    def cat5(self, ctx, M, tag):
+        """The (M, 5C) operand [g | t] of the merged ff-out / proj_out GEMM: the producer of t fills columns [4C, 5C)."""
+        return ctx.ws.planes(tag + ".cat5", M, 5 * self.dim)
+
+    def feed_forward_proj(self, ctx, t2, cat5, w_merged, x, out, M, tag):
+        """out = proj_out(t2 + ff(norm3(t2))) + x with t2's planes already in cat5[:, 4C:] (see module docstring)."""
         C = self.dim
         ln = ctx.ws.planes(tag + ".ln", M, C)
         ctx.layernorm(t2, ln, self.norm3, M, C)
-        w1, w2 = self.ff.packed()
-        g = ctx.ws.planes(tag + ".g", M, 4 * C)
-        ctx.gemm(ln, w1, None, epi=hip.EPI_GEGLU, out_planes=g)
-        t3 = ctx.ws.planes(tag + ".t3", M, C)          # only consumed by the proj_out GEMM: planes, no fp32 copy
-        ctx.gemm(g, w2, None, res=t2, out_planes=t3)
-        return t3
+        ctx.gemm(ln, self.ff.packed_geglu(), None, epi=hip.EPI_GEGLU, out_planes=cat5)      # columns [0, 4C)
+        ctx.gemm(cat5, w_merged, out, res=x)
+        return out
 
 
 class BasicTransformerBlock(_TransformerCore):
@@ -132,14 +162,14 @@ class SpatialTransformer(nn.Module):
     def packed(self):
         if self._p is None:
             self._p = (hip.pack_linear(self.proj_in.weight, self.proj_in.bias),
-                       hip.pack_linear(self.proj_out.weight, self.proj_out.bias))
+                       compose_ff_out_proj(self.transformer_blocks[0].ff, self.proj_out.weight, self.proj_out.bias))
         return self._p
 
     def run(self, ctx, x, H, W, out=None):
         B, C, L = ctx.B, self.in_channels, H * W
         M = B * L
         tb = self.transformer_blocks[0]
-        w_in, w_out = self.packed()
+        w_in, w_ffproj = self.packed()
         n = ctx.ws.planes("tf.n", M, C)
         ctx.groupnorm(x, n, self.norm, B, L, C, silu=False)
         t = ctx.ws.get("tf.t", (M, C))
@@ -156,12 +186,11 @@ class SpatialTransformer(nn.Module):
             vec = ctx.ws.get("tf.vec", (B, C))
             ctx.gemv_rows(a2.to_out[0].weight, a2.to_out[0].bias, v1, vec)
         t2 = ctx.ws.get("tf.t2", (M, C))
-        ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L)
-        t3 = tb.feed_forward(ctx, t2, M, "tf")
+        cat5 = tb.cat5(ctx, M, "tf")
+        ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L, out_planes=cat5, out_planes_col=4 * C)
         if out is None:
             out = ctx.act((M, C))
-        ctx.gemm(t3, w_out, out, res=x)
-        return out
+        return tb.feed_forward_proj(ctx, t2, cat5, w_ffproj, x, out, M, "tf")
 
 
 class ViewAlignedFeatureTransformer(nn.Module):
@@ -183,29 +212,43 @@ class ViewAlignedFeatureTransformer(nn.Module):
     def packed(self):
         if self._p is None:
             self._p = (hip.pack_linear(self.aligned_attn_proj_in.weight, self.aligned_attn_proj_in.bias),
-                       hip.pack_linear(self.aligned_attn_proj_out.weight, self.aligned_attn_proj_out.bias))
+                       compose_ff_out_proj(self.aligned_attn_transformer_blocks[0].ff, self.aligned_attn_proj_out.weight,
+                                           self.aligned_attn_proj_out.bias))
         return self._p
+
+    def packed_ovol(self):
+        """D == 1: [Wo | Wo2 Wv] (C, C + 768) with bias bo + bo2 -- attn1.to_out and the length-1 cross attention
+        to_out2(to_v(vol)) (mvdfusion/attention.py:52-62) as one Linear over the concatenated operand [o | vol]."""
+        if getattr(self, "_fused", None) is None:
+            tb = self.aligned_attn_transformer_blocks[0]
+            Wo, bo = tb.attn1.to_out[0].weight.detach().double(), tb.attn1.to_out[0].bias.detach().double()
+            Wo2, bo2 = tb.attn2.to_out[0].weight.detach().double(), tb.attn2.to_out[0].bias.detach().double()
+            Wv = tb.attn2.to_v.weight.detach().double()
+            self._fused = hip.pack_linear(torch.cat([Wo, Wo2 @ Wv], dim=1).float().contiguous(), (bo + bo2).float().contiguous())
+        return self._fused
 
     def run(self, ctx, x, H, W, out=None):
         B, C, L, D = ctx.B, self.in_channels, H * W, ctx.D
         M = B * L
         tb = self.aligned_attn_transformer_blocks[0]
-        w_in, w_out = self.packed()
-        vol = ctx.vol_levels[self.level_mapper[H]]            # planes (2, M*D, 768): this view's own depth samples
+        w_in, w_ffproj = self.packed()
+        # D == 1: the level's (M, C + 768) operand buffer [attention output | volume features]; D > 1: plain (M*D, 768) planes
+        vol, vol_col = ctx.vol_levels[self.level_mapper[H]]
         n = ctx.ws.planes("tf.n", M, C)
         ctx.groupnorm(x, n, self.aligned_attn_norm, B, L, C, silu=False)
         t = ctx.ws.get("tf.t", (M, C))
         ctx.gemm(n, w_in, t)
-        o = tb.self_attn(ctx, t, B, L, "tf")
-        t2 = ctx.ws.get("tf.t2", (M, C))
-        ctx.gemm(o, tb.attn1.packed("out"), t2, res=t)
-        a2 = tb.attn2.packed
         t2b = ctx.ws.get("tf.t2b", (M, C))
+        cat5 = tb.cat5(ctx, M, "tf")
         if D == 1:
-            vv = ctx.ws.planes("tf.vv", M, C)
-            ctx.gemm(vol, a2("v"), None, out_planes=vv)
-            ctx.gemm(vv, a2("out"), t2b, res=t2)
+            assert vol_col == C and vol.shape[-1] == 2 * (C + 768), (vol_col, C, vol.shape)
+            tb.self_attn(ctx, t, B, L, "tf", o=vol)            # o -> columns [0, C) of the [o | vol] operand
+            ctx.gemm(vol, self.packed_ovol(), t2b, res=t, out_planes=cat5, out_planes_col=4 * C)
         else:
+            o = tb.self_attn(ctx, t, B, L, "tf")
+            t2 = ctx.ws.get("tf.t2", (M, C))
+            ctx.gemm(o, tb.attn1.packed("out"), t2, res=t)
+            a2 = tb.attn2.packed
             ln2 = ctx.ws.planes("tf.ln", M, C)
             ctx.layernorm(t2, ln2, tb.norm2, M, C)
             q = ctx.ws.get("tf.q2", (M, C))
@@ -216,9 +259,7 @@ class ViewAlignedFeatureTransformer(nn.Module):
             ctx.gemm(vol, a2("v"), v)
             o2 = ctx.ws.planes("tf.o2", M, C)
             hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o2), M, D, tb.n_heads, tb.d_head, hip.stream()))
-            ctx.gemm(o2, a2("out"), t2b, res=t2)
-        t3 = tb.feed_forward(ctx, t2b, M, "tf")
+            ctx.gemm(o2, a2("out"), t2b, res=t2, out_planes=cat5, out_planes_col=4 * C)
         if out is None:
             out = ctx.act((M, C))
-        ctx.gemm(t3, w_out, out, res=x)
-        return out
+        return tb.feed_forward_proj(ctx, t2b, cat5, w_ffproj, x, out, M, "tf")

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ 
 
 // vol (B,S,S,D,C) -> out (B,S/f,S/f,D,C), mean over f x f windows (F.interpolate(mode='area') with integer ratio)
 __global__ __launch_bounds__(256) void area_pool_kernel(const float4* __restrict__ vol, u16* __restrict__ out_sp, int B, int S,
-                                                        int D, int C4, int f) {
+                                                        int D, int C4, int f, int ldp) {
   const int So = S / f;
   const size_t total = (size_t)B * So * So * D * C4;
   const float inv = 1.0f / (float)(f * f);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void area_pool_kernel(const float4* __restrict
         acc.z += v.z;
         acc.w += v.w;
       }
-    store_sp4(out_sp, e / C4, C4 * 4, c * 4, acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    store_sp4(out_sp, e / C4, ldp, c * 4, acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
   }
 }
 
@@ -220,13 +220,16 @@ extern "C" int mvd_concat_channels(const float* a, int Ca, const float* b, int C
   return 0;
 }
 
-extern "C" int mvd_area_pool(const float* vol, void* out_sp, int B, int S, int D, int C, int factor, mvd_stream_t stream) {
+extern "C" int mvd_area_pool(const float* vol, void* out_sp, int B, int S, int D, int C, int factor, int ldp,
+                             mvd_stream_t stream) {
   MVD_CHECK_ARG(vol && out_sp && C % 32 == 0 && B > 0 && S > 0 && D > 0 && C % 4 == 0 && factor >= 1 && S % factor == 0,
                 "mvd_area_pool: bad arguments");
+  if (ldp == 0) ldp = C;
+  MVD_CHECK_ARG(ldp >= C && ldp % 32 == 0 && ((uintptr_t)out_sp & 127) == 0, "mvd_area_pool: ldp=%d must be >= C, %% 32 == 0", ldp);
   const int So = S / factor;
   const size_t total = (size_t)B * So * So * D * (C / 4);
   hipLaunchKernelGGL(area_pool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)vol,
-                     (u16*)out_sp, B, S, D, C / 4, factor);
+                     (u16*)out_sp, B, S, D, C / 4, factor, ldp);
   MVD_CHECK_LAUNCH("mvd_area_pool");
   return 0;
 }

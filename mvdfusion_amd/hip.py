@@ -23,6 +23,7 @@ CAM_RECORD = 20
 TOKEN_DIM, TOKEN_LD = 723, 736
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+c_void_p = C.c_void_p
 
 
 class GemmDesc(C.Structure):
@@ -63,7 +64,7 @@ SIGNATURES = {
     "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_unet_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
-    "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_fill_zero": (_i, [_vp, _sz, _vp]),
     "mvd_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "mvd_advance_iter": (_i, [_vp, _vp]),
@@ -195,7 +196,7 @@ def pack_conv3x3(weight, bias=None):
 # ---------------------------------------------------------------------------------------------
 # packed-weight cache invalidation
 # ---------------------------------------------------------------------------------------------
-_CACHE_ATTRS = ("_p", "_temb", "_xattn", "_head", "_pq", "_q", "_fused")
+_CACHE_ATTRS = ("_p", "_pg", "_temb", "_xattn", "_head", "_pq", "_q", "_fused")
 
 
 def params_signature(module):
@@ -259,10 +260,12 @@ def split_planes(x, out=None, ldp=None):
 
 def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
          bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
-         out_planes=None, cfg=None):
+         out_planes=None, out_planes_col=0, cfg=None):
     """out = epilogue(A @ W^T).  A: split planes (M, 2*K) int16 (dense) or the NHWC image rows (B*H*W, 2*C) with
     conv=dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
-    out: fp32 tensor or None; out_planes: split-planes tensor or None (feeds the next GEMM).
+    out: fp32 tensor or None; out_planes: split-planes tensor or None (feeds the next GEMM); out_planes_col: first column
+    (multiple of 32) of a WIDER planes buffer that receives the output -- the GEMM then fills columns
+    [out_planes_col, out_planes_col + N) of every row and leaves the others alone (operand concatenation along K).
     """
     assert A.dtype == torch.int16, "A must be in split-planes format (see hip.split_planes)"
     d = GemmDesc()
@@ -288,7 +291,8 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.out = out.data_ptr()
         d.ldo = int(ldo if ldo is not None else out.shape[-1])
     if out_planes is not None:
-        d.out_sp = out_planes.data_ptr()
+        assert out_planes_col % 32 == 0 and out_planes.dtype == torch.int16
+        d.out_sp = out_planes.data_ptr() + 4 * int(out_planes_col)     # element (row, k) sits (k >> 5) * 128 bytes into its row
         d.ldp = int(out_planes.shape[-1] // 2)
     d.n_store = W.n_real
     if bias and W.bias is not None:

@@ -337,14 +337,37 @@ class UNetWrapper(nn.Module):
         return self.unet_model.get_cross_attn_parameters(finetune_cross_attn=self.finetune_cross_attn,
                                                          finetune_view_attn=self.finetune_view_attn)
 
-    def volume_pyramid(self, ctx, vol, vol_planes, B, S, D):
-        """get_volume_feats_pyramid (unet.py:198-209): area pooling at x{1, 1/2, 1/4, 1/8}; vol (B,S,S,D,768) fp32
-        and its split-bf16 planes.  Every level is returned as planes (they only feed the to_k / to_v GEMMs)."""
-        levels = [vol_planes]
+    def level_channels(self):
+        """Channel count of the ViewAlignedFeatureTransformers at each pyramid level (resolution S / 2^i)."""
+        u = self.unet_model
+        return [u.model_channels * m for m in u.channel_mult]
+
+    def level0_operand(self, ctx, B, S, D):
+        """The buffer the feature frustum's planes are written to (by GridAttn's last GEMM) and its first column.
+        D == 1: the level-0 [attention output | volume features] operand (rows, C0 + 768) of the merged to_out /
+        cross-attention GEMM (attention.py), volume columns at C0; D > 1: plain (rows * D, 768) planes."""
+        rows = B * S * S * D
+        if D == 1:
+            c0 = self.level_channels()[0]
+            return ctx.ws.get("ovol0", (rows, 2 * (c0 + 768)), torch.int16, zero=True), c0
+        return ctx.ws.get("vol0", (rows, 2 * 768), torch.int16, zero=True), 0
+
+    def volume_pyramid(self, ctx, vol, B, S, D):
+        """get_volume_feats_pyramid (unet.py:198-209): area pooling at x{1, 1/2, 1/4, 1/8}; vol (B,S,S,D,768) fp32, whose
+        planes already sit in level0_operand().  Returns [(planes buffer, first volume column)] per level; the pooled levels
+        only feed GEMMs, so they are written as planes straight into their consumers' operand buffers."""
+        levels = [self.level0_operand(ctx, B, S, D)]
         Cc = vol.shape[-1]
+        chans = self.level_channels()
         for i in range(1, len(self.unet_model.channel_mult)):
             f = 2 ** i
-            o = ctx.ws.planes(f"vol{i}", B * (S // f) * (S // f) * D, Cc)
-            hip.check(hip.lib().mvd_area_pool(hip.ptr(vol), hip.ptr(o), B, S, D, Cc, f, hip.stream()))
-            levels.append(o)
+            rows = B * (S // f) * (S // f) * D
+            if D == 1:
+                ld, col = chans[i] + Cc, chans[i]
+                o = ctx.ws.get(f"ovol{i}", (rows, 2 * ld), torch.int16, zero=True)
+            else:
+                ld, col = Cc, 0
+                o = ctx.ws.planes(f"vol{i}", rows, Cc)
+            hip.check(hip.lib().mvd_area_pool(hip.ptr(vol), hip.c_void_p(o.data_ptr() + 4 * col), B, S, D, Cc, f, ld, hip.stream()))
+            levels.append((o, col))
         return levels

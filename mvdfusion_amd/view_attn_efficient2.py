@@ -123,10 +123,11 @@ class GridAttn(nn.Module):
         return self._p
 
     def run(self, ctx, x, depth_noise, steps, it, cams_rec, in_cam_rec, input_latents, c, vol_out, V, S, D, q0=0, Vq=None,
-            vol_planes=None):
+            vol_planes=None, vol_planes_col=0):
         """x (V,5,S,S) noisy latents; c (1,256) time conditioning (t_embed[:1]); vol_out: (>=V*S*S*D, 768) buffer
         whose first Vq*S*S*D rows receive the feature frustum (row = ((v*S + y)*S + x)*D + d) of the query views
-        [q0, q0+Vq) (all V views by default; a view-parallel rank passes the range it owns)."""
+        [q0, q0+Vq) (all V views by default; a view-parallel rank passes the range it owns).  vol_planes: optional planes
+        buffer receiving the frustum as well, in columns [vol_planes_col, vol_planes_col + 768) of its rows."""
         Vq = V if Vq is None else Vq
         L = hip.lib()
         assert x.shape[1] == 5, "depth wise efficient attention requires 4+1 channels"
@@ -159,5 +160,5 @@ class GridAttn(nn.Module):
         hip.check(L.mvd_view_pool(hip.ptr(h), hip.ptr(wl.weight), hip.ptr(wl.bias), hip.ptr(pool), nseq, V, self.hidden_size,
                                   hip.stream()))
         # the frustum is consumed as fp32 (area pooling) and as planes (level-0 to_k / to_v GEMMs): write both
-        ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes)
+        ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes, out_planes_col=vol_planes_col)
         return vol_out

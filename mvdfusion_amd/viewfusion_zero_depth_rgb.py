@@ -52,7 +52,8 @@ class StepEngine:
         self.in_cam = z(1, hip.CAM_RECORD)
         self.context = z(B, 768)               # rows [V,2V) stay zero: the null branch (unet.py:173)
         self.vol = z(B * S * S * D, 768)       # rows of the null branch stay zero (unet.py:190)
-        self.vol_planes = torch.zeros(B * S * S * D, 2 * 768, dtype=torch.int16, device=dev)   # same, split-planes format
+        # the same as split planes, inside the level-0 operand buffer of the UNet's view-aligned transformers (zero-initialised)
+        self.vol_planes, self.vol_col = model.unet_model.level0_operand(self.ctx, B, S, D)
         self.x_in = torch.zeros(B * S * S, 2 * 32, dtype=torch.int16, device=dev)              # UNet input (split planes)
         self.iter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.steps = z(1, hip.STEP_STRIDE)
@@ -107,7 +108,8 @@ class StepEngine:
         hip.gemv(m.time_embed[2].weight, m.time_embed[2].bias, te1, c)
         # view-aligned features (:303-313)
         m.view_attn.run(ctx, self.x, self.depth_noise, self.steps, self.iter, self.cams, self.in_cam,
-                        self.input_latents, c, self.vol, V, S, D, q0=q0, Vq=Vq, vol_planes=self.vol_planes)
+                        self.input_latents, c, self.vol, V, S, D, q0=q0, Vq=Vq, vol_planes=self.vol_planes,
+                        vol_planes_col=self.vol_col)
         # cc_projection (:322)
         p = m.cc_projection
         c1 = ctx.ws.get("vf.cc1", (Vq, 768))
@@ -121,7 +123,7 @@ class StepEngine:
         hip.check(L.mvd_unet_input(hip.ptr(xq), hip.ptr(self.input_latents), hip.ptr(self.x_in), Vq, S, 32,
                                    int(self.cfg), st()))
         unet = m.unet_model.unet_model
-        ctx.vol_levels = m.unet_model.volume_pyramid(ctx, self.vol.view(B, S, S, D, 768), self.vol_planes, B, S, D)
+        ctx.vol_levels = m.unet_model.volume_pyramid(ctx, self.vol.view(B, S, S, D, 768), B, S, D)
         tsu = ctx.ws.get("vf.tsin_unet", (1, unet.model_channels))
         hip.check(L.mvd_timestep_embedding(hip.ptr(self.steps), hip.ptr(self.iter), hip.ptr(self.funet), hip.ptr(tsu),
                                            unet.model_channels, st()))

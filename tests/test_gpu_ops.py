@@ -61,6 +61,13 @@ def test_gemm_dense(hip, prec, M, N, K):
         op = hip.planes_like(M, N, "cuda")
         hip.gemm(Ap, Wp, None, prec=prec, res=Rc, workspace=ws, out_planes=op)
         assert rel_err(planes_to_float(op), ref) < TOL[prec] + PL
+        # ... into columns [32, 32 + N) of a wider operand buffer (operand concatenation along K), fp32 output alongside
+        wide = hip.split_planes(torch.full((M, N + 96), -3.0, device="cuda"))
+        out.zero_()
+        hip.gemm(Ap, Wp, out, prec=prec, res=Rc, workspace=ws, out_planes=wide, out_planes_col=32)
+        got = planes_to_float(wide)
+        assert rel_err(got[:, 32:32 + N], ref) < TOL[prec] + PL and rel_err(out, ref) < TOL[prec]
+        assert bool((got[:, :32] == -3.0).all()) and bool((got[:, 32 + N:] == -3.0).all())
 
 
 @pytest.mark.skipif(_BF, reason="the bf16 flavour has fp32's exponent range")
@@ -354,8 +361,15 @@ def test_area_pool_concat_input(hip):
         ref = F.interpolate(v, scale_factor=1.0 / f, mode="area").reshape(B, D, C, S // f, S // f).permute(0, 3, 4, 1, 2)
         out = hip.planes_like(B * (S // f) * (S // f) * D, C, "cuda")
         volc = vol.cuda()
-        hip.check(hip.lib().mvd_area_pool(hip.ptr(volc), hip.ptr(out), B, S, D, C, f, hip.stream()))
+        hip.check(hip.lib().mvd_area_pool(hip.ptr(volc), hip.ptr(out), B, S, D, C, f, 0, hip.stream()))
         assert rel_err(planes_to_float(out).view(B, S // f, S // f, D, C), ref) < PL
+        # into columns [64, 64 + C) of a wider operand buffer (ldp = C + 96); the other columns are left alone
+        rows, ld = B * (S // f) * (S // f) * D, C + 96
+        wide = hip.split_planes(torch.full((rows, ld), 7.0, device="cuda"))
+        hip.check(hip.lib().mvd_area_pool(hip.ptr(volc), hip.c_void_p(wide.data_ptr() + 4 * 64), B, S, D, C, f, ld, hip.stream()))
+        got = planes_to_float(wide)
+        assert rel_err(got[:, 64:64 + C].reshape(B, S // f, S // f, D, C), ref) < PL
+        assert bool((got[:, :64] == 7.0).all()) and bool((got[:, 64 + C:] == 7.0).all())
     a, b = torch.randn(100, 320, generator=g(91)), torch.randn(100, 640, generator=g(92))
     out = torch.empty(100, 960, device="cuda")
     ac, bc = a.cuda(), b.cuda()
