@@ -243,6 +243,22 @@ int mvd_gridattn_tokens(const float* x, const float* depth_noise, const float* s
                         const float* feat, const float* in_feat, const float* cams, const float* in_cam,
                         void* tokens_sp, int V, int q0, int Vq, int S, int D, float depth_scale, float depth_shift,
                         mvd_stream_t stream);
+/* Fused G1-G4 (:269-397): tokens are generated in registers and pushed through pre_layer_b, the 3 DiTBlocks over the V views,
+ * and the weight_layer softmax pooling in ONE launch; output = the pooled (Vq*S*S*D, 256) rows as split planes (the final
+ * Linear 256->768 is a plain mvd_gemm).  V must divide 16 (1, 2, 4, 8, 16: a wavefront owns 16 token rows = 16/V points);
+ * other view counts use the unfused kernels above / below.
+ *   wstream : the aggregation weights as fp16 (bf16) hi + lo in the kernel's consumption order, mvd_gridattn_fused_slots()
+ *             slots of 32 KiB (layout: csrc/gridattn_fused.hip header; packer: mvdfusion_amd/view_attn_efficient2.py)
+ *   vecs    : mvd_gridattn_fused_vec_floats() floats -- per DiT block [adaLN modulation of this step 1536 | b_qkv 768 |
+ *             b_proj 256 | b_fc1 512 | b_fc2 256], then [b_pre 256 | weight_layer.w 256 | weight_layer.b 1 ... accumulator
+ *             scales at +520: pre, then (qkv, proj, fc1, fc2) per block] */
+int mvd_gridattn_fused_slots(void);
+size_t mvd_gridattn_fused_stream_bytes(void);
+size_t mvd_gridattn_fused_vec_floats(void);
+int mvd_gridattn_fused(const float* x, const float* depth_noise, const float* steps, const int* iter, const float* grid_lin,
+                       const float* feat, const float* in_feat, const float* cams, const float* in_cam, const void* wstream,
+                       const float* vecs, void* pooled_sp, int V, int q0, int Vq, int S, int D, float depth_scale,
+                       float depth_shift, mvd_stream_t stream);
 /* timm Attention core over the V reference views (:52): qkv (Nseq*V, 3*heads*dhead) -> out (Nseq*V, heads*dhead) */
 int mvd_view_mha(const float* qkv, void* out_sp, int Nseq, int V, int heads, int dhead,
                  mvd_stream_t stream); /* output: split planes */

@@ -1,0 +1,615 @@
+// Fused cross-view aggregation of GridAttn (mvdfusion/view_attn_efficient2.py:269-410): ONE launch per step does
+//   G1-G3  depth sample -> unproject -> reproject into the V reference views and the input view -> bilinear gather ->
+//          Plucker / harmonic embeddings          (the 723-wide token never leaves registers)
+//   G4     Linear 723->256 + GELU, 3 x DiTBlock over the V views (adaLN-modulated LN, qkv, 8-head attention over V, proj,
+//          MLP 256->512->256, gated residuals), weight_layer softmax over V, weighted sum
+// and writes the pooled (Nseq, 256) rows as split planes for the last Linear 256->768 (a plain mvd_gemm).
+//
+// Mapping.  Token rows are ordered ((query view, pixel, depth sample), reference view): V consecutive rows = one 3-D point =
+// one attention sequence.  A wavefront owns 16 consecutive rows for the whole kernel; a workgroup is 4 wavefronts (64 rows).
+// Activations never touch LDS or HBM: every GEMM is computed as  out^T = W x^T  (MFMA A operand = 16 weight rows, B operand =
+// the wave's 16 activation rows), so a lane holds, for row (lane & 15), four consecutive output channels 16j + 4(lane>>4) + r
+// of each 16-channel tile j -- exactly the register image of the NEXT GEMM's B fragment once the weight k-order inside
+// every 32-block is permuted to (4g + r | 16 + 4g + r) at pack time.  LayerNorm / softmax / pooling statistics are a few
+// cross-lane shuffles.  The value projection is computed un-transposed (A = activations) so that V^T is directly the A
+// fragment of  O^T = V^T P^T  (16x16x16 MFMA), and S^T = K Q^T lands in the B-fragment layout of that MFMA.
+//
+// Weights (13 MB as fp16 hi + lo) are pre-packed on the host into ONE linear stream of 32 KiB slots in exactly the order
+// the kernel consumes them (mvdfusion_amd/view_attn_efficient2.py: pack_fused_stream), already in the swizzled LDS image,
+// so staging is a plain LDS-DMA copy (global_load_lds_dwordx4) into a 3-slot ring, two slots in flight ahead of the
+// consumer, one `s_waitcnt vmcnt(8)` + barrier per slot (64 MFMAs per wave).  The small vectors (adaLN modulation of this
+// step, biases, weight_layer) are DMA'd once into LDS, so the main loop issues no ordinary global load (those would drain
+// the DMA queue at their vmcnt(0)).
+#include "gridattn_common.hpp"
+
+namespace {
+
+constexpr int G4_RING_SLOTS = 3;
+constexpr int G4_SLOT_BYTES = 32768;                   // 16 micro-tiles (16 weight rows x 32 k, hi | lo = 2 KiB)
+constexpr int G4_VEC_BLOCK = 3328;                     // floats per DiT block: mod 1536 | b_qkv 768 | b_proj 256 | b_fc1 512 | b_fc2 256
+constexpr int G4_VEC_MISC = 3 * G4_VEC_BLOCK;          // b_pre 256 | weight_layer w 256 | weight_layer b (1) ... | acc scales at +520
+constexpr int G4_VEC_GRANULES = 44;                    // 44 KiB staged (11264 floats; 11008 used)
+constexpr int G4_SMEM = G4_RING_SLOTS * G4_SLOT_BYTES + G4_VEC_GRANULES * 1024;
+
+#ifdef MVD_OPERAND_BF16
+typedef __attribute__((ext_vector_type(4))) short op4_t;     // mfma_f32_16x16x16bf16_1k takes 4 x i16
+#define MVD_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+#else
+typedef __attribute__((ext_vector_type(4))) _Float16 op4_t;
+#define MVD_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0)
+#endif
+
+struct G4Params {
+  const float *x, *depth_noise, *steps;
+  const int* iter;
+  const float *grid_lin, *feat, *in_feat, *cams, *in_cam;
+  const unsigned char* wstream;   // nslots x 32 KiB
+  const float* vecs;              // G4_VEC_GRANULES * 256 floats
+  u16* pooled_sp;                 // (Nseq, 256) split planes
+  int V, q0, Vq, S, D, nslots;
+  float depth_scale, depth_shift;
+};
+
+struct Frag {   // one MFMA operand fragment (8 elements) as hi + lo
+  bf16x8 hi, lo;
+};
+
+__device__ __forceinline__ Frag make_frag(const float (&v)[8]) {
+  Frag f;
+  union { bf16x8 v; u16 e[8]; } H, L;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split_bf16(v[j], H.e[j], L.e[j]);
+  f.hi = H.v;
+  f.lo = L.v;
+  return f;
+}
+__device__ __forceinline__ Frag make_frag(const f32x4& a, const f32x4& b) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return make_frag(v);
+}
+
+// acc += W^T-style product with all four partial products, same term order as gemm.hip (lo*lo, lo*hi, hi*lo, hi*hi with the
+// activation as the first factor)
+__device__ __forceinline__ void mma_lolo(f32x4& acc, const Frag& w, const Frag& x) { acc = MVD_MFMA_16x16x32(w.lo, x.lo, acc, 0, 0, 0); }
+__device__ __forceinline__ void mma_lohi(f32x4& acc, const Frag& w, const Frag& x) { acc = MVD_MFMA_16x16x32(w.hi, x.lo, acc, 0, 0, 0); }
+__device__ __forceinline__ void mma_hilo(f32x4& acc, const Frag& w, const Frag& x) { acc = MVD_MFMA_16x16x32(w.lo, x.hi, acc, 0, 0, 0); }
+__device__ __forceinline__ void mma_hihi(f32x4& acc, const Frag& w, const Frag& x) { acc = MVD_MFMA_16x16x32(w.hi, x.hi, acc, 0, 0, 0); }
+// un-transposed product (A = activations, B = weights): D[activation row][weight row]
+__device__ __forceinline__ void mmu_lolo(f32x4& acc, const Frag& w, const Frag& x) { acc = MVD_MFMA_16x16x32(x.lo, w.lo, acc, 0, 0, 0); }
+__device__ __forceinline__ void mmu_lohi(f32x4& acc, const Frag& w, const Frag& x) { acc = MVD_MFMA_16x16x32(x.lo, w.hi, acc, 0, 0, 0); }
+__device__ __forceinline__ void mmu_hilo(f32x4& acc, const Frag& w, const Frag& x) { acc = MVD_MFMA_16x16x32(x.hi, w.lo, acc, 0, 0, 0); }
+__device__ __forceinline__ void mmu_hihi(f32x4& acc, const Frag& w, const Frag& x) { acc = MVD_MFMA_16x16x32(x.hi, w.hi, acc, 0, 0, 0); }
+
+struct Taps {   // grid_sample(bilinear, border, align_corners=True): pixel offsets (in floats, 256 channels / pixel) and weights
+  int o[4];
+  float w[4];
+};
+
+__device__ __forceinline__ Taps make_taps(int S, float gx, float gy) {
+  float ix = ((gx + 1.f) / 2.f) * (float)(S - 1);
+  float iy = ((gy + 1.f) / 2.f) * (float)(S - 1);
+  ix = fminf(fmaxf(ix, 0.f), (float)(S - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(S - 1));
+  if (!(ix == ix)) ix = 0.f;
+  if (!(iy == iy)) iy = 0.f;
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const int x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - x0f, wy1 = iy - y0f;
+  const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy;
+  Taps t;
+  const int ys[4] = {y0, y0, y1, y1}, xs[4] = {x0, x1, x0, x1};
+  const float ws[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool ok = ys[k] < S && xs[k] < S;
+    t.o[k] = ok ? (ys[k] * S + xs[k]) * 256 : 0;
+    t.w[k] = ok ? ws[k] : 0.f;      // bilinear4() skips such taps; a zero weight on an in-range pixel adds exactly 0
+  }
+  return t;
+}
+
+__device__ __forceinline__ f32x4 gather4(const float* __restrict__ fmap, const Taps& t, int ch) {
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 v = *(const float4*)(fmap + t.o[k] + ch);
+    o[0] += v.x * t.w[k];
+    o[1] += v.y * t.w[k];
+    o[2] += v.z * t.w[k];
+    o[3] += v.w * t.w[k];
+  }
+  return o;
+}
+
+// sin / cos with fp32-level accuracy for the embedding arguments (|a| <~ 30 rad), branch-free and small enough to be
+// unrolled 56x per lane (ocml's sinf / cosf carry a large-argument path that drags scratch memory in): three-constant
+// Cody-Waite reduction by pi/2 + the Cephes single-precision minimax polynomials on [-pi/4, pi/4] (~1 ulp).
+__device__ __forceinline__ float sincos_sel(float a, bool want_cos) {
+  const float k = rintf(a * 0.63661977236758134308f);
+  float r = __builtin_fmaf(-k, 1.5703125f, a);
+  r = __builtin_fmaf(-k, 4.837512969970703125e-4f, r);
+  r = __builtin_fmaf(-k, 7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                                  __builtin_fmaf(-0.5f, z, 1.0f));
+  const int q = ((int)k + (want_cos ? 1 : 0)) & 3;        // cos(a) = sin(a + pi/2)
+  const float v = (q & 1) ? cp : sp;
+  return (q & 2) ? -v : v;
+}
+
+// harmonic embedding element e of [sin(dim*7) | cos(dim*7) | x(dim)] without runtime-indexed arrays
+struct Vec6 {   // named members (not an array): the selects below must stay selects, not become a runtime-indexed load
+  float a, b, c, d, e, f;
+};
+__device__ __forceinline__ float pick6(float a, float b, float c, float d, float e, float f, int i) {   // by VALUE: SSA, never memory
+  float r = a;
+  r = i == 1 ? b : r;
+  r = i == 2 ? c : r;
+  r = i == 3 ? d : r;
+  r = i == 4 ? e : r;
+  r = i == 5 ? f : r;
+  return r;
+}
+// token columns 512 + e: [ref plucker 90 | ref depth 15 | query plucker 90 | query depth 15 | 1 | zero pad]; each 105-block is
+// [6-vector: sin 42 | cos 42 | x 6][scalar: sin 7 | cos 7 | x 1], harmonic index = dim * 7 + k, omega_k = 0.1 * 2^k
+__device__ __forceinline__ float token_embedding(Vec6 rpl, float rdep, Vec6 qpl, float qdep, int e) {
+  if (e >= 210) return e == 210 ? 1.0f : 0.0f;
+  const bool query = e >= 105;
+  const int i = query ? e - 105 : e;                     // index inside one 105-block
+  const bool scalar = i >= 90;
+  const int j = scalar ? i - 90 : i;                     // index inside the 90- or 15-value harmonic embedding
+  const int n = scalar ? 7 : 42;                         // number of sin (= cos) entries
+  const bool raw = j >= 2 * n;
+  const int jj = j < n ? j : j - n;
+  const int di = raw ? j - 2 * n : jj / 7;
+  const int k = jj - (jj / 7) * 7;
+  const float c6 = pick6(query ? qpl.a : rpl.a, query ? qpl.b : rpl.b, query ? qpl.c : rpl.c, query ? qpl.d : rpl.d,
+                         query ? qpl.e : rpl.e, query ? qpl.f : rpl.f, di);
+  const float comp = scalar ? (query ? qdep : rdep) : c6;
+  const float sc = sincos_sel(comp * (0.1f * (float)(1 << k)), j >= n);
+  return raw ? comp : sc;
+}
+
+template <int N>
+__device__ __forceinline__ void g4_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory");
+}
+
+__global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[G4_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const float* svec = (const float*)(smem + G4_RING_SLOTS * G4_SLOT_BYTES);
+  const int V = p.V, S = p.S, D = p.D, SS = S * S;
+
+  // ------------------------------------------------------------------ LDS-DMA engine
+  const unsigned char* wsrc = p.wstream + (size_t)wave * 8192 + lane * 16;   // this wave copies granules [8 wave, 8 wave + 8) of a slot
+  int s_issue = 0;                 // next slot to stage
+  auto issue_slot = [&]() {
+    if (s_issue < p.nslots) {
+      unsigned char* dst = smem + (s_issue % G4_RING_SLOTS) * G4_SLOT_BYTES + wave * 8192;
+      const unsigned char* src = wsrc + (size_t)s_issue * G4_SLOT_BYTES;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+    ++s_issue;
+  };
+  {   // the small vectors: 44 granules, 11 per wave
+    const unsigned char* vsrc = (const unsigned char*)p.vecs + (size_t)wave * 11 * 1024 + lane * 16;
+    unsigned char* vdst = smem + G4_RING_SLOTS * G4_SLOT_BYTES + wave * 11 * 1024;
+#pragma unroll
+    for (int i = 0; i < 11; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(vdst + i * 1024), 16, 0, 0);
+  }
+  issue_slot();
+  issue_slot();
+  int s_cur = 0;                   // slot being consumed
+  // returns the LDS base of slot s_cur once it has landed for every wave, and stages slot s_cur + 2 into the ring position
+  // that slot s_cur - 1 occupied (every wave has passed its last read of it: lgkmcnt(0) before the barrier)
+  auto acquire = [&]() -> const unsigned char* {
+    if (s_cur + 1 < p.nslots) g4_wait_barrier<8>();
+    else g4_wait_barrier<0>();
+    issue_slot();
+    const unsigned char* base = smem + (s_cur % G4_RING_SLOTS) * G4_SLOT_BYTES;
+    ++s_cur;
+    return base;
+  };
+  // fragment read offsets inside a 2 KiB micro-tile (same swizzle as gemm.hip): row R = lane & 15, 16-byte chunk g (hi) / 4 + g (lo)
+  const int fsw = (r16 >> 1) & 7;
+  const int fbase = (r16 >> 3) * 1024 + (r16 & 7) * 128;
+  const int foff_hi = fbase + ((g) ^ fsw) * 16;
+  const int foff_lo = fbase + ((4 + g) ^ fsw) * 16;
+  auto read_w = [&](const unsigned char* slot, int mt) -> Frag {
+    Frag f;
+    f.hi = *(const bf16x8*)(slot + mt * 2048 + foff_hi);
+    f.lo = *(const bf16x8*)(slot + mt * 2048 + foff_lo);
+    return f;
+  };
+
+  // ------------------------------------------------------------------ G1-G3: this lane's row of the token matrix
+  const size_t t_row = (size_t)blockIdx.x * 64 + wave * 16 + r16;
+  const size_t pt = t_row / V;
+  const int vr = (int)(t_row - pt * V);
+  const int d = (int)(pt % D);
+  const int pix = (int)((pt / D) % SS);
+  const int b = p.q0 + (int)(pt / ((size_t)D * SS));
+  // geometry of this lane's row: world point, Plucker coordinates, bilinear taps in the reference view and the input view
+  Vec6 qpl, rpl;
+  float rdep, depth;
+  Taps tr, ti;
+  {
+    const int it = p.iter[0];
+    const float sqrt_ac = p.steps[(size_t)it * MVD_STEP_STRIDE + 1];
+    const float dstd = p.steps[(size_t)it * MVD_STEP_STRIDE + 2];
+    const float dch = p.x[((size_t)b * 5 + 4) * SS + pix] / sqrt_ac;
+    const float smp = dch + dstd * p.depth_noise[(((size_t)it * V + b) * D + d) * SS + pix];
+    depth = fminf(fmaxf((smp + 1.0f) / 2.0f, 0.f), 1.f) * p.depth_scale + p.depth_shift;
+    const Cam cb = load_cam(p.cams + (size_t)b * MVD_CAM_RECORD);
+    const float ndx = p.grid_lin[pix % S], ndy = p.grid_lin[pix / S];
+    float p1[3], p2[3], dir[3], org[3], X[3];
+    unproject(cb, ndx, ndy, 1.f, p1);
+    unproject(cb, ndx, ndy, 2.f, p2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dir[j] = p2[j] - p1[j];
+      org[j] = p1[j] - dir[j];
+      X[j] = org[j] + depth * dir[j];
+    }
+    {
+      const float nrm = fmaxf(sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]), 1e-12f);
+      qpl.a = dir[0] / nrm;
+      qpl.b = dir[1] / nrm;
+      qpl.c = dir[2] / nrm;
+      qpl.d = cb.C[1] * qpl.c - cb.C[2] * qpl.b;
+      qpl.e = cb.C[2] * qpl.a - cb.C[0] * qpl.c;
+      qpl.f = cb.C[0] * qpl.b - cb.C[1] * qpl.a;
+    }
+    const Cam cv = load_cam(p.cams + (size_t)vr * MVD_CAM_RECORD);
+    {
+      const float rd[3] = {X[0] - cv.C[0], X[1] - cv.C[1], X[2] - cv.C[2]};
+      const float nr = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
+      rdep = nr;
+      const float nn = fmaxf(nr, 1e-12f);
+      rpl.a = rd[0] / nn;
+      rpl.b = rd[1] / nn;
+      rpl.c = rd[2] / nn;
+      rpl.d = cv.C[1] * rpl.c - cv.C[2] * rpl.b;
+      rpl.e = cv.C[2] * rpl.a - cv.C[0] * rpl.c;
+      rpl.f = cv.C[0] * rpl.b - cv.C[1] * rpl.a;
+    }
+    {
+      float u, v;
+      project(cv, X, u, v);
+      tr = make_taps(S, -u, -v);
+      const Cam ci = load_cam(p.in_cam);
+      project(ci, X, u, v);
+      ti = make_taps(S, -u, -v);
+    }
+  }
+  const float* fref = p.feat + (size_t)vr * SS * 256;
+  // ------------------------------------------------------------------ pre_layer: Linear(723 -> 256) + GELU
+  f32x4 h[16];          // residual stream: tile j = channels 16j + 4g + r of row r16
+  f32x4 acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // one slot = the 16 output tiles of one k-step, in groups of 4 tiles (four independent accumulators per MFMA burst)
+  auto slot_16tiles = [&](const Frag& xf) {
+    const unsigned char* sl = acquire();
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      Frag w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = read_w(sl, gq * 4 + q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mma_lolo(acc[gq * 4 + q], w[q], xf);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mma_lohi(acc[gq * 4 + q], w[q], xf);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mma_hilo(acc[gq * 4 + q], w[q], xf);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mma_hihi(acc[gq * 4 + q], w[q], xf);
+    }
+  };
+  // The token fragments are produced in chunks of four k-steps right before they are consumed (all 23 at once would not fit
+  // the register file); the ordinary loads of a chunk wait at vmcnt(0), i.e. once per chunk the two prefetched weight slots
+  // simply finish landing first.
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    Frag tk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ks = (c4 & 1) * 4 + q;
+      const float* fm = c4 < 2 ? fref : p.in_feat;
+      const Taps& tp = c4 < 2 ? tr : ti;
+      tk[q] = make_frag(gather4(fm, tp, 32 * ks + 4 * g), gather4(fm, tp, 32 * ks + 16 + 4 * g));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) slot_16tiles(tk[q]);
+  }
+  // embedding columns 512 .. 735: [ref plucker 90 | ref depth 15 | query plucker 90 | query depth 15 | 1 | 0 x 13]
+#pragma unroll
+  for (int ks = 0; ks < 7; ++ks) {
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+      v[jj] = token_embedding(rpl, rdep, qpl, depth, 32 * ks + (jj < 4 ? 4 * g + jj : 16 + 4 * g + jj - 4));
+    slot_16tiles(make_frag(v));
+  }
+  {
+    const float sc = svec[G4_VEC_MISC + 520];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float4 bb = *(const float4*)(svec + G4_VEC_MISC + 16 * j + 4 * g);
+      h[j][0] = gelu_erf(acc[j][0] * sc + bb.x);
+      h[j][1] = gelu_erf(acc[j][1] * sc + bb.y);
+      h[j][2] = gelu_erf(acc[j][2] * sc + bb.z);
+      h[j][3] = gelu_erf(acc[j][3] * sc + bb.w);
+    }
+  }
+
+  // LayerNorm (eps 1e-6, no affine) + adaLN modulate of the wave's 16 rows -> the 8 B fragments of the next GEMM
+  Frag xf[8];
+  auto ln_modulate = [&](const float* shift, const float* scale) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += (h[j][0] + h[j][1]) + (h[j][2] + h[j][3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / 256.0f;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float a = h[j][0] - mean, b2 = h[j][1] - mean, c = h[j][2] - mean, d2 = h[j][3] - mean;
+      q += (a * a + b2 * b2) + (c * c + d2 * d2);
+    }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q / 256.0f + 1e-6f);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int j = 2 * ks + half;
+        const float4 sc4 = *(const float4*)(scale + 16 * j + 4 * g), sh4 = *(const float4*)(shift + 16 * j + 4 * g);
+        v[4 * half + 0] = (h[j][0] - mean) * rstd * (sc4.x + 1.f) + sh4.x;
+        v[4 * half + 1] = (h[j][1] - mean) * rstd * (sc4.y + 1.f) + sh4.y;
+        v[4 * half + 2] = (h[j][2] - mean) * rstd * (sc4.z + 1.f) + sh4.z;
+        v[4 * half + 3] = (h[j][3] - mean) * rstd * (sc4.w + 1.f) + sh4.w;
+      }
+      xf[ks] = make_frag(v);
+    }
+  };
+  // h += gate * (acc * acc_scale + bias), then clear acc
+  auto gated_residual = [&](const float* gate, const float* bias, float sc) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float4 g4 = *(const float4*)(gate + 16 * j + 4 * g), b4 = *(const float4*)(bias + 16 * j + 4 * g);
+      h[j][0] += g4.x * (acc[j][0] * sc + b4.x);
+      h[j][1] += g4.y * (acc[j][1] * sc + b4.y);
+      h[j][2] += g4.z * (acc[j][2] * sc + b4.z);
+      h[j][3] += g4.w * (acc[j][3] * sc + b4.w);
+      acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ------------------------------------------------------------------ 3 x DiTBlock (view_attn_efficient2.py:42-67)
+  for (int blk = 0; blk < 3; ++blk) {
+    const float* vb = svec + blk * G4_VEC_BLOCK;
+    const float* mod = vb;                 // shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
+    const float sc_qkv = svec[G4_VEC_MISC + 521 + blk * 4], sc_proj = svec[G4_VEC_MISC + 522 + blk * 4];
+    const float sc_fc1 = svec[G4_VEC_MISC + 523 + blk * 4], sc_fc2 = svec[G4_VEC_MISC + 524 + blk * 4];
+    ln_modulate(mod, mod + 256);
+    // ---- attention over the V views, head by head: qkv (3 slots) then this head's slice of proj (1 slot)
+    for (int hd = 0; hd < 8; ++hd) {
+      f32x4 qkv[6];      // q0 q1 k0 k1 (transposed layout: row r16, d = 16j + 4g + r) | v0 v1 (row 4g + r, d = 16j + r16)
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6) qkv[t6] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sl3 = 0; sl3 < 3; ++sl3) {
+        const unsigned char* sl = acquire();
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          Frag w[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[q] = read_w(sl, gq * 4 + q);
+          // micro-tile index within the head phase: mt = 16 sl3 + 4 gq + q -> k-step mt / 6, tile mt % 6
+#pragma unroll
+          for (int term = 0; term < 4; ++term) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int mt = 16 * sl3 + 4 * gq + q;
+              const int ks = mt / 6, t6 = mt - ks * 6;
+              if (t6 < 4) {
+                if (term == 0) mma_lolo(qkv[t6], w[q], xf[ks]);
+                if (term == 1) mma_lohi(qkv[t6], w[q], xf[ks]);
+                if (term == 2) mma_hilo(qkv[t6], w[q], xf[ks]);
+                if (term == 3) mma_hihi(qkv[t6], w[q], xf[ks]);
+              } else {
+                if (term == 0) mmu_lolo(qkv[t6], w[q], xf[ks]);
+                if (term == 1) mmu_lohi(qkv[t6], w[q], xf[ks]);
+                if (term == 2) mmu_hilo(qkv[t6], w[q], xf[ks]);
+                if (term == 3) mmu_hihi(qkv[t6], w[q], xf[ks]);
+              }
+            }
+          }
+        }
+      }
+      // bias (+ scale on q): timm Attention q = (x Wq^T + bq) * hd^-0.5
+      const float* bq = vb + 1536 + 32 * hd;
+      const float* bk = vb + 1536 + 256 + 32 * hd;
+      const float* bv = vb + 1536 + 512 + 32 * hd;
+      const float qs = 0.17677669529663687f;       // 32^-0.5
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float4 b4q = *(const float4*)(bq + 16 * j + 4 * g), b4k = *(const float4*)(bk + 16 * j + 4 * g);
+        const float bvv = bv[16 * j + r16];
+        const float bqa[4] = {b4q.x, b4q.y, b4q.z, b4q.w}, bka[4] = {b4k.x, b4k.y, b4k.z, b4k.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qkv[j][r] = (qkv[j][r] * sc_qkv + bqa[r]) * qs;
+          qkv[2 + j][r] = qkv[2 + j][r] * sc_qkv + bka[r];
+          qkv[4 + j][r] = qkv[4 + j][r] * sc_qkv + bvv;
+        }
+      }
+      // S^T[key][query] = sum_d K[key][d] Q[query][d]   (one 16x16x32 MFMA per partial product)
+      const Frag kf = make_frag(qkv[2], qkv[3]), qf = make_frag(qkv[0], qkv[1]);
+      f32x4 st = {0.f, 0.f, 0.f, 0.f};
+      st = MVD_MFMA_16x16x32(kf.lo, qf.lo, st, 0, 0, 0);
+      st = MVD_MFMA_16x16x32(kf.lo, qf.hi, st, 0, 0, 0);
+      st = MVD_MFMA_16x16x32(kf.hi, qf.lo, st, 0, 0, 0);
+      st = MVD_MFMA_16x16x32(kf.hi, qf.hi, st, 0, 0, 0);
+      // lane holds keys 4g + r of query r16; only keys of the query's own 3-D point (same group of V rows) take part
+      float mx = -INFINITY;
+      bool ok[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ok[r] = (4 * g + r) / V == r16 / V;
+        if (ok[r]) mx = fmaxf(mx, st[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float den = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[r] = ok[r] ? expf(st[r] - mx) : 0.f;
+        den += st[r];
+      }
+      den += __shfl_xor(den, 16, 64);
+      den += __shfl_xor(den, 32, 64);
+      // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]   (16x16x16 MFMA; A = V^T fragment = the un-transposed v tile)
+      op4_t ph, pl;
+      {
+        union { op4_t v; u16 e[4]; } H, L;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) split_bf16(st[r] / den, H.e[r], L.e[r]);
+        ph = H.v;
+        pl = L.v;
+      }
+      f32x4 ot[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        union { op4_t v; u16 e[4]; } H, L;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) split_bf16(qkv[4 + j][r], H.e[r], L.e[r]);
+        ot[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ot[j] = MVD_MFMA_16x16x16(L.v, pl, ot[j]);
+        ot[j] = MVD_MFMA_16x16x16(L.v, ph, ot[j]);
+        ot[j] = MVD_MFMA_16x16x16(H.v, pl, ot[j]);
+        ot[j] = MVD_MFMA_16x16x16(H.v, ph, ot[j]);
+      }
+      // proj: this head's 32 input channels are k-step hd of W_proj
+      const Frag of = make_frag(ot[0], ot[1]);
+      slot_16tiles(of);
+    }
+    gated_residual(mod + 512, vb + 2304, sc_proj);
+    // ---- MLP 256 -> 512 (GELU) -> 256 in chunks of 64 hidden channels: fc1 chunk (2 slots) then its two k-steps of fc2 (2 slots)
+    ln_modulate(mod + 768, mod + 1024);
+    for (int ch = 0; ch < 8; ++ch) {
+      f32x4 f1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) f1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sl2 = 0; sl2 < 2; ++sl2) {
+        const unsigned char* sl = acquire();
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {     // group = one k-step, the chunk's four 16-channel tiles
+          Frag w[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[q] = read_w(sl, gq * 4 + q);
+          const int ks = 4 * sl2 + gq;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mma_lolo(f1[q], w[q], xf[ks]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mma_lohi(f1[q], w[q], xf[ks]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mma_hilo(f1[q], w[q], xf[ks]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mma_hihi(f1[q], w[q], xf[ks]);
+        }
+      }
+      const float* b1 = vb + 2560 + 64 * ch;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *(const float4*)(b1 + 16 * q + 4 * g);
+        f1[q][0] = gelu_erf(f1[q][0] * sc_fc1 + b4.x);
+        f1[q][1] = gelu_erf(f1[q][1] * sc_fc1 + b4.y);
+        f1[q][2] = gelu_erf(f1[q][2] * sc_fc1 + b4.z);
+        f1[q][3] = gelu_erf(f1[q][3] * sc_fc1 + b4.w);
+      }
+      slot_16tiles(make_frag(f1[0], f1[1]));
+      slot_16tiles(make_frag(f1[2], f1[3]));
+    }
+    gated_residual(mod + 1280, vb + 3072, sc_fc2);
+  }
+
+  // ------------------------------------------------------------------ weight_layer + softmax over V + weighted sum (:83,396-397)
+  {
+    const float* wl = svec + G4_VEC_MISC + 256;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float4 w4 = *(const float4*)(wl + 16 * j + 4 * g);
+      part += h[j][0] * w4.x + h[j][1] * w4.y + h[j][2] * w4.z + h[j][3] * w4.w;
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    const float lg = part + svec[G4_VEC_MISC + 512];
+    // the V rows of a point are V consecutive lanes (r16): reduce over the low log2(V) lane bits
+    float mx = lg;
+    for (int o = 1; o < V; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float e = expf(lg - mx);
+    float den = e;
+    for (int o = 1; o < V; o <<= 1) den += __shfl_xor(den, o, 64);
+    const float pw = e / den;
+    const size_t prow = t_row / V;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float v0 = h[j][0] * pw, v1 = h[j][1] * pw, v2 = h[j][2] * pw, v3 = h[j][3] * pw;
+      for (int o = 1; o < V; o <<= 1) {
+        v0 += __shfl_xor(v0, o, 64);
+        v1 += __shfl_xor(v1, o, 64);
+        v2 += __shfl_xor(v2, o, 64);
+        v3 += __shfl_xor(v3, o, 64);
+      }
+      if (vr == 0) store_sp4(p.pooled_sp, prow, 256, 16 * j + 4 * g, v0, v1, v2, v3);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mvd_gridattn_fused_slots(void) { return 23 + 3 * 64; }
+extern "C" size_t mvd_gridattn_fused_stream_bytes(void) { return (size_t)(23 + 3 * 64) * G4_SLOT_BYTES; }
+extern "C" size_t mvd_gridattn_fused_vec_floats(void) { return (size_t)G4_VEC_GRANULES * 256; }
+
+extern "C" int mvd_gridattn_fused(const float* x, const float* depth_noise, const float* steps, const int* iter,
+                                  const float* grid_lin, const float* feat, const float* in_feat, const float* cams,
+                                  const float* in_cam, const void* wstream, const float* vecs, void* pooled_sp, int V, int q0,
+                                  int Vq, int S, int D, float depth_scale, float depth_shift, mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && depth_noise && steps && iter && grid_lin && feat && in_feat && cams && in_cam && wstream && vecs && pooled_sp,
+                "mvd_gridattn_fused: null pointer");
+  MVD_CHECK_ARG(V == 1 || V == 2 || V == 4 || V == 8 || V == 16, "mvd_gridattn_fused: V=%d must divide 16 (use the unfused path)", V);
+  MVD_CHECK_ARG(q0 >= 0 && Vq > 0 && q0 + Vq <= V && S > 1 && D > 0, "mvd_gridattn_fused: bad shape");
+  MVD_CHECK_ARG(((uintptr_t)wstream & 15) == 0 && ((uintptr_t)vecs & 15) == 0 && ((uintptr_t)pooled_sp & 127) == 0,
+                "mvd_gridattn_fused: wstream / vecs must be 16-byte, pooled_sp 128-byte aligned");
+  const size_t T = (size_t)Vq * S * S * D * V;
+  MVD_CHECK_ARG(T % 64 == 0, "mvd_gridattn_fused: token count %zu must be a multiple of 64", T);
+  G4Params p;
+  p.x = x; p.depth_noise = depth_noise; p.steps = steps; p.iter = iter; p.grid_lin = grid_lin; p.feat = feat;
+  p.in_feat = in_feat; p.cams = cams; p.in_cam = in_cam; p.wstream = (const unsigned char*)wstream; p.vecs = vecs;
+  p.pooled_sp = (u16*)pooled_sp; p.V = V; p.q0 = q0; p.Vq = Vq; p.S = S; p.D = D; p.nslots = 23 + 3 * 64;
+  p.depth_scale = depth_scale; p.depth_shift = depth_shift;
+  hipLaunchKernelGGL(g4_fused_kernel, dim3((unsigned)(T / 64)), dim3(256), 0, (hipStream_t)stream, p);
+  MVD_CHECK_LAUNCH("mvd_gridattn_fused");
+  return 0;
+}

@@ -70,6 +70,10 @@ SIGNATURES = {
     "mvd_advance_iter": (_i, [_vp, _vp]),
     "mvd_zembed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvd_gridattn_tokens": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _f, _f, _vp]),
+    "mvd_gridattn_fused_slots": (_i, []),
+    "mvd_gridattn_fused_stream_bytes": (_sz, []),
+    "mvd_gridattn_fused_vec_floats": (_sz, []),
+    "mvd_gridattn_fused": (_i, [_vp] * 12 + [_i, _i, _i, _i, _i, _f, _f, _vp]),
     "mvd_view_mha": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_view_pool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mvd_cfg_ddim_update": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _f, _i, _vp]),

@@ -18,6 +18,82 @@ from . import hip
 from .cameras import pack_cameras
 
 
+# ------------------------------------------------------------------------------------------------
+# weight stream of the fused aggregation kernel (csrc/gridattn_fused.hip)
+# ------------------------------------------------------------------------------------------------
+_G4_VEC_BLOCK, _G4_VEC_MISC = 3328, 3 * 3328
+
+
+def _microtiles(W, scale, bf16):
+    """(N, K) fp32 -> (N/16, K/32, 1024) int16: every (16 weight rows x 32 k) micro-tile as its 2 KiB LDS image --
+    x*scale ~= hi + lo in the MFMA operand type, k inside the 32-block permuted to the fragment order of the kernel's
+    register-resident activations (slot (c, j): k = 4c + j for j < 4, 16 + 4c + j - 4 otherwise), 16-byte chunk c (0-3 hi,
+    4-7 lo) of row R at position (R & 7) * 8 + (c ^ ((R >> 1) & 7)) of granule R >> 3 (the swizzle of csrc/gemm.hip)."""
+    N, K = W.shape
+    assert N % 16 == 0 and K % 32 == 0, (N, K)
+    w = (W.detach().double().cpu() * scale).float()
+    dt = torch.bfloat16 if bf16 else torch.float16
+    hi = w.to(dt)
+    lo = (w - hi.float()).to(dt)
+    perm = torch.tensor([(4 * c + j) if j < 4 else (16 + 4 * c + j - 4) for c in range(4) for j in range(8)])
+
+    def chunks(t):
+        return t.contiguous().view(torch.int16).view(N // 16, 16, K // 32, 32)[..., perm].reshape(N // 16, 16, K // 32, 4, 8)
+
+    data = torch.cat([chunks(hi), chunks(lo)], dim=3).permute(0, 2, 1, 3, 4)            # (nt, ks, R, c8, 8)
+    R, c8 = torch.arange(16), torch.arange(8)
+    gran = (R >> 3)[:, None].expand(16, 8)
+    pos = ((R & 7) * 8)[:, None] + (c8[None, :] ^ ((R >> 1) & 7)[:, None])
+    img = torch.empty(N // 16, K // 32, 2, 64, 8, dtype=torch.int16)
+    img[:, :, gran, pos, :] = data
+    return img.reshape(N // 16, K // 32, 1024)
+
+
+def pack_fused_stream(ga, bf16=False):
+    """GridAttn parameters -> (stream int16 (215 * 16, 1024) = 215 slots of 32 KiB in the kernel's consumption order,
+    vecs fp32 (11264,) with everything but the per-step adaLN modulation filled in)."""
+    C = ga.hidden_size
+    blocks = list(ga.aggregation_transformer.layer_list)
+    assert C == 256 and len(blocks) == 3 and all(b.num_heads == 8 and b.mlp.fc1.out_features == 512 for b in blocks)
+    vecs = torch.zeros(hip.lib().mvd_gridattn_fused_vec_floats(), dtype=torch.float32)
+    tiles = []
+
+    def scaled(Wt):
+        sc = hip._pack_scale(Wt.detach())
+        return _microtiles(Wt, sc, bf16), 1.0 / sc
+
+    wpre = torch.zeros(C, 736)
+    wpre[:, :723] = ga.pre_layer_b[0].weight.detach().float().cpu()
+    pre, s_pre = scaled(wpre)
+    tiles.append(pre.permute(1, 0, 2).reshape(-1, 1024))                                # for ks: for nt
+    vecs[_G4_VEC_MISC:_G4_VEC_MISC + 256] = ga.pre_layer_b[0].bias.detach().float().cpu()
+    wl = ga.aggregation_transformer.weight_layer
+    vecs[_G4_VEC_MISC + 256:_G4_VEC_MISC + 512] = wl.weight.detach().float().cpu().reshape(-1)
+    vecs[_G4_VEC_MISC + 512] = float(wl.bias.detach().float().cpu())
+    vecs[_G4_VEC_MISC + 520] = s_pre
+    for bi, blk in enumerate(blocks):
+        q, s_q = scaled(blk.attn.qkv.weight.float().cpu())          # (48, 8, 1024)
+        pj, s_p = scaled(blk.attn.proj.weight.float().cpu())        # (16, 8, 1024)
+        f1, s_1 = scaled(blk.mlp.fc1.weight.float().cpu())         # (32, 8, 1024)
+        f2, s_2 = scaled(blk.mlp.fc2.weight.float().cpu())         # (16, 16, 1024)
+        for hd in range(8):
+            rows = torch.tensor([2 * hd, 2 * hd + 1, 16 + 2 * hd, 16 + 2 * hd + 1, 32 + 2 * hd, 32 + 2 * hd + 1])
+            tiles.append(q[rows].permute(1, 0, 2).reshape(-1, 1024))                    # mt = 6 ks + tile
+            tiles.append(pj[:, hd])                                                     # 16 output tiles of k-step hd
+        for ch in range(8):
+            tiles.append(f1[4 * ch:4 * ch + 4].permute(1, 0, 2).reshape(-1, 1024))      # for ks: the chunk's 4 tiles
+            tiles.append(f2[:, 2 * ch:2 * ch + 2].permute(1, 0, 2).reshape(-1, 1024))   # for u: for nt
+        o = bi * _G4_VEC_BLOCK
+        vecs[o + 1536:o + 2304] = blk.attn.qkv.bias.detach().float().cpu()
+        vecs[o + 2304:o + 2560] = blk.attn.proj.bias.detach().float().cpu()
+        vecs[o + 2560:o + 3072] = blk.mlp.fc1.bias.detach().float().cpu()
+        vecs[o + 3072:o + 3328] = blk.mlp.fc2.bias.detach().float().cpu()
+        vecs[_G4_VEC_MISC + 521 + 4 * bi:_G4_VEC_MISC + 525 + 4 * bi] = torch.tensor([s_q, s_p, s_1, s_2])
+    stream = torch.cat(tiles, 0).contiguous()
+    assert stream.shape[0] == 16 * hip.lib().mvd_gridattn_fused_slots(), stream.shape
+    return stream, vecs
+
+
 class _TimmAttention(nn.Module):      # parameter holder: timm.models.vision_transformer.Attention(qkv_bias=True)
     def __init__(self, dim, num_heads):
         super().__init__()
@@ -115,6 +191,7 @@ class GridAttn(nn.Module):
             nn.init.constant_(blk.adaLN_modulation[-1].weight, 0)
             nn.init.constant_(blk.adaLN_modulation[-1].bias, 0)
         self._p = None
+        self._fused = None
 
     def packed(self):
         if self._p is None:
@@ -122,12 +199,27 @@ class GridAttn(nn.Module):
                        hip.pack_linear(self.final_layer_b.weight, self.final_layer_b.bias))
         return self._p
 
+    def packed_fused(self, device):
+        """(weight stream, vecs) of the fused aggregation kernel on `device` (packed once; the adaLN part of vecs is
+        rewritten every step)."""
+        if self._fused is None:
+            stream, vecs = pack_fused_stream(self, bf16=hip.OPERAND_FORMAT == "bf16")
+            self._fused = (stream.to(device), vecs.to(device))
+        return self._fused
+
+    def fused_supported(self, V, T):
+        blocks = self.aggregation_transformer.layer_list
+        return (V in (1, 2, 4, 8, 16) and T % 64 == 0 and self.hidden_size == 256 and len(blocks) == 3 and
+                all(b.num_heads == 8 and b.mlp.fc1.out_features == 512 for b in blocks))
+
     def run(self, ctx, x, depth_noise, steps, it, cams_rec, in_cam_rec, input_latents, c, vol_out, V, S, D, q0=0, Vq=None,
-            vol_planes=None, vol_planes_col=0):
+            vol_planes=None, vol_planes_col=0, fused=None):
         """x (V,5,S,S) noisy latents; c (1,256) time conditioning (t_embed[:1]); vol_out: (>=V*S*S*D, 768) buffer
         whose first Vq*S*S*D rows receive the feature frustum (row = ((v*S + y)*S + x)*D + d) of the query views
         [q0, q0+Vq) (all V views by default; a view-parallel rank passes the range it owns).  vol_planes: optional planes
-        buffer receiving the frustum as well, in columns [vol_planes_col, vol_planes_col + 768) of its rows."""
+        buffer receiving the frustum as well, in columns [vol_planes_col, vol_planes_col + 768) of its rows.
+        fused: None = the single-launch aggregation kernel (mvd_gridattn_fused) whenever V divides 16, else the unfused chain
+        of token kernel + GEMMs; True / False force one of them."""
         Vq = V if Vq is None else Vq
         L = hip.lib()
         assert x.shape[1] == 5, "depth wise efficient attention requires 4+1 channels"
@@ -145,6 +237,21 @@ class GridAttn(nn.Module):
             half = 1.0 / float(S)
             grid_lin = torch.linspace(1.0 - half, -1.0 + half, S, dtype=torch.float32).to(ctx.device)
             ctx.ws.bufs[("ga.lin", S)] = grid_lin
+        if fused is None:
+            fused = self.fused_supported(V, T)
+        if fused:
+            assert self.fused_supported(V, T), (V, T)
+            stream, vecs = self.packed_fused(ctx.device)
+            for bi, blk in enumerate(self.aggregation_transformer.layer_list):      # adaLN modulation of this step -> vecs
+                lin = blk.adaLN_modulation[1]
+                hip.gemv(lin.weight, lin.bias, c, vecs[bi * _G4_VEC_BLOCK:bi * _G4_VEC_BLOCK + 1536].view(1, 1536), act_in=hip.ACT_SILU)
+            pool = ctx.ws.planes("ga.pool", nseq, self.hidden_size)
+            hip.check(L.mvd_gridattn_fused(hip.ptr(x), hip.ptr(depth_noise), hip.ptr(steps), hip.ptr(it), hip.ptr(grid_lin),
+                                           hip.ptr(feat), hip.ptr(in_feat), hip.ptr(cams_rec), hip.ptr(in_cam_rec), hip.ptr(stream),
+                                           hip.ptr(vecs), hip.ptr(pool), V, q0, Vq, S, D, float(self.depth_scale),
+                                           float(self.depth_shift), hip.stream()))
+            ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes, out_planes_col=vol_planes_col)
+            return vol_out
         tokens = ctx.ws.planes("ga.tokens", T, hip.TOKEN_LD)
         hip.check(L.mvd_gridattn_tokens(hip.ptr(x), hip.ptr(depth_noise), hip.ptr(steps), hip.ptr(it), hip.ptr(grid_lin),
                                         hip.ptr(feat), hip.ptr(in_feat), hip.ptr(cams_rec), hip.ptr(in_cam_rec),

@@ -328,6 +328,48 @@ def test_vae_mirror_keys_and_guards():
         vae.encode(torch.zeros(1, 3, 64, 64))
 
 
+def test_fused_gridattn_weight_stream_layout():
+    """pack_fused_stream: 215 slots of 32 KiB, and a fragment read the way csrc/gridattn_fused.hip does it (row lane & 15,
+    16-byte chunk lane >> 4, swizzled) returns W[row, permuted k] for micro-tiles picked across the stream."""
+    from mvdfusion_amd import hip
+    from mvdfusion_amd import view_attn_efficient2 as va
+    ga = va.GridAttn(in_channels=5, input_size=32, output_dim=768, num_layers=3, n_pts_per_ray=1)
+    syn.fill_module_(ga, "view_attn.")
+    stream, vecs = va.pack_fused_stream(ga)
+    assert stream.shape == (215 * 16, 1024) and stream.dtype == torch.int16 and vecs.numel() == 11264
+
+    def read(tile, row, g, scale):
+        b = stream[tile].view(torch.float16)
+        oh = ((row >> 3) * 1024 + (row & 7) * 128 + ((g ^ ((row >> 1) & 7)) * 16)) // 2
+        ol = ((row >> 3) * 1024 + (row & 7) * 128 + (((4 + g) ^ ((row >> 1) & 7)) * 16)) // 2
+        return (b[oh:oh + 8].float() + b[ol:ol + 8].float()) * scale
+
+    kperm = lambda ks, g: [32 * ks + (4 * g + j if j < 4 else 16 + 4 * g + j - 4) for j in range(8)]
+    misc = 3 * 3328
+    # pre layer: slot ks, micro-tile nt
+    Wpre = torch.zeros(256, 736)
+    Wpre[:, :723] = ga.pre_layer_b[0].weight.detach()
+    for ks, nt, row, g in [(0, 0, 0, 0), (22, 15, 9, 3), (7, 5, 14, 1)]:
+        got = read(ks * 16 + nt, row, g, float(vecs[misc + 520]))
+        assert torch.allclose(got, Wpre[16 * nt + row, kperm(ks, g)], rtol=1e-6, atol=1e-7)
+    # block 1, head 3: qkv micro-tile mt = 6 ks + t6 -> rows {q, k, v} x {0, 1}; then proj k-step 3
+    blk = ga.aggregation_transformer.layer_list[1]
+    base = (23 + 64) * 16 + 3 * 64            # slots before block 1, then 3 heads x 4 slots x 16 micro-tiles
+    for ks, t6, row, g in [(0, 0, 1, 0), (5, 3, 7, 2), (7, 5, 15, 3)]:
+        wrow = [96, 112, 256 + 96, 256 + 112, 512 + 96, 512 + 112][t6] + row
+        got = read(base + 6 * ks + t6, row, g, float(vecs[misc + 521 + 4]))
+        assert torch.allclose(got, blk.attn.qkv.weight.detach()[wrow, kperm(ks, g)], rtol=1e-6, atol=1e-7)
+    got = read(base + 48 + 11, 4, 2, float(vecs[misc + 522 + 4]))
+    assert torch.allclose(got, blk.attn.proj.weight.detach()[16 * 11 + 4, kperm(3, 2)], rtol=1e-6, atol=1e-7)
+    # block 1, MLP chunk 5: fc1 (32 micro-tiles: 4 ks + ... ) then fc2 k-steps 10, 11
+    mb = (23 + 64) * 16 + 8 * 64 + 5 * 64
+    got = read(mb + 4 * 6 + 2, 3, 1, float(vecs[misc + 523 + 4]))          # ks 6, chunk tile 2 -> hidden rows 64*5 + 32 ..
+    assert torch.allclose(got, blk.mlp.fc1.weight.detach()[64 * 5 + 32 + 3, kperm(6, 1)], rtol=1e-6, atol=1e-7)
+    got = read(mb + 32 + 16 + 9, 12, 0, float(vecs[misc + 524 + 4]))       # u = 1 -> k-step 11, output tile 9
+    assert torch.allclose(got, blk.mlp.fc2.weight.detach()[16 * 9 + 12, kperm(11, 0)], rtol=1e-6, atol=1e-7)
+    assert torch.equal(vecs[3328 + 1536:3328 + 2304], blk.attn.qkv.bias.detach())
+
+
 def test_det_fill_is_stable_and_nonzero():
     a = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))
     b = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))
