@@ -82,7 +82,7 @@ def profile_kernel_groups(m, eng, cfg_scale):
     kernel groups (attention, GroupNorm, LayerNorm, the whole GridAttn block)."""
     from mvdfusion_amd import hip
     from mvdfusion_amd.view_attn_efficient2 import GridAttn
-    recs, groups = [], {"attention": [], "groupnorm": [], "layernorm": [], "gridattn": []}
+    recs, groups = [], {"attention": [], "groupnorm": [], "layernorm": [], "gridattn": [], "gridattn_fused_kernel": []}
     real = dict(gemm=hip.gemm, attention=hip.attention, groupnorm=hip.groupnorm, layernorm=hip.layernorm, ga=GridAttn.run)
 
     def ev_pair():
@@ -141,6 +141,19 @@ def profile_kernel_groups(m, eng, cfg_scale):
         groups["gridattn"].append(dict(flops=T * (3516416.0 + 3072.0 * V), bytes=0.0, ev=(e0, e1)))
         return r
 
+    lib = hip.lib()
+    real_fused = lib.mvd_gridattn_fused
+
+    def timed_fused(*a):
+        e0, e1 = ev_pair()
+        e0.record()
+        r = real_fused(*a)
+        e1.record()
+        V, Vq, S, D = a[12], a[14], a[15], a[16]
+        groups["gridattn_fused_kernel"].append(dict(flops=Vq * S * S * D * V * (3516416.0 + 3072.0 * V), bytes=0.0, ev=(e0, e1)))
+        return r
+
+    lib.mvd_gridattn_fused = timed_fused
     hip.gemm, hip.attention, hip.groupnorm, hip.layernorm, GridAttn.run = timed_gemm, timed_attention, timed_groupnorm, \
         timed_layernorm, timed_ga
     try:
@@ -155,6 +168,7 @@ def profile_kernel_groups(m, eng, cfg_scale):
     finally:
         hip.gemm, hip.attention, hip.groupnorm, hip.layernorm, GridAttn.run = real["gemm"], real["attention"], \
             real["groupnorm"], real["layernorm"], real["ga"]
+        lib.mvd_gridattn_fused = real_fused
     by = {}
     for r in recs:
         ms = r["ev"][0].elapsed_ms(r["ev"][1])
@@ -362,6 +376,10 @@ def main():
             rg["gridattn"]["note"] = ("whole GridAttn block (z-embed, token generation, aggregation transformer, pooling, 256->768); "
                                       "FLOPs = T*(3516416 + 3072*V), the aggregation tail SURVEY.md section 8(d) puts the >=40% "
                                       "MFMA target on")
+        if "gridattn_fused_kernel" in rg:
+            rg["gridattn_fused_kernel"]["note"] = ("g4_fused_kernel alone (csrc/gridattn_fused.hip): token generation + pre layer + 3 DiT "
+                                                   "blocks + pooling in one launch; the north-star 'cross-view attention kernel'. "
+                                                   "mfma_pipe_frac = fraction of the dense 16-bit MFMA peak actually issued (4 products per MAC)")
         out["roofline_groups"] = rg
         if a.shard_emulate:
             r_, n_ = (int(t) for t in a.shard_emulate.split("/"))

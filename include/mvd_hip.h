@@ -83,6 +83,8 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, floa
 #define MVD_ACT_SILU 2
 
 #define MVD_GEMM_TILES 5 /* tile shapes of mvd_gemm_desc.cfg */
+#define MVD_B_PACKED 0   /* B: weight image of mvd_pack_linear_weight / mvd_pack_conv3x3_weight */
+#define MVD_B_PLANES 1   /* B: (N, ldb) row-major split planes (an activation), N % 16 == 0 */
 
 typedef struct mvd_gemm_desc {
   int M, N, K;      /* logical sizes; N % 16 == 0 after padding of the packed weight, K as packed (multiple of 32) */
@@ -97,7 +99,11 @@ typedef struct mvd_gemm_desc {
   int B, Hin, Win, Cin, Hout, Wout, stride, upsample; /* upsample: input is nearest-2x upsampled before the conv */
   int no_pad_tl;         /* 1: no zero padding on the top / left edge, i.e. F.pad(x, (0,1,0,1)) + conv(stride 2, padding 0) of
                             the VAE Downsample (diffusionmodules/model.py:72-76); taps past the bottom / right edge read zeros */
-  const void* Wp;   /* packed weight (mvd_pack_*) */
+  const void* Wp;   /* B operand: packed weight (mvd_pack_*), or -- b_mode == MVD_B_PLANES -- an (N, ldb) activation matrix in split
+                       planes, i.e. out = A B^T of two activation tensors (the VAE mid-block attention: Q K^T and P V,
+                       external/sd1/ldm/modules/diffusionmodules/model.py:184-199) */
+  int b_mode;       /* MVD_B_* */
+  int ldb;          /* elements per row of a planes B operand; multiple of 32 */
   float acc_scale;  /* accumulator scale = 1 / (pack scale); 0 is treated as 1 */
   int prec;         /* MVD_PREC_* */
   /* epilogue */

@@ -97,33 +97,43 @@ class AttnBlock(nn.Module):
         self._p = None
 
     def packed(self):
+        """(q|k projection weight, v weight as an A operand [planes], v bias, proj_out weight)."""
         if self._p is None:
-            w = torch.cat([m.weight.detach().reshape(self.in_channels, -1) for m in (self.q, self.k, self.v)], 0)
-            b = torch.cat([m.bias.detach() for m in (self.q, self.k, self.v)], 0)
-            self._p = (hip.pack_linear(w, b), hip.pack_linear(self.proj_out.weight, self.proj_out.bias))
+            C = self.in_channels
+            w = torch.cat([m.weight.detach().reshape(C, -1) for m in (self.q, self.k)], 0)
+            b = torch.cat([m.bias.detach() for m in (self.q, self.k)], 0)
+            wv = hip.split_planes(self.v.weight.detach().reshape(C, -1).float().contiguous())
+            bv = self.v.bias.detach().float().contiguous()
+            torch.cuda.current_stream().synchronize()      # (pack time only: temporaries above)
+            self._p = (hip.pack_linear(w, b), wv, bv, hip.pack_linear(self.proj_out.weight, self.proj_out.bias))
         return self._p
 
     def run(self, ctx, x, B, H, W):
+        """AttnBlock.forward (diffusionmodules/model.py:184-199): one 512-wide head over the h*w tokens of each image.
+        Everything is enqueued on the stream -- no host synchronisation, no per-call weight packing (graph-capturable):
+        Q K^T and P V are mvd_gemm calls whose B operand is an ACTIVATION in split planes (MVD_B_PLANES); V^T comes out of a
+        GEMM with the roles swapped (A = W_v, B = the normalised tokens); the value bias is added after P V (rows of P sum
+        to one)."""
         C, L = self.in_channels, H * W
         M = B * L
         assert L % 32 == 0 and L <= 4096, "mvd_softmax_rows holds one row of <= 4096 keys"
-        w_qkv, w_out = self.packed()
+        w_qk, wv_planes, bv, w_out = self.packed()
         n = ctx.ws.planes("vae.attn.n", M, C)
         ctx.groupnorm(x, n, self.norm, B, L, C, silu=False)
-        qkv = ctx.ws.get("vae.attn.qkv", (M, 3 * C))
-        ctx.gemm(n, w_qkv, qkv)
+        qk = ctx.ws.planes("vae.attn.qk", M, 2 * C)                 # [q | k] per token, as planes (operands of Q K^T)
+        ctx.gemm(n, w_qk, None, out_planes=qk)
         o = ctx.ws.planes("vae.attn.o", M, C)
-        qp = ctx.ws.planes("vae.attn.q", L, C)
         logits = ctx.ws.get("vae.attn.logits", (L, L))
         prob = ctx.ws.planes("vae.attn.p", L, L)
-        for b in range(B):       # the (L, L) score matrix of one image at a time: K_b and V_b^T take the weight role
-            rows = qkv[b * L:(b + 1) * L]
-            hip.split_planes(rows[:, :C].contiguous(), qp)
-            ctx.gemm(qp, hip.pack_linear(rows[:, C:2 * C].contiguous()), logits, bias=False)
+        vt = ctx.ws.planes("vae.attn.vt", C, L)                      # V^T of one image
+        for b in range(B):
+            rows = slice(b * L, (b + 1) * L)
+            k_b = hip.PlanesOperand(qk[rows, 2 * C:], N=L, K=C, ld=2 * C)     # columns [C, 2C) of the [q | k] planes (a view)
+            ctx.gemm(qk[rows], k_b, logits, M=L, lda=2 * C, bias=False)
             hip.softmax_rows(logits, prob, scale=float(C) ** -0.5, out_scale=1024.0)   # p ~ 1/L would sit in fp16 subnormals
-            wv = hip.pack_linear(rows[:, 2 * C:].t().contiguous())
-            wv.acc_scale /= 1024.0
-            ctx.gemm(prob, wv, None, bias=False, out_planes=o[b * L:(b + 1) * L])
+            ctx.gemm(wv_planes, hip.PlanesOperand(n[rows], N=L, K=C), None, bias=False, out_planes=vt)
+            pv = hip.PlanesOperand(vt, N=C, K=L, bias=bv, acc_scale=1.0 / 1024.0)
+            ctx.gemm(prob, pv, None, out_planes=o[rows])
         out = ctx.act((M, C))
         ctx.gemm(o, w_out, out, res=x)
         return out

@@ -256,9 +256,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const int R = (gi & 1) * 8 + gr;
     const int gc = (lane & 7) ^ ((R >> 1) & 7);
     const int nt = (n0 >> 4) + (gi >> 1);
-    b_src[i] = (gi < B_GRAN && nt < p.nt16) ? (const u16*)d.Wp + (size_t)nt * 1024 + R * 64 + gc * 8 : nullptr;
+    if (d.b_mode == MVD_B_PLANES) {           // B rows are rows of an activation matrix in split planes (same 128-byte lines as A)
+      const int n = n0 + gi * 8 + gr;
+      b_src[i] = (gi < B_GRAN && n < d.N) ? (const u16*)d.Wp + (size_t)n * 2 * d.ldb + gc * 8 : nullptr;
+    } else {
+      b_src[i] = (gi < B_GRAN && nt < p.nt16) ? (const u16*)d.Wp + (size_t)nt * 1024 + R * 64 + gc * 8 : nullptr;
+    }
   }
-  const size_t b_kstride = (size_t)p.nt16 * 1024;   // elements between consecutive k-tiles of the packed weight
+  // elements between consecutive k-tiles: packed weight = one row of micro-tiles; planes = the next 128-byte line of the row
+  const size_t b_kstride = d.b_mode == MVD_B_PLANES ? (size_t)64 : (size_t)p.nt16 * 1024;
 
   // Running DMA sources: every stage() call moves one k-tile forward.  Dense A and the packed weights advance a
   // pointer (rows / weight tiles outside the problem sit on the zero page with step 0).  Conv K order is
@@ -702,6 +708,10 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   } else {
     MVD_CHECK_ARG(false, "mvd_gemm: bad epilogue %d", d.epi);
   }
+  if (d.b_mode == MVD_B_PLANES)
+    MVD_CHECK_ARG(d.ldb >= d.K && d.ldb % 32 == 0, "mvd_gemm: B planes need ldb=%d >= K=%d, a multiple of 32", d.ldb, d.K);
+  else
+    MVD_CHECK_ARG(d.b_mode == MVD_B_PACKED, "mvd_gemm: bad b_mode %d", d.b_mode);
   if (d.acc_scale == 0.f) d.acc_scale = 1.f;
   p.nk = d.K / 32;
   p.nt16 = d.N / 16;

@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
         ("M", _i), ("N", _i), ("K", _i),
         ("A", _vp), ("lda", _i), ("a_mode", _i),
         ("B", _i), ("Hin", _i), ("Win", _i), ("Cin", _i), ("Hout", _i), ("Wout", _i), ("stride", _i), ("upsample", _i), ("no_pad_tl", _i),
-        ("Wp", _vp), ("acc_scale", _f), ("prec", _i),
+        ("Wp", _vp), ("b_mode", _i), ("ldb", _i), ("acc_scale", _f), ("prec", _i),
         ("epi", _i), ("act", _i), ("out", _vp), ("ldo", _i), ("out_sp", _vp), ("ldp", _i),
         ("n_store", _i),
         ("bias", _vp), ("bias_b", _vp), ("rows_per_batch", _i), ("ldbb", _i), ("colscale", _vp), ("res", _vp), ("ldr", _i),
@@ -148,6 +148,21 @@ class PackedWeight:
     def __init__(self, data, N, K, n_real, bias, geglu=False, conv_cin=0, acc_scale=1.0):
         self.data, self.N, self.K, self.n_real, self.bias, self.geglu, self.conv_cin = data, N, K, n_real, bias, geglu, conv_cin
         self.acc_scale = acc_scale
+
+
+class PlanesOperand:
+    """An activation matrix (N rows, K columns, split planes with `ld` elements per row) in the B-operand role of mvd_gemm:
+    out = A @ B^T between two activations (MVD_B_PLANES).  Duck-types PackedWeight for hip.gemm."""
+
+    __slots__ = ("data", "N", "K", "n_real", "bias", "geglu", "conv_cin", "acc_scale", "ld")
+
+    def __init__(self, planes, N=None, K=None, bias=None, acc_scale=1.0, ld=None):
+        assert planes.dtype == torch.int16 and planes.dim() == 2
+        self.data, self.ld = planes, int(ld if ld is not None else planes.shape[-1] // 2)   # ld: row stride when `planes` is a column view
+        self.N = int(N if N is not None else planes.shape[0])
+        self.K = int(K if K is not None else self.ld)
+        assert self.N % 16 == 0 and self.K % 32 == 0 and self.K <= self.ld, (self.N, self.K, self.ld)
+        self.n_real, self.bias, self.geglu, self.conv_cin, self.acc_scale = self.N, bias, False, 0, acc_scale
 
 
 def _pack_scale(w):
@@ -276,6 +291,8 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     d.N, d.K = W.N, W.K
     d.A = A.data_ptr()
     d.Wp = W.data.data_ptr()
+    if isinstance(W, PlanesOperand):
+        d.b_mode, d.ldb = 1, W.ld
     d.acc_scale = W.acc_scale
     d.prec = prec
     if conv is not None:
@@ -321,7 +338,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.workspace = workspace.data_ptr()
         d.workspace_elems = workspace.numel()
     key = (d.M, d.N, d.K, d.a_mode, d.Cin, d.stride, d.upsample, d.no_pad_tl, d.epi, d.prec, res is not None, out is not None,
-           out_planes is not None, splitk)
+           out_planes is not None, splitk, d.b_mode)
     if cfg is None:
         cfg = _TUNED.get(key)
     if cfg is None and AUTOTUNE:

@@ -1,0 +1,50 @@
+"""View-parallel path on the GPU: TWO ranks (one process each, both on this box's single GPU) run
+sample_view_parallel -- StepEngine shards + captured hipGraphs + the ViewExchange all-gather of the updated latent rows -- over
+RCCL (backend "nccl").  Some RCCL builds refuse two ranks on one device; then the same job runs over gloo (CUDA tensors staged
+through the host) and the test records which backend carried it.  The 8-GPU run itself belongs to the driver."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(backend, V, steps):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), backend, str(V), str(steps)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    recs = [json.loads(l.split("DISTJSON ", 1)[1]) for l in r.stdout.splitlines() if "DISTJSON " in l]
+    return r, recs
+
+
+@pytest.mark.parametrize("V", [4])
+def test_two_rank_view_parallel_on_one_gpu(V):
+    steps = 3
+    r, recs = _run("nccl", V, steps)
+    used = "nccl"
+    if r.returncode != 0 or len(recs) != 2:
+        print("RCCL with two ranks on one device did not run here:\n" + (r.stderr[-1500:] or r.stdout[-1500:]))
+        r, recs = _run("gloo", V, steps)
+        used = "gloo"
+    assert r.returncode == 0 and len(recs) == 2, r.stderr[-3000:]
+    print(f"view-parallel 2-rank job carried by backend: {used}")
+    rec0 = [x for x in recs if x["rank"] == 0][0]
+    assert all(x["replicas_identical"] for x in recs)
+    assert rec0["finite"] and rec0["rmse"] < 1e-5 and rec0["max_abs_diff"] < 1e-4, rec0
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"backend": used, "records": recs}, open(os.path.join(out, "dist_2rank_one_gpu.json"), "w"))

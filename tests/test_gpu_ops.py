@@ -99,6 +99,28 @@ def test_gemm_operand_range_contract(hip):
     assert bool(torch.isfinite(out[4:]).all())                                # other rows are unaffected
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 512), (512, 1024, 512), (200, 48, 96)])
+def test_gemm_activation_b_operand(hip, M, N, K):
+    """MVD_B_PLANES: out = A @ B^T with B an ACTIVATION in split planes (no packed weight): the VAE mid-block attention's
+    Q K^T / P V, including a B operand that is a column view of a wider planes buffer and every tile shape."""
+    A = torch.randn(M, K, generator=g(11))
+    Bm = torch.randn(N, K, generator=g(12))
+    bias = torch.randn(N, generator=g(13))
+    ref = A @ Bm.t() * 0.5 + bias
+    Ap = hip.split_planes(A.cuda())
+    wide = hip.split_planes(torch.cat([torch.randn(N, 64, generator=g(14)), Bm], 1).cuda())      # B lives in columns [64, 64 + K)
+    Bop = hip.PlanesOperand(wide[:, 2 * 64:], N=N, K=K, bias=bias.cuda(), acc_scale=0.5, ld=64 + K)
+    out = torch.empty(M, N, device="cuda")
+    ws = torch.empty(8 * 1024 * 1024, device="cuda")
+    hip.gemm(Ap, Bop, out, workspace=ws)
+    assert rel_err(out, ref) < TOL[4]
+    for cfg in hip.GEMM_CONFIGS[::2]:
+        for sk in (1, 2):
+            out.zero_()
+            hip.gemm(Ap, Bop, out, workspace=ws, cfg=cfg, splitk=sk)
+            assert rel_err(out, ref) < TOL[4], (cfg, sk)
+
+
 def test_gemm_epilogues(hip):
     M, C = 512, 320
     A = torch.randn(M, C, generator=g(5))
