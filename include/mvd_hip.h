@@ -133,12 +133,14 @@ typedef struct mvd_gemm_desc {
   int splitk;
   float* workspace;
   size_t workspace_elems;
-  /* kernel configuration: 0 = built-in heuristic; otherwise cfg = 1 + 4 * tile + 2 * loop + order with
+  /* kernel configuration: 0 = built-in heuristic; otherwise cfg = 1 + 8 * tile + 2 * loop + order with
    *   tile : 0 = 64x64 (4 waves)  1 = 128x128 (8 waves)  2 = 128x80 (4 waves)  3 = 64x80 (4 waves)  4 = 128x160 (8 waves);
    *          tiles >= 2 (the 80-column family for N = 320 * k: no N padding, 256 workgroups at M = 8192, N = 320) serve
    *          MVD_EPI_STORE only
-   *   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop (both keep two k-tiles in LDS; the pipelined one also
-   *          double-buffers the MFMA fragments in registers)
+   *   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop (two k-tiles in LDS, MFMA fragments double-buffered in
+   *          registers), 2 = staggered (8-wave tiles only: three k-tiles in LDS, the two wavefronts of a SIMD half an
+   *          iteration apart, so one issues LDS-DMA / fragment reads while the other runs MFMAs), 3 = staggered with four
+   *          k-tiles in LDS (128x128 only)
    *   order: 0 = n-fastest, 1 = m-fastest order of the output tiles over the 8 XCDs.
    * The host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
    * winner from then on (mvdfusion_amd/hip.py: autotune). */

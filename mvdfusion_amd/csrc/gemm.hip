@@ -21,7 +21,11 @@
 // (r&7)*8 + (cc ^ (r>>1)), which is conflict-free for the 16-lane ds_read_b128 groups).  Running source pointers: the
 // k loop carries no address arithmetic beyond one add per granule; rows/columns outside the problem (M/N edges, conv
 // zero padding) source a 16-byte zero page.
-// Two LDS buffers and two loop variants (template STAGES): 2 = plain (DMA of k-tile t+1 in flight under the MFMAs of t;
+// Loop variants (template STAGES).  4 = STAGGERED (8-wave tiles only, three LDS buffers): the two wavefronts that share a SIMD
+// run half an iteration apart -- in every phase one of them issues its LDS-DMA share of k-tile t+2 and reads its fragments of
+// k-tile t (memory phase) while its partner runs the MFMAs of its own current k-tile, one raw s_barrier per phase.  The DMA /
+// ds_read issue time (60-185 cycles per 1 KiB DMA instruction) that otherwise sits between two MFMA bursts of a SIMD is then
+// covered by the partner's MFMAs.  Two LDS buffers for the other two variants: 2 = plain (DMA of k-tile t+1 in flight under the MFMAs of t;
 // two co-resident workgroups per CU hide each other's waits), 3 = register-pipelined (fragments of t+1 read and DMA of
 // t+2 issued under the MFMAs of t).  One `s_waitcnt vmcnt lgkmcnt` + raw `s_barrier` per k-tile.
 // NS = 1: acc += A_hi*B_hi.  NS = 3: acc += A_lo*B_hi + A_hi*B_lo + A_hi*B_hi.  NS = 4: + A_lo*B_lo first (the kernel is
@@ -170,7 +174,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   constexpr int C4 = WTN / 4;                         // float4 columns of a wave tile row
   constexpr int EPI_BYTES = NW * WTM * LDW * 4;
   constexpr bool PIPE = STAGES == 3;                   // 3 = register-pipelined loop (still two LDS buffers)
-  constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  constexpr bool STAG = STAGES >= 4;                   // 4 / 5 = staggered wave groups with three / four LDS buffers
+  constexpr int NBUF = STAG ? STAGES - 1 : 2;
+  constexpr int LEAD = NBUF - 1;                       // staggered loop: k-tiles staged ahead of the one being read
+  constexpr int SMEM = NBUF * STAGE > EPI_BYTES ? NBUF * STAGE : EPI_BYTES;
+  static_assert(!STAG || NW == 8, "the staggered loop pairs the two wavefronts of each SIMD: 8-wave tiles only");
   static_assert(A_GRAN % NW == 0, "A granules must divide evenly over the waves");
   static_assert(WTM % 16 == 0 && WTN % 16 == 0 && B_GRAN % 2 == 0, "wave tiles are made of 16x16 MFMA tiles");
 
@@ -380,7 +388,52 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     }
   };
 
-  if (PIPE) {
+  if (STAG) {
+    // ---- staggered loop, three LDS buffers.  Phases ph = 0 .. 2 nkt, one raw barrier each.  Group g (0: waves 0-3, 1: waves
+    //      4-7 -- a workgroup's waves are dealt to the 4 SIMDs round-robin, so each group has one wave per SIMD) runs
+    //      MEM(t) in phase 2t + g and MFMA(t) in phase 2t + g + 1:
+    //        MEM(t)  : issue this wave's DMA share of k-tile t+LEAD into buffer (t+LEAD)%NBUF (its last readers finished two
+    //                  phases ago), read the fragments of k-tile t, then wait until this wave's share of k-tile t+1 has landed
+    //                  (counted vmcnt: the newer stages stay in flight) -- its first reader is two barriers away.  An LDS-DMA
+    //                  round trip is ~1500 cycles even from L2 (tools/probes/dma_probe.hip), longer than one k-tile of MFMAs,
+    //                  so LEAD >= 2 stages must be in flight per workgroup
+    //        MFMA(t) : the TM x TN x NS MFMAs on the fragments read in the previous phase
+    //      so at any time one wave of a SIMD feeds the MFMA pipe while the other one issues memory instructions.
+    const int grp = wave >> 2;
+    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    // prologue: k-tiles 0 .. LEAD-1 in flight, k-tile 0 landed for everybody
+#pragma unroll
+    for (int q = 0; q < LEAD; ++q) {
+      if (q < nkt) {
+        stage(q);
+        advance_tap();
+      }
+    }
+    if (nkt >= LEAD) wait_vm_and_barrier<(LEAD - 1) * LPS>();
+    else wait_vm_and_barrier<0>();
+    for (int ph = 0; ph <= 2 * nkt; ++ph) {
+      const int u = ph - grp;
+      if (u >= 0 && u < 2 * nkt) {
+        const int t = u >> 1;
+        if ((u & 1) == 0) {
+          // MEM(t): stage k-tile t + LEAD, read the fragments of k-tile t, then make sure this wave's share of k-tile t + 1
+          // has landed: only the newest LEAD - 1 stages (k-tiles t + 2 .. t + LEAD) may still be in flight
+          const bool more = t + LEAD < nkt;
+          if (more) {
+            stage((t + LEAD) % NBUF);
+            advance_tap();
+          }
+          read_frags(t % NBUF, ah, al, bh, bl);
+          if (more) wait_vm_and_barrier<(LEAD - 1) * LPS>();
+          else wait_vm_and_barrier<0>();      // tail: drain (at most LEAD - 1 short iterations)
+          continue;
+        }
+        mfma_tile(ah, al, bh, bl);
+      }
+      asm volatile("s_barrier" ::: "memory");
+    }
+    __syncthreads();   // the epilogue reuses the stage buffers
+  } else if (PIPE) {
     // ---- register-pipelined loop, two LDS buffers.  While the MFMAs of k-tile t run out of one fragment register set,
     //      the wave reads k-tile t+1 from LDS into the other set and issues the DMA of k-tile t+2 into the buffer that
     //      tile t occupied (its fragments are already in registers).  One barrier per k-tile; the DMA it waits for was
@@ -607,26 +660,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-// Tile configurations (mvd_gemm_desc.cfg = 1 + 4 * tile + 2 * loop + order; 0 = built-in heuristic).
+// Tile configurations (mvd_gemm_desc.cfg = 1 + 6 * tile + 2 * loop + order; 0 = built-in heuristic).
 //   tile : 0 = 64x64 (2x2 waves)  1 = 128x128 (2x4)  2 = 128x80 (4x1)  3 = 64x80 (4x1)  4 = 128x160 (4x2)
-//   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop      order : 0 = n-fastest tile order, 1 = m-fastest
+//   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop, 2 = staggered wave groups, 3 LDS buffers (8-wave tiles 1 and
+//          4 only), 3 = staggered, 4 LDS buffers (tile 1 only: 128 KiB)
+//   order : 0 = n-fastest tile order, 1 = m-fastest
 // The 80-column family serves MVD_EPI_STORE only (GEGLU / QKV epilogues address 32-column wave tiles).
 struct TileInfo {
-  int bm, bn;
+  int bm, bn, waves;
   int cores_plain, cores_pipe;   // workgroups that fit one CU (LDS / registers), per loop variant
 };
-static const TileInfo kTiles[MVD_GEMM_TILES] = {{64, 64, 5, 3}, {128, 128, 2, 1}, {128, 80, 2, 2}, {64, 80, 4, 3}, {128, 160, 1, 1}};
+static const TileInfo kTiles[MVD_GEMM_TILES] = {{64, 64, 4, 5, 3}, {128, 128, 8, 2, 1}, {128, 80, 4, 2, 2}, {64, 80, 4, 4, 3},
+                                                {128, 160, 8, 1, 1}};
 
 // Split-K selection by a small time model (unit: 0.7 us ~ one DMA round trip).  What matters most is how evenly
 // tiles*splits workgroups divide over the 256 CUs (192 tiles: 1, 2 or 3 splits all leave a CU with 180 k-tiles, 4 splits
 // give every CU 3 x 45), then whether enough workgroups are co-resident to hide the per-k-tile DMA latency, then the cost
 // of the fp32 partial-sum round trip.
-static int choose_splits(long tiles, int nk, const TileInfo& ti, bool pipelined, size_t mn) {
+static int choose_splits(long tiles, int nk, const TileInfo& ti, int loop, size_t mn) {
   const double area = (double)ti.bm * ti.bn / (128.0 * 128.0);
   const double t_mfma = 0.75 * area;                 // MFMA-pipe time of one k-tile of one workgroup
-  const double t_lat = pipelined ? 0.4 : 1.0;        // exposed DMA latency per k-tile of a workgroup running alone
+  const double t_lat = loop == 0 ? 1.0 : (loop == 1 ? 0.4 : (loop == 2 ? 0.2 : 0.1));   // exposed DMA latency per k-tile, workgroup alone
   const double t_epi = 0.27 + 1.73 * area;
-  const int coresident = pipelined ? ti.cores_pipe : ti.cores_plain;
+  const int coresident = loop == 0 ? ti.cores_plain : (loop == 1 ? ti.cores_pipe : 1);
   const double red_fixed = 6.0, red_per_split = (double)mn * 8.0 / 3.0e12 / 0.7e-6;
   int best = 1;
   double best_t = 1e30;
@@ -717,12 +773,14 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   p.nt16 = d.N / 16;
   // ---- kernel configuration: explicit (cfg >= 1) or the built-in heuristic (128x128 once the grid fills the chip, else 64x64)
   int tile, loop = 0, order = -1;
-  MVD_CHECK_ARG(d.cfg >= 0 && d.cfg <= 4 * MVD_GEMM_TILES, "mvd_gemm: bad cfg %d", d.cfg);
+  MVD_CHECK_ARG(d.cfg >= 0 && d.cfg <= 8 * MVD_GEMM_TILES, "mvd_gemm: bad cfg %d", d.cfg);
   if (d.cfg >= 1) {
-    tile = (d.cfg - 1) >> 2;
-    loop = ((d.cfg - 1) >> 1) & 1;
+    tile = (d.cfg - 1) / 8;
+    loop = ((d.cfg - 1) % 8) >> 1;
     order = (d.cfg - 1) & 1;
     MVD_CHECK_ARG(tile < 2 || d.epi == MVD_EPI_STORE, "mvd_gemm: cfg %d (80-column tile) serves MVD_EPI_STORE only", d.cfg);
+    MVD_CHECK_ARG(loop < 2 || kTiles[tile].waves == 8, "mvd_gemm: cfg %d: the staggered loop needs an 8-wave tile", d.cfg);
+    MVD_CHECK_ARG(loop < 3 || tile == 1, "mvd_gemm: cfg %d: four LDS buffers fit the 128x128 tile only", d.cfg);
   } else {
     const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
     tile = (tiles128 >= 128 && (d.N >= 512 || d.K >= 2048)) ? 1 : 0;
@@ -740,7 +798,7 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   p.m_fastest = order;
   int splits = d.splitk;
   const long tiles = (long)p.tiles_m * p.tiles_n;
-  if (splits == 0) splits = choose_splits(tiles, p.nk, ti, loop == 1, (size_t)d.M * d.N);
+  if (splits == 0) splits = choose_splits(tiles, p.nk, ti, loop, (size_t)d.M * d.N);
   if (splits < 1) splits = 1;
   if (splits > p.nk) splits = p.nk;
   if (splits > 1) {
@@ -753,17 +811,21 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   p.kt_per_split = cdiv(p.nk, splits);
   p.splits = cdiv(p.nk, p.kt_per_split);
   hipStream_t s = (hipStream_t)stream;
-  switch (tile * 2 + loop) {
+  switch (tile * 4 + loop) {
     case 0: launch_cfg<64, 64, 2, 2, 2>(p, s); break;
     case 1: launch_cfg<64, 64, 2, 2, 3>(p, s); break;
-    case 2: launch_cfg<128, 128, 2, 4, 2>(p, s); break;
-    case 3: launch_cfg<128, 128, 2, 4, 3>(p, s); break;
-    case 4: launch_cfg<128, 80, 4, 1, 2>(p, s); break;
-    case 5: launch_cfg<128, 80, 4, 1, 3>(p, s); break;
-    case 6: launch_cfg<64, 80, 4, 1, 2>(p, s); break;
-    case 7: launch_cfg<64, 80, 4, 1, 3>(p, s); break;
-    case 8: launch_cfg<128, 160, 4, 2, 2>(p, s); break;
-    default: launch_cfg<128, 160, 4, 2, 3>(p, s); break;
+    case 4: launch_cfg<128, 128, 2, 4, 2>(p, s); break;
+    case 5: launch_cfg<128, 128, 2, 4, 3>(p, s); break;
+    case 6: launch_cfg<128, 128, 2, 4, 4>(p, s); break;
+    case 7: launch_cfg<128, 128, 2, 4, 5>(p, s); break;
+    case 8: launch_cfg<128, 80, 4, 1, 2>(p, s); break;
+    case 9: launch_cfg<128, 80, 4, 1, 3>(p, s); break;
+    case 12: launch_cfg<64, 80, 4, 1, 2>(p, s); break;
+    case 13: launch_cfg<64, 80, 4, 1, 3>(p, s); break;
+    case 16: launch_cfg<128, 160, 4, 2, 2>(p, s); break;
+    case 17: launch_cfg<128, 160, 4, 2, 3>(p, s); break;
+    case 18: launch_cfg<128, 160, 4, 2, 4>(p, s); break;
+    default: MVD_CHECK_ARG(false, "mvd_gemm: no kernel for tile %d loop %d", tile, loop);
   }
   MVD_CHECK_LAUNCH("mvd_gemm");
   if (p.splits > 1) {

@@ -351,23 +351,37 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     return out
 
 
-# mvd_gemm_desc.cfg = 1 + 4 * tile + 2 * loop + order (include/mvd_hip.h)
+# mvd_gemm_desc.cfg = 1 + 8 * tile + 2 * loop + order (include/mvd_hip.h)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
-GEMM_CONFIGS = tuple(range(1, 4 * len(GEMM_TILES) + 1))
+GEMM_LOOPS = (2, 3, 4, 5)       # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups (3 / 4 LDS buffers)
+
+
+def _cfg_parts(cfg):
+    return (cfg - 1) // 8, ((cfg - 1) % 8) >> 1, (cfg - 1) & 1          # tile, loop, order
+
+
+def _cfg_valid(cfg, epi):
+    tile, loop, _ = _cfg_parts(cfg)
+    bm, bn, wm, wn = GEMM_TILES[tile]
+    return (loop < 2 or wm * wn == 8) and (loop < 3 or tile == 1) and (tile < 2 or epi == EPI_STORE)
+
+
+GEMM_CONFIGS = tuple(c for c in range(1, 8 * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
 
 
 def gemm_configs(epi=EPI_STORE):
-    """Kernel configurations valid for an epilogue (the 80-column tiles serve EPI_STORE only)."""
-    return GEMM_CONFIGS if epi == EPI_STORE else GEMM_CONFIGS[:8]
+    """Kernel configurations valid for an epilogue (the 80-column tiles serve EPI_STORE only; the staggered loop needs an
+    8-wave tile)."""
+    return tuple(c for c in GEMM_CONFIGS if _cfg_valid(c, epi))
 
 
 def kernel_symbol(cfg, prec, conv):
     """The gemm_kernel<BM, BN, WM, WN, NS, AMODE, LOOP> instantiation (as rocprofv3 prints it) that `cfg` selects."""
     if not cfg:
         return f"gemm_kernel<auto, {prec}, {1 if conv else 0}>"
-    bm, bn, wm, wn = GEMM_TILES[(cfg - 1) >> 2]
-    loop = 3 if ((cfg - 1) >> 1) & 1 else 2              # 2 = plain two-buffer loop, 3 = register-pipelined loop
-    return f"gemm_kernel<{bm}, {bn}, {wm}, {wn}, {prec}, {1 if conv else 0}, {loop}>"
+    tile, loop, _ = _cfg_parts(cfg)
+    bm, bn, wm, wn = GEMM_TILES[tile]
+    return f"gemm_kernel<{bm}, {bn}, {wm}, {wn}, {prec}, {1 if conv else 0}, {GEMM_LOOPS[loop]}>"
 
 
 LAST_CFG = 0
