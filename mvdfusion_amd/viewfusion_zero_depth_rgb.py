@@ -62,6 +62,7 @@ class StepEngine:
         self.f256 = _sinusoid_freqs(256).to(dev)
         self.funet = _sinusoid_freqs(model.unet_model.unet_model.model_channels).to(dev)
         self.graphs = {}
+        self.drop_masks = None     # training forward: (clip_mask, volume_mask, concat_mask), each (Vq,) in {0, 1} (unet.py:140-151)
         self.n_rows = 1            # rows of the device step table; the kernels index steps[iter], noise[iter] unchecked
         self.done = 0              # host mirror of the device iteration counter
 
@@ -117,11 +118,22 @@ class StepEngine:
         ctx.gemv_rows(p[0].weight, p[0].bias, self.clip_v_embed[q0:q0 + Vq], c1, act_out=hip.ACT_SILU)
         ctx.gemv_rows(p[2].weight, p[2].bias, c1, c2, act_out=hip.ACT_SILU)
         ctx.gemv_rows(p[4].weight, p[4].bias, c2, self.context[:Vq])
+        if self.drop_masks is not None:        # UNetWrapper.forward(is_train=True) condition dropout (eager only, never captured)
+            clip_m, vol_m, cat_m = self.drop_masks
+            self.context[:Vq] *= clip_m[:, None]
+            self.vol.view(B, -1)[:Vq] *= vol_m[:, None]
+            vp = self.vol_planes.view(B, S * S * D, -1)
+            vp[:Vq, :, 2 * self.vol_col:] *= vol_m.to(torch.int16)[:, None, None]        # x * {0, 1} keeps / zeroes the planes
         ctx.context = self.context
         # UNet on the CFG batch (unet.py:167-196)
         xq, x0q, epsq = self.x[q0:q0 + Vq], self.x0[q0:q0 + Vq], self.eps[q0:q0 + Vq]
         hip.check(L.mvd_unet_input(hip.ptr(xq), hip.ptr(self.input_latents), hip.ptr(self.x_in), Vq, S, 32,
                                    int(self.cfg), st()))
+        if self.drop_masks is not None:        # x_concat channels 5..9 of the (rows, [32 hi | 32 lo]) input planes
+            xin = self.x_in.view(B, S * S, 64)
+            cm = self.drop_masks[2].to(torch.int16)[:, None, None]
+            xin[:Vq, :, 5:10] *= cm
+            xin[:Vq, :, 37:42] *= cm
         unet = m.unet_model.unet_model
         ctx.vol_levels = m.unet_model.volume_pyramid(ctx, self.vol.view(B, S, S, D, 768), B, S, D)
         tsu = ctx.ws.get("vf.tsin_unet", (1, unet.model_channels))
@@ -320,9 +332,12 @@ class ViewFusion(nn.Module):
 
     @torch.no_grad()
     def apply_model(self, noisy_latents, batch_cameras, input_latents, input_cameras, clip_v_embed, t, prev_depth=None,
-                    cfg_scale=1.0, depth_noise=None):
+                    cfg_scale=1.0, depth_noise=None, drop_rand=None):
         """viewfusion_zero_depth_rgb.py:282-345.  ``depth_noise`` (V,D,S,S) optionally injects the N(0,1) draw that
-        the reference takes inside GridAttn (view_attn_efficient2.py:431); default: torch's device generator."""
+        the reference takes inside GridAttn (view_attn_efficient2.py:431); default: torch's device generator.
+        With cfg_scale == 1 the reference calls UNetWrapper.forward(is_train=True): when the model was built with
+        drop_conditions=True and is in training mode, the per-view condition dropout of unet.py:109-151 is applied
+        (``drop_rand`` (V,) optionally injects its torch.rand draw)."""
         assert prev_depth is None, "feed_prev_depth is not part of the shipped configurations"
         V, _, S, _ = noisy_latents.shape
         D = self.view_attn.n_pts_per_ray
@@ -337,7 +352,16 @@ class ViewFusion(nn.Module):
             depth_noise = torch.randn(V, D, S, S, device=noisy_latents.device)
         eng.set_schedule(table, depth_noise.reshape(1, V, D, S, S), torch.zeros(1, V, 5, S, S))
         eng.x.copy_(noisy_latents)
-        eng.step(cfg_scale, do_update=False)
+        eng.drop_masks = None
+        if not cfg and self.drop_conditions and self.training:
+            r = torch.rand(V, device=noisy_latents.device) if drop_rand is None else drop_rand.to(noisy_latents.device).float()
+            drop_clip, drop_vol = (r > 0.15) & (r <= 0.2), (r > 0.1) & (r <= 0.15)          # get_drop_scheme 'default' (unet.py:109-117)
+            drop_cat, drop_all = (r > 0.05) & (r <= 0.1), r <= 0.05
+            eng.drop_masks = tuple(1.0 - (dm | drop_all).float() for dm in (drop_clip, drop_vol, drop_cat))
+        try:
+            eng.step(cfg_scale, do_update=False, use_graph=eng.drop_masks is None)
+        finally:
+            eng.drop_masks = None
         return hip.check_finite(eng.eps.clone(), "ViewFusion.apply_model")
 
     def sample(self, batch, trainer_config, cfg_scale, return_input=False, depth=False, verbose=True):
@@ -350,10 +374,42 @@ class ViewFusion(nn.Module):
             return x_sample, batch_latents, input_latents, batch_cameras, intermediates
         return res
 
+    @torch.no_grad()
+    def p_losses(self, batch, trainer_config, noise_source=None):
+        """viewfusion_zero_depth_rgb.py:362-392 -- the training objective's FORWARD pass on the HIP path: prepare_batch, shared
+        random timestep, q_sample, apply_model (cfg 1, condition dropout when self.training), MSE against the noise.
+        The value is a plain tensor: there are no backward kernels yet, so it serves validation /
+        loss monitoring, not optimisation.  ``noise_source(V, D, S) -> dict(t, noise, depth_noise, drop_rand)`` injects the
+        reference's random draws (parity tests); default: torch's device generator in the reference's order."""
+        batch_latents, batch_cameras, input_latents, input_cameras, clip_v_embed = self.prepare_batch(batch, trainer_config)
+        V, _, S, _ = batch_latents.shape
+        D = self.view_attn.n_pts_per_ray
+        dev = batch_latents.device
+        if noise_source is not None:
+            ns = noise_source(V, D, S)
+            t, noise = ns["t"].to(dev), ns["noise"].to(dev)
+            depth_noise, drop_rand = ns["depth_noise"].to(dev), ns["drop_rand"].to(dev)
+        else:
+            t = self.scheduler.sample_random_times(V, share_t=True, device=dev)
+            noise = torch.randn_like(batch_latents)
+            depth_noise, drop_rand = torch.randn(V, D, S, S, device=dev), torch.rand(V, device=dev)
+        sac = self.scheduler.sqrt_alphas_cumprod.to(dev)[t].view(V, 1, 1, 1)
+        s1m = self.scheduler.sqrt_one_minus_alphas_cumprod.to(dev)[t].view(V, 1, 1, 1)
+        noisy = sac * batch_latents + s1m * noise                                          # scheduler.q_sample (:55-64)
+        pred = self.apply_model(noisy, batch_cameras, input_latents, input_cameras, clip_v_embed, t, depth_noise=depth_noise,
+                                drop_rand=drop_rand)
+        if self.objective == "noise":
+            target = noise
+        elif self.objective == "x_start":
+            target = batch_latents
+        else:
+            raise AssertionError(f"objective {self.objective} not implemented")
+        assert self.loss_type == "l2", "loss_type 'l2' is the only one the reference implements (:86-87)"
+        return torch.nn.functional.mse_loss(target, pred).mean()
+
     def forward(self, batch, trainer_config):
-        raise NotImplementedError(
-            "training (p_losses, viewfusion_zero_depth_rgb.py:362-397) needs backward kernels; it is the next row of the "
-            "scope table (SURVEY.md section 8f rank 4) and is not built in this round")
+        """viewfusion_zero_depth_rgb.py:394-397.  Forward value only -- see p_losses; .backward() on it raises."""
+        return self.p_losses(batch, trainer_config)
 
     def configure_optimizers(self, lr=None, verbose=False):
         lr = self.learning_rate if lr is None else lr

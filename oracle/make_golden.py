@@ -496,6 +496,97 @@ def gold_prepare_batch(tag, random_views, with_depths, seed):
     save(tag, seed=np.int64(seed), batch_latents=bl, input_latents=il, clip_v_embed=cv, bc_R=bc.R, bc_T=bc.T,
          bc_f=bc.focal_length, bc_p=bc.principal_point, ic_R=ic.R, ic_T=ic.T, ic_f=ic.focal_length, ic_p=ic.principal_point)
 
+def gold_train_loss(model_channels, V, D, tag, seed, S_img=256):
+    """The REAL ViewFusion.forward / p_losses (viewfusion_zero_depth_rgb.py:362-397) -- prepare_batch (reference VAE ch=32,
+    stub CLIP), shared random timestep, q_sample, GridAttn + UNetWrapper.forward(is_train=True) WITH the condition dropout
+    of unet.py:109-151, MSE -- on a seeded 16-view GSO batch.  The seed is chosen so that the dropout masks are not all-keep.
+    Stored: the loss, the prediction (strided), and the random draws of this call in the reference's order (timestep,
+    q_sample noise [re-derivable], depth-sample noise [re-derivable], dropout uniform)."""
+    import torch.nn as nn
+    from external.sd1.ldm.models.autoencoder import AutoencoderKL
+    from mvdfusion.view_attn_efficient2 import GridAttn
+    from mvdfusion.scheduler import DDPMScheduler
+    from mvdfusion.unet import UNetWrapper
+    from mvdfusion.viewfusion_zero_depth_rgb import ViewFusion
+    S = S_img // 8
+
+    class Facade(nn.Module):
+        prepare_batch = ViewFusion.prepare_batch
+        encode = ViewFusion.encode
+        encode_clip = ViewFusion.encode_clip
+        embed_time = ViewFusion.embed_time
+        apply_model = ViewFusion.apply_model
+        p_losses = ViewFusion.p_losses
+        forward = ViewFusion.forward
+
+        def __init__(self):
+            super().__init__()
+            dd = dict(VAE_DDCONFIG)
+            dd["ch"] = 32
+            self.vae = AutoencoderKL(ddconfig=dd, lossconfig=dict(target="torch.nn.Identity"), embed_dim=4)
+            fill_ref(self.vae, "vae.")
+            self.clip_image_encoder = syn.StubClipImageEncoder()
+            self.z_scale_factor, self.embed_camera_pose = 0.18215, True
+            self.view_attn = GridAttn(in_channels=5, input_size=S, output_dim=768, num_layers=3, z_near_far_scale=0.8,
+                                      n_pts_per_ray=D)
+            w = UNetWrapper.__new__(UNetWrapper)
+            nn.Module.__init__(w)
+            w.unet_model = _unet(model_channels, S)
+            w.drop_conditions, w.drop_scheme, w.use_zero_123 = True, "default", True
+            self.unet_model = w
+            self.scheduler = DDPMScheduler(1000)
+            self.cc_projection = nn.Sequential(nn.Linear(796, 768), nn.SiLU(True), nn.Linear(768, 768), nn.SiLU(True),
+                                               nn.Linear(768, 768))
+            self.time_embed_dim = 256
+            self.time_embed = nn.Sequential(nn.Linear(256, 256), nn.SiLU(True), nn.Linear(256, 256))
+            self.feed_prev_depth, self.objective = False, "noise"
+            self.loss_fn = torch.nn.functional.mse_loss
+            self.register_buffer("_device", torch.tensor([0.0]), persistent=False)
+
+    m = Facade()
+    for name in ("view_attn", "cc_projection", "time_embed"):
+        fill_ref(getattr(m, name), name + ".")
+    m.train()                                    # is_train=True path; the model has no dropout / batch-norm layers
+    rig = syn.gso_rig()
+    g = torch.Generator().manual_seed(seed)
+    batch = dict(images=torch.rand(16, 3, S_img, S_img, generator=g), R=rig.R, T=rig.T, f=rig.focal_length, c=rig.principal_point,
+                 depths=torch.rand(16, 1, S_img, S_img, generator=g))
+    cfg = dict(input_batch_size=1, train_batch_size=V, random_views=False)
+    # the draws of p_losses in order: randint (V,), randn (V,5,S,S), [GridAttn] normal == mean + std * randn (V,D,S,S), rand (V,)
+    draw_seed = None
+    for cand in range(1000, 1100):
+        torch.manual_seed(cand)
+        torch.randint(0, 1000, (V,))
+        torch.randn(V, 5, S, S)
+        torch.randn(V, D, S, S)
+        r = torch.rand(V)
+        if bool((r <= 0.2).any()) and bool((r > 0.2).any()):
+            draw_seed = cand
+            break
+    torch.manual_seed(draw_seed)
+    t_draw = torch.randint(0, 1000, (V,))
+    torch.randn(V, 5, S, S)
+    torch.randn(V, D, S, S)
+    drop_rand = torch.rand(V)
+    preds = {}
+    orig = Facade.apply_model
+
+    def spy(self, *a, **k):
+        out = orig(self, *a, **k)
+        preds["pred"] = out.detach().clone()
+        return out
+
+    Facade.apply_model = spy
+    torch.manual_seed(draw_seed)
+    t0 = time.time()
+    with torch.no_grad():
+        loss = m(batch, cfg)
+    print(f"  train loss mc={model_channels} V={V} D={D}: ref {time.time() - t0:.1f}s, loss {float(loss):.6f}, draw seed {draw_seed}, "
+          f"t {int(t_draw[0])}, drop uniform {[round(float(x), 3) for x in drop_rand]}")
+    save(tag, loss=loss, pred_strided=preds["pred"][:, :, ::3, ::5].contiguous(), pred_std=preds["pred"].std(), batch_seed=np.int64(seed),
+         draw_seed=np.int64(draw_seed), t=t_draw, drop_rand=drop_rand)
+
+
 ALL = {
     "schedule": gold_schedule,
     "cameras": gold_cameras,
@@ -514,6 +605,7 @@ ALL = {
     "unet320_s64": lambda: gold_unet(320, 2, 1, "unet_mc320_v2_d1_s64", S=64, full=False),
     "unet320_d3": lambda: gold_unet(320, 2, 3, "unet_mc320_v2_d3", t_val=501),
     "gridattn_v15": gold_gridattn_v15,
+    "train32_d3": lambda: gold_train_loss(32, 4, 3, "train_loss_mc32_v4_d3", seed=31),
     "traj32": lambda: gold_trajectory(32, 4, 1, "traj_mc32_v4_d1", steps=5),
     "traj320": lambda: gold_trajectory(320, 4, 1, "traj_mc320_v4_d1_50steps", steps=50),
     "traj320_f64": lambda: gold_trajectory_f64(320, 4, 1, "traj_mc320_v4_d1_50steps_f64", steps=50),

@@ -173,3 +173,59 @@ def test_sample_then_decode_end_to_end():
     img = m.decode(x[:, :4])
     assert img.shape == (4, 3, 256, 256) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
     assert bool(torch.isfinite(img).all())
+
+
+def test_training_forward_loss_vs_reference_golden():
+    """ViewFusion.forward / p_losses (viewfusion_zero_depth_rgb.py:362-397) on the HIP path against the REAL reference's loss:
+    prepare_batch (HIP VAE encode, stub CLIP), shared timestep, q_sample, GridAttn with D = 3 depth samples, the UNet's training
+    call WITH per-view condition dropout (unet.py:109-151: view 2 of this draw drops its concat latents), MSE.  The random
+    draws are replayed in the reference's order from the fixture's seed (oracle/make_golden.py: train32_d3).  Forward value
+    only: the product has no backward kernels yet."""
+    from conftest import model_config
+    from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
+    gd = load_golden("train_loss_mc32_v4_d3")
+    V, D, S = 4, 3, 32
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    cfg = model_config(32, D=D)
+    cfg["vae_config"] = dict(target="external.sd1.ldm.models.autoencoder.AutoencoderKL",
+                             params=dict(embed_dim=4, ddconfig=dd, lossconfig=dict(target="torch.nn.Identity")))
+    m = ViewFusion(clip_image_encoder=syn.StubClipImageEncoder(), **cfg)
+    syn.fill_module_(m)
+    m = m.cuda().train()
+    assert m.drop_conditions
+    rig = syn.gso_rig()
+    g = torch.Generator().manual_seed(int(gd["batch_seed"]))
+    batch = dict(images=torch.rand(16, 3, 256, 256, generator=g).cuda(), R=rig.R, T=rig.T, f=rig.focal_length, c=rig.principal_point,
+                 depths=torch.rand(16, 1, 256, 256, generator=g).cuda())
+    tc = dict(input_batch_size=1, train_batch_size=V, random_views=False)
+
+    def draws(V_, D_, S_):
+        torch.manual_seed(int(gd["draw_seed"]))
+        t = torch.randint(0, 1000, (V_,))
+        t = torch.zeros_like(t) + t[0]                          # share_t=True (scheduler.py:47-48)
+        noise = torch.randn(V_, 5, S_, S_)
+        dn = torch.randn(V_, D_, S_, S_)
+        dr = torch.rand(V_)
+        assert torch.equal(dr, gd["drop_rand"]) and int(t[0]) == int(gd["t"][0])
+        return dict(t=t, noise=noise, depth_noise=dn, drop_rand=dr)
+
+    pred_box = {}
+    real_apply = m.apply_model
+
+    def spy(*a, **k):
+        out = real_apply(*a, **k)
+        pred_box["pred"] = out.detach().cpu()
+        return out
+
+    m.apply_model = spy
+    loss = m.p_losses(batch, tc, noise_source=draws)
+    ref = float(gd["loss"])
+    print(f"training forward loss: HIP {float(loss):.6f}  reference {ref:.6f}")
+    assert rel_err(pred_box["pred"][:, :, ::3, ::5], gd["pred_strided"]) < 3e-4
+    assert abs(float(loss) - ref) / ref < 1e-4
+    # eval mode: no dropout -> a different (deterministic) value; and the value carries no autograd graph
+    m.eval()
+    loss_eval = m.p_losses(batch, tc, noise_source=draws)
+    assert abs(float(loss_eval) - float(loss)) > 1e-6 and not loss.requires_grad
