@@ -105,10 +105,10 @@ def profile_kernel_groups(m, eng, cfg_scale):
                          flops=2.0 * M * N * Kp, bytes=abytes, ev=(e0, e1)))
         return r
 
-    def timed_attention(planes, out, B, heads, L, dhead, prec=hip.PREC_X4):
+    def timed_attention(planes, out, B, heads, L, dhead, prec=hip.PREC_X4, Lkeys=0):
         e0, e1 = ev_pair()
         e0.record()
-        r = real["attention"](planes, out, B, heads, L, dhead, prec=prec)
+        r = real["attention"](planes, out, B, heads, L, dhead, prec=prec, Lkeys=Lkeys)
         e1.record()
         groups["attention"].append(dict(flops=4.0 * B * heads * L * L * dhead, bytes=0.0, ev=(e0, e1)))
         return r
@@ -121,10 +121,10 @@ def profile_kernel_groups(m, eng, cfg_scale):
         groups["groupnorm"].append(dict(flops=0.0, bytes=12.0 * B * HW * Cc, ev=(e0, e1)))   # read x twice, write planes
         return r
 
-    def timed_layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False):
+    def timed_layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False, y_f32=None):
         e0, e1 = ev_pair()
         e0.record()
-        r = real["layernorm"](x, y, w, b, rows, Cc, eps, w_plus_one)
+        r = real["layernorm"](x, y, w, b, rows, Cc, eps, w_plus_one, y_f32)
         e1.record()
         groups["layernorm"].append(dict(flops=0.0, bytes=8.0 * rows * Cc, ev=(e0, e1)))
         return r

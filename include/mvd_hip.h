@@ -81,6 +81,7 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, floa
 #define MVD_ACT_NONE 0
 #define MVD_ACT_GELU 1 /* exact erf GELU (nn.GELU(), F.gelu) */
 #define MVD_ACT_SILU 2
+#define MVD_ACT_QUICKGELU 3 /* x * sigmoid(1.702 x): the MLP activation of OpenAI CLIP's vision transformer */
 
 #define MVD_GEMM_TILES 5 /* tile shapes of mvd_gemm_desc.cfg */
 #define MVD_B_PACKED 0   /* B: weight image of mvd_pack_linear_weight / mvd_pack_conv3x3_weight */
@@ -181,8 +182,8 @@ int mvd_softmax_rows(const float* x, void* y_sp, int rows, int cols, int ldx, fl
 
 /* LayerNorm over the last dim.  w/b may be NULL (no affine).  w_plus_one: y = norm * (1 + w) + b
  * (adaLN "modulate", view_attn_efficient2.py:15-16,51,53,65-66); attention.py:211-213, mvdfusion/attention.py:35-37. */
-int mvd_layernorm(const float* x, void* y_sp, const float* w, const float* b, int rows, int C, float eps,
-                  int w_plus_one, mvd_stream_t stream); /* y_sp: split planes (rows, C), C % 32 == 0 */
+int mvd_layernorm(const float* x, void* y_sp, float* y_f32, const float* w, const float* b, int rows, int C, float eps,
+                  int w_plus_one, mvd_stream_t stream); /* y_sp: split planes (rows, C), C % 32 == 0, and / or y_f32: fp32 (rows, C) */
 
 /* ------------------------------------------------------------------------------------------------
  * Self-attention over the tokens of one view (CrossAttention with context=None, attention.py:170-193).
@@ -194,8 +195,10 @@ int mvd_layernorm(const float* x, void* y_sp, const float* w, const float* b, in
 size_t mvd_attn_qk_plane_elems(int B, int heads, int L, int dhead);
 size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead);
 int mvd_attn_lpad(int L);
+/* L = tokens (rows) per batch item; Lkeys (0 = L) = the leading tokens that take part as KEYS: a sequence padded to a multiple
+ * of 4 rows (CLIP: 257 -> 260) keeps its padding rows out of every softmax. */
 int mvd_attention(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
-                  const void* vt_lo, void* out_sp, int ldo, int B, int heads, int L, int dhead, int prec,
+                  const void* vt_lo, void* out_sp, int ldo, int B, int heads, int L, int Lkeys, int dhead, int prec,
                   mvd_stream_t stream);
 
 /* Per-pixel cross attention of one query token against D context tokens (DualAttnetionBlock attn2,

@@ -18,7 +18,7 @@ template <int DQ, int DV, int NS>
 __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
                                                    const u16* __restrict__ k_hi, const u16* __restrict__ k_lo,
                                                    const u16* __restrict__ vt_hi, const u16* __restrict__ vt_lo,
-                                                   u16* __restrict__ out_sp, int ldo, int H, int L, int Lpad, int dhead) {
+                                                   u16* __restrict__ out_sp, int ldo, int H, int L, int Lk, int Lpad, int dhead) {
   constexpr int NPL = NS >= 3 ? 2 : 1;
   constexpr int KP = DQ + 8;       // LDS pitch of a K row (bf16 elements)
   constexpr int VP = KV_TILE + 8;  // LDS pitch of a V^T row
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
   for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (L + KV_TILE - 1) / KV_TILE;
+  const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;     // keys [0, Lk) take part (Lk <= L: trailing padding tokens are masked)
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * KV_TILE;
     __syncthreads();
@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
     }
     // ---- online softmax (per query column c; keys are spread over registers and the 4 lane groups)
     // (q carries dhead^-0.5 * log2(e) from the QKV epilogue, so the scores are base-2 logits: exp2 below is a bare v_exp_f32)
-    if (kv0 + KV_TILE > L) {      // ragged last tile only (uniform branch): keys past L do not take part
+    if (kv0 + KV_TILE > Lk) {     // ragged last tile only (uniform branch): keys past Lk do not take part
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (kv0 + kt * 16 + g * 4 + r >= L) s[kt][r] = -INFINITY;
+          if (kv0 + kt * 16 + g * 4 + r >= Lk) s[kt][r] = -INFINITY;
     }
     float mt = -INFINITY;
 #pragma unroll
@@ -338,14 +338,14 @@ __global__ __launch_bounds__(256) void view_pool_kernel(const float* __restrict_
 
 template <int NS>
 int launch_attn(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi, const void* vt_lo,
-                void* out_sp, int ldo, int B, int H, int L, int Lpad, int dhead, hipStream_t s) {
+                void* out_sp, int ldo, int B, int H, int L, int Lk, int Lpad, int dhead, hipStream_t s) {
   const int dq = (dhead + 31) & ~31, dv = (dhead + 15) & ~15;
   dim3 grid((Lpad / 64) * H * B), block(256);
 #define MVD_ATTN_CASE(DQ, DV)                                                                                          \
   if (dq == DQ && dv == DV) {                                                                                          \
     hipLaunchKernelGGL((attn_kernel<DQ, DV, NS>), grid, block, 0, s, (const u16*)q_hi, (const u16*)q_lo,               \
                        (const u16*)k_hi, (const u16*)k_lo, (const u16*)vt_hi, (const u16*)vt_lo, (u16*)out_sp, ldo, H, \
-                       L, Lpad, dhead);                                                                                \
+                       L, Lk, Lpad, dhead);                                                                            \
     return 0;                                                                                                          \
   }
   MVD_ATTN_CASE(32, 16)
@@ -369,20 +369,22 @@ extern "C" size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead) {
 }
 
 extern "C" int mvd_attention(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
-                             const void* vt_lo, void* out_sp, int ldo, int B, int heads, int L, int dhead, int prec,
+                             const void* vt_lo, void* out_sp, int ldo, int B, int heads, int L, int Lkeys, int dhead, int prec,
                              mvd_stream_t stream) {
   MVD_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out_sp, "mvd_attention: null pointer");
   MVD_CHECK_ARG(B > 0 && heads > 0 && L > 0 && dhead > 0 && dhead % 4 == 0, "mvd_attention: bad shape (dhead %% 4 == 0)");
   MVD_CHECK_ARG(ldo % 32 == 0 && ((uintptr_t)out_sp & 127) == 0, "mvd_attention: out must be split planes (ldo %% 32 == 0, 128-byte aligned)");
   MVD_CHECK_ARG(prec == MVD_PREC_BF16 || prec == MVD_PREC_BF16X3 || prec == MVD_PREC_X4, "mvd_attention: bad prec");
   const int Lpad = mvd_attn_lpad(L);
+  const int Lk = Lkeys > 0 ? Lkeys : L;
+  MVD_CHECK_ARG(Lk <= L, "mvd_attention: Lkeys=%d must be <= L=%d", Lk, L);
   int rc;
   if (prec == MVD_PREC_X4)
-    rc = launch_attn<4>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+    rc = launch_attn<4>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lk, Lpad, dhead, (hipStream_t)stream);
   else if (prec == MVD_PREC_BF16X3)
-    rc = launch_attn<3>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+    rc = launch_attn<3>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lk, Lpad, dhead, (hipStream_t)stream);
   else
-    rc = launch_attn<1>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lpad, dhead, (hipStream_t)stream);
+    rc = launch_attn<1>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lk, Lpad, dhead, (hipStream_t)stream);
   MVD_CHECK_ARG(rc == 0, "mvd_attention: unsupported head dim %d (supported: <=32, 33..64, 65..96 with dv 80, 160)", dhead);
   MVD_CHECK_LAUNCH("mvd_attention");
   return 0;

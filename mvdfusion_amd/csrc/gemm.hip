@@ -54,6 +54,7 @@ struct GemmParams {
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == MVD_ACT_GELU) return gelu_erf(v);
   if (act == MVD_ACT_SILU) return silu_f(v);
+  if (act == MVD_ACT_QUICKGELU) return v / (1.0f + expf(-1.702f * v));       // x * sigmoid(1.702 x) (OpenAI CLIP QuickGELU)
   return v;
 }
 
@@ -558,18 +559,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       const int dq = (d.dhead + 31) & ~31;
       u16* ph = (u16*)(which == 0 ? d.q_hi : d.k_hi);
       u16* pl = (u16*)(which == 0 ? d.q_lo : d.k_lo);
-      const float sc = (which == 0 ? d.qscale : 1.0f) * d.acc_scale;
 #pragma unroll
       for (int ps = 0; ps < WTM / 8; ++ps) {
         const int row = ps * 8 + (lane >> 3), col = (lane & 7) * 4;
         const int m = wm0 + row, n = wn0 + col;
         if (m >= d.M) continue;
-        const float4 v = *(const float4*)(sC + row * LDW + col);
+        float4 v = *(const float4*)(sC + row * LDW + col);
         const int cc = n - which * C;
         const int head = cc / d.dhead, dd = cc - head * d.dhead;
         const int b = m / d.L, tok = m - b * d.L;
         const size_t idx = ((size_t)(b * d.heads + head) * d.Lpad + tok) * dq + dd;
-        store_planes4(ph, pl, idx, v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+        const float qs = which == 0 ? d.qscale : 1.0f;
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias) bb = *(const float4*)(d.bias + n);        // in_proj bias (nn.MultiheadAttention, timm qkv_bias); SD attention has none
+        store_planes4(ph, pl, idx, (v.x * d.acc_scale + bb.x) * qs, (v.y * d.acc_scale + bb.y) * qs, (v.z * d.acc_scale + bb.z) * qs,
+                      (v.w * d.acc_scale + bb.w) * qs);
       }
     } else {                      // V^T: each lane takes 4 consecutive tokens of one channel (8-byte stores, keys contiguous)
       const int dv = (d.dhead + 15) & ~15;
@@ -583,8 +587,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         if (m >= d.M) continue;
         const int b = m / d.L, tok = m - b * d.L;
         const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
-        store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, sC[row * LDW + col] * d.acc_scale, sC[(row + 1) * LDW + col] * d.acc_scale,
-                      sC[(row + 2) * LDW + col] * d.acc_scale, sC[(row + 3) * LDW + col] * d.acc_scale);
+        const float bv = d.bias ? d.bias[wn0 + col] : 0.f;
+        store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, sC[row * LDW + col] * d.acc_scale + bv, sC[(row + 1) * LDW + col] * d.acc_scale + bv,
+                      sC[(row + 2) * LDW + col] * d.acc_scale + bv, sC[(row + 3) * LDW + col] * d.acc_scale + bv);
       }
     }
     return;

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 // LayerNorm: one wave per row, C <= 1280 (5 float4 per lane); two-pass statistics in registers.
 template <int MAXV>
-__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, u16* __restrict__ y_sp,
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, u16* __restrict__ y_sp, float* __restrict__ y_f32,
                                                  const float* __restrict__ w, const float* __restrict__ bia, int rows, int C, float eps,
                                                  int w_plus_one) {
   const int lane = threadIdx.x & 63;
@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, u1
         o.z += bb.z;
         o.w += bb.w;
       }
-      store_sp4(y_sp, (size_t)row, C, idx * 4, o.x, o.y, o.z, o.w);
+      if (y_sp) store_sp4(y_sp, (size_t)row, C, idx * 4, o.x, o.y, o.z, o.w);
+      if (y_f32) ((float4*)(y_f32 + (size_t)row * C))[idx] = o;
     }
   }
 }
@@ -293,20 +294,20 @@ extern "C" int mvd_softmax_rows(const float* x, void* y_sp, int rows, int cols, 
   return 0;
 }
 
-extern "C" int mvd_layernorm(const float* x, void* y_sp, const float* w, const float* b, int rows, int C, float eps,
+extern "C" int mvd_layernorm(const float* x, void* y_sp, float* y_f32, const float* w, const float* b, int rows, int C, float eps,
                              int w_plus_one, mvd_stream_t stream) {
-  MVD_CHECK_ARG(x && y_sp && rows > 0, "mvd_layernorm: bad arguments");
+  MVD_CHECK_ARG(x && (y_sp || y_f32) && rows > 0, "mvd_layernorm: bad arguments");
   MVD_CHECK_ARG(C % 32 == 0, "mvd_layernorm: split-planes output needs C %% 32 == 0 (C=%d)", C);
   u16* yh = (u16*)y_sp;
   MVD_CHECK_ARG(C % 4 == 0 && C >= 4 && C <= 1280, "mvd_layernorm: C=%d must be a multiple of 4 and <= 1280", C);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(cdiv(rows, 4));
   if (C <= 256)
-    hipLaunchKernelGGL(ln_kernel<1>, grid, dim3(256), 0, s, x, yh, w, b, rows, C, eps, w_plus_one);
+    hipLaunchKernelGGL(ln_kernel<1>, grid, dim3(256), 0, s, x, yh, y_f32, w, b, rows, C, eps, w_plus_one);
   else if (C <= 512)
-    hipLaunchKernelGGL(ln_kernel<2>, grid, dim3(256), 0, s, x, yh, w, b, rows, C, eps, w_plus_one);
+    hipLaunchKernelGGL(ln_kernel<2>, grid, dim3(256), 0, s, x, yh, y_f32, w, b, rows, C, eps, w_plus_one);
   else
-    hipLaunchKernelGGL(ln_kernel<5>, grid, dim3(256), 0, s, x, yh, w, b, rows, C, eps, w_plus_one);
+    hipLaunchKernelGGL(ln_kernel<5>, grid, dim3(256), 0, s, x, yh, y_f32, w, b, rows, C, eps, w_plus_one);
   MVD_CHECK_LAUNCH("mvd_layernorm");
   return 0;
 }

@@ -17,7 +17,7 @@ OPERAND_FORMAT = os.environ.get("MVD_OPERAND_FORMAT", "f16")   # chosen before t
 PREC_BF16, PREC_BF16X3, PREC_X4 = 1, 3, 4
 A_DENSE, A_CONV3X3 = 0, 1
 EPI_STORE, EPI_GEGLU, EPI_QKV = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_QUICKGELU = 0, 1, 2, 3
 STEP_STRIDE = 8
 CAM_RECORD = 20
 TOKEN_DIM, TOKEN_LD = 723, 736
@@ -55,12 +55,12 @@ SIGNATURES = {
     "mvd_gemv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_groupnorm_chunks": (_i, [_i]),
     "mvd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
-    "mvd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "mvd_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "mvd_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "mvd_attn_qk_plane_elems": (_sz, [_i, _i, _i, _i]),
     "mvd_attn_vt_plane_elems": (_sz, [_i, _i, _i, _i]),
     "mvd_attn_lpad": (_i, [_i]),
-    "mvd_attention": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _vp]),
+    "mvd_attention": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_unet_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
@@ -458,9 +458,9 @@ def groupnorm(x, y, gamma, beta, B, HW, Cc, eps, silu, ws):
     return y
 
 
-def layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False):
-    """y: split planes (rows, 2*C)."""
-    check(lib().mvd_layernorm(ptr(x), ptr(y), ptr(w), ptr(b), rows, Cc, eps, int(w_plus_one), stream()))
+def layernorm(x, y, w, b, rows, Cc, eps=1e-5, w_plus_one=False, y_f32=None):
+    """y: split planes (rows, 2*C) (or None); y_f32: optional fp32 (rows, C) copy of the result."""
+    check(lib().mvd_layernorm(ptr(x), ptr(y), ptr(y_f32), ptr(w), ptr(b), rows, Cc, eps, int(w_plus_one), stream()))
     return y
 
 
@@ -471,11 +471,11 @@ def softmax_rows(x, y, scale=1.0, out_scale=1.0):
     return y
 
 
-def attention(planes, out, B, heads, L, dhead, prec=PREC_X4):
-    """out: split planes (B*L, 2*heads*dhead)."""
+def attention(planes, out, B, heads, L, dhead, prec=PREC_X4, Lkeys=0):
+    """out: split planes (B*L, 2*heads*dhead).  Lkeys (0 = L): leading tokens of each sequence that act as keys."""
     qh, ql, kh, kl, vh, vl = planes
     check(lib().mvd_attention(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(out), out.shape[-1] // 2, B, heads,
-                              L, dhead, prec, stream()))
+                              L, Lkeys, dhead, prec, stream()))
     return out
 
 

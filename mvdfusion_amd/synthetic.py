@@ -17,7 +17,7 @@ import torch
 from .cameras import Cameras, get_camera_slice, get_relative_camera, look_at_view_transform
 
 _NORM_TOKENS = (".norm.", ".norm1.", ".norm2.", ".norm3.", "in_layers.0.", "out_layers.0.", "out.0.",
-                "aligned_attn_norm.", ".norm_out.")
+                "aligned_attn_norm.", ".norm_out.", ".ln_1.", ".ln_2.", ".ln_pre.", ".ln_post.", ".ln_final.")
 _RESIDUAL_OUT_TOKENS = ("out_layers.3.", ".proj_out.", "aligned_attn_proj_out.", "to_out.0.", "ff.net.2.",
                         "attn.proj.", "mlp.fc2.")
 
@@ -46,7 +46,7 @@ def det_fill(name, shape, dtype=torch.float32):
         v = 0.02 * v
     else:
         v = 0.02 * v
-    return torch.from_numpy(np.ascontiguousarray(v)).to(dtype)
+    return torch.from_numpy(np.ascontiguousarray(v)).to(dtype).reshape(shape)
 
 
 def det_fill_state_dict(spec):

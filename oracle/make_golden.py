@@ -587,6 +587,32 @@ def gold_train_loss(model_channels, V, D, tag, seed, S_img=256):
          draw_seed=np.int64(draw_seed), t=t_draw, drop_rand=drop_rand)
 
 
+def gold_clip(name, tag, B=2, R=256, seed=41):
+    """The REAL FrozenCLIPImageEmbedder (encoders/modules.py:402-441: bicubic resize -> (x+1)/2 -> CLIP mean/std ->
+    model.encode_image -> .float(), .encode() adds the token axis) on seeded images in [-1, 1].  OpenAI's `clip` package is not in
+    the reference tree, so `clip.load` is the structural restatement in oracle/shims.py (published CLIP model.py); weights =
+    name-keyed fill.  Pins the reference's preprocessing / call order and the oracle restatement; the ViT arithmetic itself is
+    only pinned to the published architecture (parity unpinned, see oracle/ref_torch.py)."""
+    from external.sd1.ldm.modules.encoders.modules import FrozenCLIPImageEmbedder
+    enc = FrozenCLIPImageEmbedder(model=name)
+    fill_ref(enc, "clip_image_encoder.")
+    enc.eval()
+    sd = {k: v for k, v in sd_of(enc, "clip_image_encoder.").items() if ".visual." in k}
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, R, R, generator=g) * 2.0 - 1.0
+    t0 = time.time()
+    with torch.no_grad():
+        ref = enc.encode(x)
+    dt = time.time() - t0
+    heads = {"ViT-L/14": 16, "tiny-test": 2}[name]
+    with torch.no_grad():
+        mine = O.clip_image_embed(sd, x, heads=heads)
+    e = rel_err(mine, ref)
+    print(f"  clip {name}: ref {dt:.1f}s, out {tuple(ref.shape)} std {float(ref.std()):.4f}, oracle vs reference rel-max {e:.2e}")
+    assert e < 2e-5, e
+    save(tag, seed=np.int64(seed), out=ref, spec=json.dumps([[k, list(v.shape)] for k, v in enc.state_dict().items()]))
+
+
 ALL = {
     "schedule": gold_schedule,
     "cameras": gold_cameras,
@@ -605,6 +631,8 @@ ALL = {
     "unet320_s64": lambda: gold_unet(320, 2, 1, "unet_mc320_v2_d1_s64", S=64, full=False),
     "unet320_d3": lambda: gold_unet(320, 2, 3, "unet_mc320_v2_d3", t_val=501),
     "gridattn_v15": gold_gridattn_v15,
+    "clip_tiny": lambda: gold_clip("tiny-test", "clip_tiny"),
+    "clip_l14": lambda: gold_clip("ViT-L/14", "clip_vit_l14"),
     "train32_d3": lambda: gold_train_loss(32, 4, 3, "train_loss_mc32_v4_d3", seed=31),
     "traj32": lambda: gold_trajectory(32, 4, 1, "traj_mc32_v4_d1", steps=5),
     "traj320": lambda: gold_trajectory(320, 4, 1, "traj_mc320_v4_d1_50steps", steps=50),

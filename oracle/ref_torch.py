@@ -564,3 +564,58 @@ def viewfusion_encode(sd, images, z_scale_factor=0.18215, **kw):
     (distributions.py:27,61-62)."""
     m = vae_encode_moments(sd, "vae.", torch.clip(images * 2 - 1.0, -1.0, 1.0), **kw)
     return torch.chunk(m, 2, dim=1)[0] * z_scale_factor
+
+
+# ---------------------------------------------------------------------------------------------
+# CLIP image encoder (SURVEY.md section 8(f) rank 3): FrozenCLIPImageEmbedder, external/sd1/ldm/modules/encoders/modules.py:402-441.
+# The vision transformer itself lives in OpenAI's `clip` package (clip/model.py, NOT in the reference tree, version unpinned:
+# requirements.txt "git+https://github.com/openai/CLIP.git"): restated here from its published architecture -- PARITY UNPINNED for
+# that part; the reference's own preprocessing / call order is pinned through oracle/make_golden.py (clip_l14).
+# ---------------------------------------------------------------------------------------------
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_preprocess(x, size=224):
+    """FrozenCLIPImageEmbedder.preprocess encoders/modules.py:422-431 (kornia.geometry.resize bicubic, align_corners=True,
+    antialias=False == F.interpolate; kornia.enhance.normalize == (x - mean) / std)."""
+    x = F.interpolate(x, size=(size, size), mode="bicubic", align_corners=True)
+    x = (x + 1.0) / 2.0
+    mean = torch.tensor(CLIP_MEAN, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(CLIP_STD, dtype=x.dtype).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+def clip_encode_image(sd, pre, x, heads):
+    """clip.model.VisionTransformer.forward (published CLIP model.py): conv1 patchify -> [class | patches] + positional
+    embedding -> ln_pre -> ResidualAttentionBlocks (x + MHA(ln_1 x); x + c_proj(QuickGELU(c_fc(ln_2 x)))) -> ln_post(class) @ proj."""
+    w = sd[pre + "conv1.weight"]
+    width, patch = w.shape[0], w.shape[-1]
+    h = F.conv2d(x, w, None, stride=patch)                                   # (B, width, g, g)
+    B = h.shape[0]
+    h = h.reshape(B, width, -1).permute(0, 2, 1)                             # (B, g*g, width)
+    cls = sd[pre + "class_embedding"].to(h.dtype) + torch.zeros(B, 1, width, dtype=h.dtype)
+    h = torch.cat([cls, h], dim=1) + sd[pre + "positional_embedding"]
+    h = F.layer_norm(h, (width,), sd[pre + "ln_pre.weight"], sd[pre + "ln_pre.bias"], 1e-5)
+    i = 0
+    dh = width // heads
+    while f"{pre}transformer.resblocks.{i}.ln_1.weight" in sd:
+        b = f"{pre}transformer.resblocks.{i}."
+        y = F.layer_norm(h, (width,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], 1e-5)
+        qkv = F.linear(y, sd[b + "attn.in_proj_weight"], sd[b + "attn.in_proj_bias"])
+        q, k, v = (t.reshape(B, -1, heads, dh).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        a = torch.softmax((q * dh ** -0.5) @ k.transpose(-2, -1), dim=-1) @ v     # nn.MultiheadAttention scaling
+        a = a.transpose(1, 2).reshape(B, -1, width)
+        h = h + F.linear(a, sd[b + "attn.out_proj.weight"], sd[b + "attn.out_proj.bias"])
+        y = F.layer_norm(h, (width,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5)
+        y = F.linear(y, sd[b + "mlp.c_fc.weight"], sd[b + "mlp.c_fc.bias"])
+        y = y * torch.sigmoid(1.702 * y)                                      # QuickGELU
+        h = h + F.linear(y, sd[b + "mlp.c_proj.weight"], sd[b + "mlp.c_proj.bias"])
+        i += 1
+    cls = F.layer_norm(h[:, 0, :], (width,), sd[pre + "ln_post.weight"], sd[pre + "ln_post.bias"], 1e-5)
+    return cls @ sd[pre + "proj"]
+
+
+def clip_image_embed(sd, images_pm1, heads=16, pre="clip_image_encoder.model.visual."):
+    """FrozenCLIPImageEmbedder.encode encoders/modules.py:433-441: (B,3,H,W) in [-1,1] -> (B,1,768)."""
+    return clip_encode_image(sd, pre, clip_preprocess(images_pm1), heads).float().unsqueeze(1)

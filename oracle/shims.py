@@ -323,6 +323,99 @@ def _mod(name, **attrs):
     return m
 
 
+# ---------------------------------------------------------------------------------------------
+# clip / kornia (used only by external/sd1/ldm/modules/encoders/modules.py:402-441).  Published behaviour:
+#   clip.load(name) -> (CLIP model, preprocess);  CLIP.encode_image(x) = self.visual(x.type(self.dtype));  VisionTransformer as in
+#   clip/model.py (conv1 no bias, class_embedding, positional_embedding, ln_pre, Transformer of ResidualAttentionBlock
+#   [nn.MultiheadAttention, LayerNorm, c_fc -> QuickGELU -> c_proj], ln_post, proj).  kornia.geometry.resize(bicubic) wraps
+#   F.interpolate; kornia.enhance.normalize = (x - mean[:, None, None]) / std[:, None, None].
+# ---------------------------------------------------------------------------------------------
+def _kornia_resize(x, size, interpolation="bilinear", align_corners=None, antialias=False, **kw):
+    import torch.nn.functional as F
+    assert not antialias
+    return F.interpolate(x, size=size, mode=interpolation, align_corners=align_corners)
+
+
+def _kornia_normalize(x, mean, std):
+    return (x - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1)
+
+
+def _clip_load(name="ViT-L/14", device="cpu", jit=False, **kw):
+    import torch
+    import torch.nn as nn
+    from collections import OrderedDict
+    cfg = {"ViT-L/14": (224, 14, 1024, 24, 16, 768, 768), "tiny-test": (224, 14, 128, 2, 2, 64, 64)}[name]
+    image, patch, width, layers, heads, out_dim, text_width = cfg
+
+    class QuickGELU(nn.Module):
+        def forward(self, x):
+            return x * torch.sigmoid(1.702 * x)
+
+    class ResidualAttentionBlock(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn = nn.MultiheadAttention(width, heads)
+            self.ln_1 = nn.LayerNorm(width)
+            self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(width, width * 4)), ("gelu", QuickGELU()),
+                                                  ("c_proj", nn.Linear(width * 4, width))]))
+            self.ln_2 = nn.LayerNorm(width)
+
+        def forward(self, x):                      # x: (L, N, width), sequence first as in CLIP
+            y = self.ln_1(x)
+            x = x + self.attn(y, y, y, need_weights=False)[0]
+            return x + self.mlp(self.ln_2(x))
+
+    class Transformer(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.resblocks = nn.Sequential(*[ResidualAttentionBlock() for _ in range(layers)])
+
+        def forward(self, x):
+            return self.resblocks(x)
+
+    class VisionTransformer(nn.Module):
+        def __init__(self):
+            super().__init__()
+            scale = width ** -0.5
+            self.conv1 = nn.Conv2d(3, width, kernel_size=patch, stride=patch, bias=False)
+            self.class_embedding = nn.Parameter(scale * torch.randn(width))
+            self.positional_embedding = nn.Parameter(scale * torch.randn((image // patch) ** 2 + 1, width))
+            self.ln_pre = nn.LayerNorm(width)
+            self.transformer = Transformer()
+            self.ln_post = nn.LayerNorm(width)
+            self.proj = nn.Parameter(scale * torch.randn(width, out_dim))
+
+        def forward(self, x):
+            x = self.conv1(x)
+            x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+            x = torch.cat([self.class_embedding.to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype), x], dim=1)
+            x = x + self.positional_embedding.to(x.dtype)
+            x = self.ln_pre(x)
+            x = self.transformer(x.permute(1, 0, 2)).permute(1, 0, 2)
+            x = self.ln_post(x[:, 0, :])
+            return x @ self.proj
+
+    class CLIP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.visual = VisionTransformer()
+            self.transformer = nn.Identity()         # the text tower; the reference deletes it (encoders/modules.py:417)
+            self.token_embedding = nn.Embedding(49408, text_width)
+            self.positional_embedding = nn.Parameter(torch.empty(77, text_width))
+            self.ln_final = nn.LayerNorm(text_width)
+            self.text_projection = nn.Parameter(torch.empty(text_width, out_dim))
+            self.logit_scale = nn.Parameter(torch.ones([]))
+
+        @property
+        def dtype(self):
+            return self.visual.conv1.weight.dtype
+
+        def encode_image(self, image):
+            return self.visual(image.type(self.dtype))
+
+    return CLIP(), None
+
+
 def install(reference_root="/root/reference"):
     """Inject the stand-ins and put the reference on sys.path (idempotent)."""
     sys.dont_write_bytecode = True
@@ -355,10 +448,12 @@ def install(reference_root="/root/reference"):
                     return yaml.safe_load(f)
         _mod("omegaconf", OmegaConf=OmegaConf, ListConfig=ListConfig)
         _mod("omegaconf.listconfig", ListConfig=ListConfig)
-    if "clip" not in sys.modules:          # facade-only, inert (CLIP / VAE are not on the hot path)
-        _mod("clip", load=lambda *a, **k: (_ for _ in ()).throw(RuntimeError("clip stub")))
+    if "clip" not in sys.modules:          # OpenAI CLIP is not vendored by the reference: structural restatement (clip/model.py)
+        _mod("clip", load=_clip_load)
     if "kornia" not in sys.modules:
-        _mod("kornia")
+        k = _mod("kornia")
+        k.geometry = _mod("kornia.geometry", resize=_kornia_resize)
+        k.enhance = _mod("kornia.enhance", normalize=_kornia_normalize)
     if "pytorch_lightning" not in sys.modules:
         _mod("pytorch_lightning", LightningModule=nn.Module, seed_everything=lambda s: torch.manual_seed(s))
     if reference_root not in sys.path:

@@ -370,6 +370,31 @@ def test_fused_gridattn_weight_stream_layout():
     assert torch.equal(vecs[3328 + 1536:3328 + 2304], blk.attn.qkv.bias.detach())
 
 
+def test_oracle_clip_vs_reference_golden_and_mirror_keys():
+    """oracle clip_image_embed against the golden produced by the REAL FrozenCLIPImageEmbedder (encoders/modules.py:402-441; the
+    un-vendored `clip` package is the structural restatement of oracle/shims.py), and the product mirror's parameter names =
+    the reference's state_dict keys (clip_image_encoder.model.visual.* ...)."""
+    import json
+    from mvdfusion_amd.encoders import FrozenCLIPImageEmbedder
+    gd = load_golden("clip_tiny")
+    spec = json.loads(str(gd["spec"]))
+    sd = syn.det_fill_state_dict([("clip_image_encoder." + k, tuple(s)) for k, s in spec])
+    g = torch.Generator().manual_seed(int(gd["seed"]))
+    x = torch.rand(2, 3, 256, 256, generator=g) * 2.0 - 1.0
+    with torch.no_grad():
+        out = O.clip_image_embed({k: v for k, v in sd.items() if ".visual." in k}, x, heads=2)
+    assert rel_err(out, gd["out"]) < 1e-5
+    mine = FrozenCLIPImageEmbedder(model="tiny-test")
+    assert {k for k, _ in spec} == set(mine.state_dict().keys())
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == {k: tuple(s) for k, s in spec}
+    ref_l14 = {k for k, _ in json.loads(str(load_golden("clip_vit_l14")["spec"]))}
+    with torch.device("meta"):
+        big = FrozenCLIPImageEmbedder(model="ViT-L/14")
+    assert ref_l14 == set(big.state_dict().keys())
+    with pytest.raises(RuntimeError):
+        mine(x)                                   # CPU tensor: the product has no CPU path
+
+
 def test_det_fill_is_stable_and_nonzero():
     a = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))
     b = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))

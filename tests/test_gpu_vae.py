@@ -229,3 +229,24 @@ def test_training_forward_loss_vs_reference_golden():
     m.eval()
     loss_eval = m.p_losses(batch, tc, noise_source=draws)
     assert abs(float(loss_eval) - float(loss)) > 1e-6 and not loss.requires_grad
+
+
+@pytest.mark.parametrize("name,model", [("clip_tiny", "tiny-test"), ("clip_vit_l14", "ViT-L/14")])
+def test_clip_image_encoder_vs_reference_golden(name, model):
+    """FrozenCLIPImageEmbedder.encode on the HIP path (patch-embedding GEMM, 24 x [LN, QKV GEMM + bias, flash attention over 257
+    keys in 260-row sequences, out_proj, LN, c_fc + QuickGELU, c_proj], ln_post, projection) against the golden produced by the
+    REAL reference class (oracle/make_golden.py: clip_tiny / clip_l14)."""
+    from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.encoders import FrozenCLIPImageEmbedder
+    gd = load_golden(name)
+    enc = FrozenCLIPImageEmbedder(model=model)
+    syn.fill_module_(enc, "clip_image_encoder.")
+    enc = enc.cuda().eval()
+    g = torch.Generator().manual_seed(int(gd["seed"]))
+    x = (torch.rand(2, 3, 256, 256, generator=g) * 2.0 - 1.0).cuda()
+    out = enc.encode(x)
+    assert out.shape == gd["out"].shape
+    assert rel_err(out.cpu(), gd["out"]) < 2e-4, rel_err(out.cpu(), gd["out"])
+    # a second call (cached packed weights, static buffers) is bit-identical; a list input is the unconditional zero vector
+    assert torch.equal(enc.encode(x), out)
+    assert float(enc([""]).abs().max()) == 0.0
