@@ -90,7 +90,19 @@ class FrozenCLIPImageEmbedder(nn.Module):
     def __init__(self, model="ViT-L/14", jit=False, device="cpu", antialias=False, precision="f16x4"):
         super().__init__()
         assert not jit and not antialias, "the reference constructs it with jit=False, antialias=False"
-        self.model = _CLIP(*_CONFIGS[model])
+        # `model` is a CLIP model name or -- as in configs/*.yaml (clip_path: weights/clip_vit_14.ckpt) -- a checkpoint file that
+        # clip.load() would open: the shipped configs all use ViT-L/14
+        arch = model if model in _CONFIGS else "ViT-L/14"
+        self.model = _CLIP(*_CONFIGS[arch])
+        if model not in _CONFIGS:
+            import os
+            if os.path.exists(model):
+                try:
+                    sd = torch.jit.load(model, map_location="cpu").state_dict()       # OpenAI ships TorchScript archives
+                except Exception:
+                    sd = torch.load(model, map_location="cpu")
+                    sd = sd.get("state_dict", sd)
+                self.model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
         self.antialias = antialias
         self.register_buffer("mean", torch.Tensor([0.48145466, 0.4578275, 0.40821073]), persistent=False)
         self.register_buffer("std", torch.Tensor([0.26862954, 0.26130258, 0.27577711]), persistent=False)

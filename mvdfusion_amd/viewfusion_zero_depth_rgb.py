@@ -213,7 +213,6 @@ class ViewFusion(nn.Module):
         self.scheduler = DDPMScheduler(**params(ddpm_config))
         # VAE: `vae_config` (configs/*.yaml: external.sd1.ldm.models.autoencoder.AutoencoderKL) builds the HIP-backed decode
         # mirror (mvdfusion_amd/autoencoder.py; its encode needs an injected module); an injected `vae` takes precedence.
-        # CLIP runs once per sample on plain PyTorch-ROCm and is injected by the harness (out of hot-path scope).
         if vae is not None:
             self.vae = vae
         elif vae_config is not None:
@@ -223,8 +222,16 @@ class ViewFusion(nn.Module):
                 sd = torch.load(vae_path, map_location="cpu")
                 sd = sd.get("state_dict", sd)
                 self.vae.load_state_dict({k.replace("first_stage_model.", ""): v for k, v in sd.items()}, strict=False)
+        # CLIP image encoder (viewfusion_zero_depth_rgb.py:103-105: FrozenCLIPImageEmbedder(model=clip_path), frozen): an injected
+        # module takes precedence; otherwise `clip_path` (the CLIP model name of configs/*.yaml, e.g. "ViT-L/14") builds the
+        # HIP-backed mirror, whose weights come with the checkpoint's clip_image_encoder.* keys.
         if clip_image_encoder is not None:
             self.clip_image_encoder = clip_image_encoder
+        elif clip_path:
+            from .encoders import FrozenCLIPImageEmbedder
+            self.clip_image_encoder = FrozenCLIPImageEmbedder(model=clip_path, precision=precision)
+            for prm in self.clip_image_encoder.parameters():
+                prm.requires_grad_(False)
         self.cc_projection = nn.Sequential(nn.Linear(768 + 14 * 2, 768), nn.SiLU(True), nn.Linear(768, 768),
                                            nn.SiLU(True), nn.Linear(768, 768))
         nn.init.eye_(list(self.cc_projection.parameters())[0][:768, :768])
