@@ -62,6 +62,32 @@ def fill_module_(module, prefix=""):
     return module
 
 
+def synthetic_zero123_ckpt(unet_sd, in_ch=8, out_ch=4):
+    """A zero123 / SD-shaped checkpoint for the view-conditioned UNet whose (reference-named) state_dict is `unet_sd`: no
+    aligned_attn_* keys, the blocks that follow an inserted ViewAlignedFeatureTransformer at their ORIGINAL indices
+    (middle_block.3 -> .2, output_blocks.{5,8}.3.conv -> .2.conv), 8-channel stem / 4-channel head, `model.diffusion_model.`
+    prefix, plus first-stage / cond-stage keys that must be ignored.  Values: det_fill keyed by the checkpoint key."""
+    ck = {}
+    for k, v in unet_sd.items():
+        if "aligned_attn_" in k:
+            continue
+        name = k
+        for dst, src in (("middle_block.3.", "middle_block.2."), ("output_blocks.5.3.conv.", "output_blocks.5.2.conv."),
+                         ("output_blocks.8.3.conv.", "output_blocks.8.2.conv.")):
+            if name.startswith(dst):
+                name = src + name[len(dst):]
+        shape = list(v.shape)
+        if name == "input_blocks.0.0.weight":
+            shape[1] = in_ch
+        if name in ("out.2.weight", "out.2.bias"):
+            shape[0] = out_ch
+        ck["model.diffusion_model." + name] = det_fill("zero123." + name, tuple(shape))
+    ck["first_stage_model.encoder.conv_in.weight"] = torch.zeros(4, 3, 3, 3)
+    ck["cond_stage_model.model.visual.proj"] = torch.zeros(8, 8)
+    return {"state_dict": ck, "global_step": 1}
+
+
+
 # ---------------------------------------------------------------------------------------------
 GSO_AZIMUTHS = [0.0, 0.39269909262657166, 0.7853981852531433, 1.1780972480773926, 1.5707963705062866,
                 1.9634953737258911, 2.356194496154785, 2.7488934993743896, 3.1415927410125732, 3.5342917442321777,

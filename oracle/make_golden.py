@@ -613,6 +613,46 @@ def gold_clip(name, tag, B=2, R=256, seed=41):
     save(tag, seed=np.int64(seed), out=ref, spec=json.dumps([[k, list(v.shape)] for k, v in enc.state_dict().items()]))
 
 
+def gold_ckpt_remap(model_channels=32):
+    """The REAL checkpoint loader (utils/load_model.py:26-110 with UNetWrapper's replace_key / param_mapper / remove_keys,
+    mvdfusion/unet.py:70-93, viewfusion_zero_depth_rgb.py:69) on a synthetic zero123-shaped checkpoint: per-key sums of the
+    resulting UNet state_dict."""
+    import tempfile
+    from utils.load_model import load_model_from_config
+    p = dict(UNET_PARAMS)
+    p["model_channels"] = model_channels
+    cfg = {"target": "mvdfusion.unet.UNetModel", "params": p}
+    base = _unet(model_channels)
+    ck = syn.synthetic_zero123_ckpt(base.state_dict())
+    pm = {}
+    for pre_src, pre_dst in (("output_blocks.5.2.conv.", "output_blocks.5.3.conv."), ("output_blocks.8.2.conv.", "output_blocks.8.3.conv.")):
+        for leaf in ("weight", "bias"):
+            pm[pre_src + leaf] = pre_dst + leaf
+    for leaf in ("in_layers.0", "in_layers.2", "emb_layers.1", "out_layers.0", "out_layers.3"):
+        for wb in ("weight", "bias"):
+            pm[f"middle_block.2.{leaf}.{wb}"] = f"middle_block.3.{leaf}.{wb}"
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "zero123.ckpt")
+        torch.save(ck, path)
+        torch.manual_seed(0)
+        net = load_model_from_config(cfg, path, verbose=False, replace_key=["model.diffusion_model.", ""],
+                                     ignore_keys=["aligned_attn_"], param_mapper=pm,
+                                     remove_keys=["input_blocks.0.0.weight", "out.2.weight", "out.2.bias"])
+    sd = net.state_dict()
+    loaded = {k: float(v.double().sum()) for k, v in sd.items() if "aligned_attn_" not in k and
+              k not in ("input_blocks.0.0.weight", "out.2.weight", "out.2.bias")}
+    # every loaded key must carry the checkpoint's values (not the initialiser's)
+    for k, vsum in loaded.items():
+        src = k
+        for dst, s0 in (("middle_block.3.", "middle_block.2."), ("output_blocks.5.3.conv.", "output_blocks.5.2.conv."),
+                        ("output_blocks.8.3.conv.", "output_blocks.8.2.conv.")):
+            if src.startswith(dst):
+                src = s0 + src[len(dst):]
+        assert abs(vsum - float(ck["state_dict"]["model.diffusion_model." + src].double().sum())) < 1e-9, k
+    save("ckpt_remap_mc32", keys=json.dumps(sorted(loaded)), sums=np.asarray([loaded[k] for k in sorted(loaded)]))
+    print(f"  checkpoint remap: {len(loaded)} keys loaded by the reference loader from the synthetic zero123 checkpoint")
+
+
 ALL = {
     "schedule": gold_schedule,
     "cameras": gold_cameras,
@@ -631,6 +671,7 @@ ALL = {
     "unet320_s64": lambda: gold_unet(320, 2, 1, "unet_mc320_v2_d1_s64", S=64, full=False),
     "unet320_d3": lambda: gold_unet(320, 2, 3, "unet_mc320_v2_d3", t_val=501),
     "gridattn_v15": gold_gridattn_v15,
+    "ckpt_remap": gold_ckpt_remap,
     "clip_tiny": lambda: gold_clip("tiny-test", "clip_tiny"),
     "clip_l14": lambda: gold_clip("ViT-L/14", "clip_vit_l14"),
     "train32_d3": lambda: gold_train_loss(32, 4, 3, "train_loss_mc32_v4_d3", seed=31),

@@ -395,6 +395,37 @@ def test_oracle_clip_vs_reference_golden_and_mirror_keys():
         mine(x)                                   # CPU tensor: the product has no CPU path
 
 
+def test_zero123_checkpoint_remap_matches_reference_loader(tmp_path):
+    """load_unet_checkpoint (mirror of utils/load_model.py:26-110 + the param_mapper / remove_keys of mvdfusion/unet.py:70-93,
+    viewfusion_zero_depth_rgb.py:69) on a synthetic zero123-shaped checkpoint: the same keys end up with the same values as
+    with the REAL loader (golden ckpt_remap_mc32: per-key sums), the 8->10 channel stem / 4->5 channel head are dropped and the
+    aligned_attn_* layers keep their initialisation."""
+    import json
+    from mvdfusion_amd.load_model import load_unet_checkpoint
+    from mvdfusion_amd.unet import UNetModel
+    from conftest import UNET_PARAMS
+    gd = load_golden("ckpt_remap_mc32")
+    p = dict(UNET_PARAMS)
+    p["model_channels"] = 32
+    torch.manual_seed(0)
+    net = UNetModel(**p)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    path = str(tmp_path / "zero123.ckpt")
+    torch.save(syn.synthetic_zero123_ckpt(net.state_dict()), path)
+    res = load_unet_checkpoint(net, path, remove_keys=["input_blocks.0.0.weight", "out.2.weight", "out.2.bias"])
+    after = net.state_dict()
+    keys = json.loads(str(gd["keys"]))
+    sums = gd["sums"].double() if torch.is_tensor(gd["sums"]) else torch.tensor(gd["sums"]).double()
+    assert len(keys) == 683
+    for k, ref in zip(keys, sums):
+        assert abs(float(after[k].double().sum()) - float(ref)) < 1e-9 * max(1.0, abs(float(ref))), k
+    untouched = [k for k in after if k not in keys]
+    assert all("aligned_attn_" in k or k in ("input_blocks.0.0.weight", "out.2.weight", "out.2.bias") for k in untouched)
+    assert all(torch.equal(after[k], before[k]) for k in untouched)
+    assert not any("aligned_attn_" not in k and k not in ("input_blocks.0.0.weight", "out.2.weight", "out.2.bias")
+                   for k in res.missing_keys)
+
+
 def test_det_fill_is_stable_and_nonzero():
     a = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))
     b = syn.det_fill("unet_model.unet_model.out.2.weight", (5, 32, 3, 3))
