@@ -10,13 +10,11 @@ def main():
     d, out = sys.argv[1], sys.argv[2]
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     rows = list(csv.DictReader(open(f[0])))
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
-    cut = ids[len(ids) * 2 // 3]                       # steady state: the last third of the dispatches
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from pmc_traffic import steady_rows
+    rows = steady_rows(rows)                            # graph-replayed steps only (no autotuner launches)
     acc = {}
     for r in rows:
-        if int(r["Dispatch_Id"]) < cut:
-            continue
         k = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"])
         k = re.sub(r"\(.*$", "", k)
         a = acc.setdefault(k, {})
