@@ -14,18 +14,26 @@ namespace {
 
 constexpr int KV_TILE = 64;
 
-template <int DQ, int DV, int NS>
+// QT = 16-query tiles per wavefront (1 or 2).  A workgroup = 4 wavefronts = 64 * QT queries of one (batch, head).  K / V^T tiles
+// of 64 keys go through LDS with issue-early / write-late register staging: the global loads of key tile t+1 are issued before
+// the MFMAs of tile t and written to LDS after them -- into the other buffer with one barrier per key tile (NBUF = 2, head dims
+// <= 64), or into the same buffer between two barriers (NBUF = 1: the wide heads, whose tiles would not leave room for two
+// workgroups per CU).  With QT = 2 the K / V^T fragments read from LDS feed two query tiles (half the LDS traffic per MFMA).
+template <int DQ, int DV, int NS, int QT, int NBUF>
 __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
                                                    const u16* __restrict__ k_hi, const u16* __restrict__ k_lo,
                                                    const u16* __restrict__ vt_hi, const u16* __restrict__ vt_lo,
                                                    u16* __restrict__ out_sp, int ldo, int H, int L, int Lk, int Lpad, int dhead) {
   constexpr int NPL = NS >= 3 ? 2 : 1;
-  constexpr int KP = DQ + 8;       // LDS pitch of a K row (bf16 elements)
+  constexpr int KP = DQ + 8;       // LDS pitch of a K row (16-bit elements)
   constexpr int VP = KV_TILE + 8;  // LDS pitch of a V^T row
   constexpr int QS = DQ / 32;      // MFMA k-steps over the head dim
   constexpr int DT = DV / 16;      // output d-tiles
-  __shared__ __attribute__((aligned(16))) u16 sK[NPL][KV_TILE][KP];
-  __shared__ __attribute__((aligned(16))) u16 sV[NPL][DV][VP];
+  constexpr int KCH = KV_TILE * DQ / 8;            // 16-byte chunks of a K tile (per plane)
+  constexpr int VCH = DV * 8;                      // 16-byte chunks of a V^T tile (per plane)
+  constexpr int KREG = (KCH + 255) / 256, VREG = (VCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) u16 sK[NBUF][NPL][KV_TILE][KP];
+  __shared__ __attribute__((aligned(16))) u16 sV[NBUF][NPL][DV][VP];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -38,144 +46,192 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int qblocks = Lpad / 64;
+  const int qblocks = (Lpad + 64 * QT - 1) / (64 * QT);
   const int bhi = logical / qblocks;
   const int b = bhi / H, h = bhi - b * H;
-  const int q0 = (logical - bhi * qblocks) * 64 + wave * 16;
-  const bool active = q0 < L;
+  const int q0 = (logical - bhi * qblocks) * 64 * QT + wave * 16 * QT;      // first query of this wave
   const size_t bh = (size_t)b * H + h;
   const u16* kp[2] = {k_hi + bh * Lpad * DQ, k_lo + bh * Lpad * DQ};
   const u16* vp[2] = {vt_hi + bh * DV * Lpad, vt_lo + bh * DV * Lpad};
 
-  bf16x8 qh[QS], ql[QS];
-  {
-    const size_t qoff = (bh * Lpad + q0 + c) * DQ + g * 8;
+  bool active[QT];
+  bf16x8 qh[QT][QS], ql[QT][QS];
+#pragma unroll
+  for (int t2 = 0; t2 < QT; ++t2) {
+    active[t2] = q0 + 16 * t2 < L;
+    const bool inb = q0 + 16 * t2 + c < Lpad;           // rows past Lpad belong to the next head's planes: never read them
+    const size_t qoff = (bh * Lpad + q0 + 16 * t2 + c) * DQ + g * 8;
 #pragma unroll
     for (int ks = 0; ks < QS; ++ks) {
-      qh[ks] = *(const bf16x8*)(q_hi + qoff + ks * 32);
-      if (NS >= 3) ql[ks] = *(const bf16x8*)(q_lo + qoff + ks * 32);
+      qh[t2][ks] = inb ? *(const bf16x8*)(q_hi + qoff + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (NS >= 3) ql[t2][ks] = inb ? *(const bf16x8*)(q_lo + qoff + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
-  f32x4 o[DT];
+  f32x4 o[QT][DT];
+  float m_run[QT], l_run[QT];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int t2 = 0; t2 < QT; ++t2) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[t2][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m_run[t2] = -INFINITY;
+    l_run[t2] = 0.f;
+  }
 
-  const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;     // keys [0, Lk) take part (Lk <= L: trailing padding tokens are masked)
-  for (int t = 0; t < ntiles; ++t) {
-    const int kv0 = t * KV_TILE;
-    __syncthreads();
-    // ---- stage K tile (contiguous 64*DQ bf16 per plane) and V^T tile (DV rows x 64 keys) into LDS
-    constexpr int KCH = KV_TILE * DQ / 8;
-    constexpr int VCH = DV * 8;
+  // ---- staging: each thread owns fixed 16-byte chunks of the K tile / V^T tile (both planes)
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;      // (HIP's uint4 is a struct-of-union: arrays of it stay in memory)
+  u32x4 kr[NPL][KREG], vr[NPL][VREG];
+  auto load_tile = [&](int kv0) __attribute__((always_inline)) {
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
-      for (int ch = tid; ch < KCH; ch += 256) {
+#pragma unroll
+      for (int i = 0; i < KREG; ++i) {       // (threads past the tile re-load its last chunk: every register is always defined)
+        const int ch = min(tid + i * 256, KCH - 1);
         const int row = ch / (DQ / 8), kc = ch - row * (DQ / 8);
-        *(uint4*)&sK[pl][row][kc * 8] = *(const uint4*)(kp[pl] + ((size_t)(kv0 + row)) * DQ + kc * 8);
+        kr[pl][i] = *(const u32x4*)(kp[pl] + ((size_t)(kv0 + row)) * DQ + kc * 8);
       }
-      for (int ch = tid; ch < VCH; ch += 256) {
+#pragma unroll
+      for (int i = 0; i < VREG; ++i) {
+        const int ch = min(tid + i * 256, VCH - 1);
         const int row = ch >> 3, kc = ch & 7;
-        *(uint4*)&sV[pl][row][kc * 8] = *(const uint4*)(vp[pl] + (size_t)row * Lpad + kv0 + kc * 8);
+        vr[pl][i] = *(const u32x4*)(vp[pl] + (size_t)row * Lpad + kv0 + kc * 8);
       }
     }
-    __syncthreads();
-    if (!active) continue;
+  };
+  auto write_tile = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+      for (int i = 0; i < KREG; ++i) {       // (threads past the tile store the last chunk again: same address, same value)
+        const int ch = min(tid + i * 256, KCH - 1);
+        const int row = ch / (DQ / 8), kc = ch - row * (DQ / 8);
+        *(u32x4*)&sK[buf][pl][row][kc * 8] = kr[pl][i];
+      }
+#pragma unroll
+      for (int i = 0; i < VREG; ++i) {
+        const int ch = min(tid + i * 256, VCH - 1);
+        const int row = ch >> 3, kc = ch & 7;
+        *(u32x4*)&sV[buf][pl][row][kc * 8] = vr[pl][i];
+      }
+    }
+  };
 
-    // ---- S^T = K Q^T : s[kt][r] = S[q = c][key = kv0 + kt*16 + g*4 + r]
-    f32x4 s[4];
+  const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;     // keys [0, Lk) take part (Lk <= L: trailing padding tokens are masked)
+  load_tile(0);
+  write_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * KV_TILE, buf = NBUF == 2 ? (t & 1) : 0;
+    if (t + 1 < ntiles) load_tile(kv0 + KV_TILE);      // in flight under the MFMAs below
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t2 = 0; t2 < QT; ++t2) {
+      if (!active[t2]) continue;
+      // ---- S^T = K Q^T : s[kt][r] = S[q = c][key = kv0 + kt*16 + g*4 + r]
+      f32x4 s[4];
 #pragma unroll
-      for (int ks = 0; ks < QS; ++ks) {
-        const bf16x8 kh = *(const bf16x8*)&sK[0][kt * 16 + c][ks * 32 + g * 8];
-        if (NS >= 3) {
-          const bf16x8 kl = *(const bf16x8*)&sK[NPL - 1][kt * 16 + c][ks * 32 + g * 8];
-          if (NS == 4) s[kt] = MVD_MFMA_16x16x32(kl, ql[ks], s[kt], 0, 0, 0);
-          s[kt] = MVD_MFMA_16x16x32(kl, qh[ks], s[kt], 0, 0, 0);
-          s[kt] = MVD_MFMA_16x16x32(kh, ql[ks], s[kt], 0, 0, 0);
+      for (int kt = 0; kt < 4; ++kt) {
+        s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < QS; ++ks) {
+          const bf16x8 kh = *(const bf16x8*)&sK[buf][0][kt * 16 + c][ks * 32 + g * 8];
+          if (NS >= 3) {
+            const bf16x8 kl = *(const bf16x8*)&sK[buf][NPL - 1][kt * 16 + c][ks * 32 + g * 8];
+            if (NS == 4) s[kt] = MVD_MFMA_16x16x32(kl, ql[t2][ks], s[kt], 0, 0, 0);
+            s[kt] = MVD_MFMA_16x16x32(kl, qh[t2][ks], s[kt], 0, 0, 0);
+            s[kt] = MVD_MFMA_16x16x32(kh, ql[t2][ks], s[kt], 0, 0, 0);
+          }
+          s[kt] = MVD_MFMA_16x16x32(kh, qh[t2][ks], s[kt], 0, 0, 0);
         }
-        s[kt] = MVD_MFMA_16x16x32(kh, qh[ks], s[kt], 0, 0, 0);
       }
-    }
-    // ---- online softmax (per query column c; keys are spread over registers and the 4 lane groups)
-    // (q carries dhead^-0.5 * log2(e) from the QKV epilogue, so the scores are base-2 logits: exp2 below is a bare v_exp_f32)
-    if (kv0 + KV_TILE > Lk) {     // ragged last tile only (uniform branch): keys past Lk do not take part
+      // ---- online softmax (per query column c; keys are spread over registers and the 4 lane groups)
+      // (q carries dhead^-0.5 * log2(e) from the QKV epilogue, so the scores are base-2 logits: exp2 below is a bare v_exp_f32)
+      if (kv0 + KV_TILE > Lk) {     // ragged last tile only (uniform branch): keys past Lk do not take part
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + kt * 16 + g * 4 + r >= Lk) s[kt][r] = -INFINITY;
+      }
+      float mt = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (kv0 + kt * 16 + g * 4 + r >= Lk) s[kt][r] = -INFINITY;
-    }
-    float mt = -INFINITY;
+        for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kt][r]);
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run[t2], mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[t2] - m_new);
+      m_run[t2] = m_new;
+      float psum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kt][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
-        psum += s[kt][r];
-      }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < DT; ++i) o[i] *= alpha;
-    // ---- P^T as MFMA B operand: k-slot (g, j): j<4 -> key 32u + 4g + j ; j>=4 -> key 32u + 16 + 4g + (j-4)
-    bf16x8 ph[2], pl2[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      union { bf16x8 v; u16 e[8]; } H8, L8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float pv = j < 4 ? s[2 * u][j] : s[2 * u + 1][j - 4];
-        if (NS >= 3) {
-          split_bf16(pv, H8.e[j], L8.e[j]);
-        } else {
-          H8.e[j] = to_op_bits(pv);
+        for (int r = 0; r < 4; ++r) {
+          s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+          psum += s[kt][r];
         }
-      }
-      ph[u] = H8.v;
-      if (NS >= 3) pl2[u] = L8.v;
-    }
-    // ---- O^T += V^T P^T
+      l_run[t2] = l_run[t2] * alpha + psum;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
+      for (int i = 0; i < DT; ++i) o[t2][i] *= alpha;
+      // ---- P^T as MFMA B operand: k-slot (g, j): j<4 -> key 32u + 4g + j ; j>=4 -> key 32u + 16 + 4g + (j-4)
+      bf16x8 ph[2], pl2[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        union { bf16x8 v; uint2 h2[2]; } VH, VL;
-        VH.h2[0] = *(const uint2*)&sV[0][dt * 16 + c][32 * u + 4 * g];
-        VH.h2[1] = *(const uint2*)&sV[0][dt * 16 + c][32 * u + 16 + 4 * g];
-        if (NS >= 3) {
-          VL.h2[0] = *(const uint2*)&sV[NPL - 1][dt * 16 + c][32 * u + 4 * g];
-          VL.h2[1] = *(const uint2*)&sV[NPL - 1][dt * 16 + c][32 * u + 16 + 4 * g];
-          if (NS == 4) o[dt] = MVD_MFMA_16x16x32(VL.v, pl2[u], o[dt], 0, 0, 0);
-          o[dt] = MVD_MFMA_16x16x32(VL.v, ph[u], o[dt], 0, 0, 0);
-          o[dt] = MVD_MFMA_16x16x32(VH.v, pl2[u], o[dt], 0, 0, 0);
+        union { bf16x8 v; u16 e[8]; } H8, L8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = j < 4 ? s[2 * u][j] : s[2 * u + 1][j - 4];
+          if (NS >= 3) {
+            split_bf16(pv, H8.e[j], L8.e[j]);
+          } else {
+            H8.e[j] = to_op_bits(pv);
+          }
         }
-        o[dt] = MVD_MFMA_16x16x32(VH.v, ph[u], o[dt], 0, 0, 0);
+        ph[u] = H8.v;
+        if (NS >= 3) pl2[u] = L8.v;
+      }
+      // ---- O^T += V^T P^T
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          union { bf16x8 v; uint2 h2[2]; } VH, VL;
+          VH.h2[0] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 4 * g];
+          VH.h2[1] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 16 + 4 * g];
+          if (NS >= 3) {
+            VL.h2[0] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 4 * g];
+            VL.h2[1] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 16 + 4 * g];
+            if (NS == 4) o[t2][dt] = MVD_MFMA_16x16x32(VL.v, pl2[u], o[t2][dt], 0, 0, 0);
+            o[t2][dt] = MVD_MFMA_16x16x32(VL.v, ph[u], o[t2][dt], 0, 0, 0);
+            o[t2][dt] = MVD_MFMA_16x16x32(VH.v, pl2[u], o[t2][dt], 0, 0, 0);
+          }
+          o[t2][dt] = MVD_MFMA_16x16x32(VH.v, ph[u], o[t2][dt], 0, 0, 0);
+        }
       }
     }
+    if (NBUF == 2) {
+      if (t + 1 < ntiles) write_tile(buf ^ 1);         // the other buffer: its readers finished before the previous barrier
+      __syncthreads();
+    } else {
+      __syncthreads();                                 // everyone is done reading the single buffer
+      if (t + 1 < ntiles) write_tile(0);
+      __syncthreads();
+    }
   }
-  if (!active) return;
-  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int q = q0 + c;
-  if (q < L) {
-    const size_t orow = (size_t)b * L + q;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      const int d0 = dt * 16 + g * 4;
-      if (d0 < dhead) store_sp4(out_sp, orow, ldo, h * dhead + d0, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+  for (int t2 = 0; t2 < QT; ++t2) {
+    if (!active[t2]) continue;
+    float l_tot = l_run[t2] + __shfl_xor(l_run[t2], 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + 16 * t2 + c;
+    if (q < L) {
+      const size_t orow = (size_t)b * L + q;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = dt * 16 + g * 4;
+        if (d0 < dhead)
+          store_sp4(out_sp, orow, ldo, h * dhead + d0, o[t2][dt][0] * inv, o[t2][dt][1] * inv, o[t2][dt][2] * inv, o[t2][dt][3] * inv);
+      }
     }
   }
 }
@@ -340,13 +396,21 @@ template <int NS>
 int launch_attn(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi, const void* vt_lo,
                 void* out_sp, int ldo, int B, int H, int L, int Lk, int Lpad, int dhead, hipStream_t s) {
   const int dq = (dhead + 31) & ~31, dv = (dhead + 15) & ~15;
-  dim3 grid((Lpad / 64) * H * B), block(256);
-#define MVD_ATTN_CASE(DQ, DV)                                                                                          \
-  if (dq == DQ && dv == DV) {                                                                                          \
-    hipLaunchKernelGGL((attn_kernel<DQ, DV, NS>), grid, block, 0, s, (const u16*)q_hi, (const u16*)q_lo,               \
-                       (const u16*)k_hi, (const u16*)k_lo, (const u16*)vt_hi, (const u16*)vt_lo, (u16*)out_sp, ldo, H, \
-                       L, Lk, Lpad, dhead);                                                                            \
-    return 0;                                                                                                          \
+  // two query tiles per wavefront once that still leaves >= 2 workgroups per CU (long sequences); small heads only
+  const long wg2 = (long)((Lpad + 127) / 128) * H * B;
+  const bool two = dq <= 96 && wg2 >= 512;
+  const dim3 block(256);
+#define MVD_ATTN_CASE(DQ, DV)                                                                                            \
+  if (dq == DQ && dv == DV) {                                                                                            \
+    if (two && DQ <= 96)                                                                                                  \
+      hipLaunchKernelGGL((attn_kernel<DQ, DV, NS, (DQ <= 96 ? 2 : 1), (DQ <= 64 ? 2 : 1)>), dim3((unsigned)wg2), block, 0, s, (const u16*)q_hi, \
+                         (const u16*)q_lo, (const u16*)k_hi, (const u16*)k_lo, (const u16*)vt_hi, (const u16*)vt_lo, (u16*)out_sp,  \
+                         ldo, H, L, Lk, Lpad, dhead);                                                                    \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((attn_kernel<DQ, DV, NS, 1, (DQ <= 64 ? 2 : 1)>), dim3((Lpad / 64) * H * B), block, 0, s, (const u16*)q_hi, \
+                         (const u16*)q_lo, (const u16*)k_hi, (const u16*)k_lo, (const u16*)vt_hi, (const u16*)vt_lo, (u16*)out_sp,  \
+                         ldo, H, L, Lk, Lpad, dhead);                                                                    \
+    return 0;                                                                                                            \
   }
   MVD_ATTN_CASE(32, 16)
   MVD_ATTN_CASE(32, 32)
