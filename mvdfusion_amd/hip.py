@@ -386,6 +386,21 @@ def kernel_symbol(cfg, prec, conv):
     return f"gemm_kernel<{bm}, {bn}, {wm}, {wn}, {prec}, {1 if conv else 0}, {GEMM_LOOPS[loop]}>"
 
 
+def save_tuned(path):
+    """Persist the autotuner's choices (problem key -> (cfg, splitk)) so that separate processes -- the bench run and the rocprofv3
+    counter passes of one profiling session -- launch identical kernels."""
+    import json
+    with open(path, "w") as f:
+        json.dump([[list(k), list(v)] for k, v in _TUNED.items()], f)
+
+
+def load_tuned(path):
+    import json
+    for k, v in json.load(open(path)):
+        _TUNED[tuple(k)] = tuple(v)
+    return len(_TUNED)
+
+
 LAST_CFG = 0
 AUTOTUNE = False          # set by the step engine around its eager warm-up step (never during graph capture)
 _TUNED = {}

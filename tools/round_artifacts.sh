@@ -7,18 +7,25 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd $R
-python bench.py --steps 100 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.log
-python bench.py --views 8 --steps 50 --warmup 3 --no-cpu-baseline --shard-emulate 0/8 > $O/bench_v8_s32.json 2> $O/bench_v8_s32.log
-python bench.py --views 8 --latent 64 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_v8_s64.json 2> $O/bench_v8_s64.log
+# one autotuning per workload, shared by the bench run and every rocprofv3 pass (identical kernels everywhere)
+T4=$O/tuned_v4_s32.json; T8=$O/tuned_v8_s32.json; T864=$O/tuned_v8_s64.json
+rm -f $T4 $T8 $T864
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --tune-cache $T4 > /dev/null 2>&1
+python bench.py --views 8 --steps 10 --warmup 3 --no-cpu-baseline --tune-cache $T8 > /dev/null 2>&1
+python bench.py --views 8 --latent 64 --steps 5 --warmup 2 --no-cpu-baseline --tune-cache $T864 > /dev/null 2>&1
+python bench.py --steps 100 --warmup 5 --tune-cache $T4 > $O/bench_n1.json 2> $O/bench_n1.log
+python bench.py --views 8 --steps 50 --warmup 3 --no-cpu-baseline --shard-emulate 0/8 --tune-cache $T8 > $O/bench_v8_s32.json 2> $O/bench_v8_s32.log
+python bench.py --views 8 --latent 64 --steps 20 --warmup 3 --no-cpu-baseline --tune-cache $T864 > $O/bench_v8_s64.json 2> $O/bench_v8_s64.log
 cd /tmp && export TMPDIR=/tmp
 out=$O/prof
 rm -rf $out
-rocprofv3 --kernel-trace --stats -d $out -o bench --output-format csv -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline > $O/prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out -o bench --output-format csv -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --tune-cache $T4 > $O/prof.log 2>&1
 cp $out/bench_kernel_stats.csv $O/bench_n1_kernel_stats.csv
 python $R/tools/trace_summary.py $out $O/step_trace_v4.json > $O/step_trace_v4.txt
 rm -rf $out
-bash $R/tools/pmc_traffic.sh ${tag}_v4_s32_d1 > $O/pmc_traffic_v4.log 2>&1
-bash $R/tools/pmc_traffic.sh ${tag}_v8_s32_d1 --views 8 > $O/pmc_traffic_v8.log 2>&1
-bash $R/tools/pmc_traffic.sh ${tag}_v8_s64_d1 --views 8 --latent 64 > $O/pmc_traffic_v8s64.log 2>&1
-bash $R/tools/pmc_mfma.sh ${tag} > $O/pmc_mfma.log 2>&1
+bash $R/tools/pmc_traffic.sh ${tag}_v4_s32_d1 --tune-cache $T4 > $O/pmc_traffic_v4.log 2>&1
+bash $R/tools/pmc_traffic.sh ${tag}_v8_s32_d1 --views 8 --tune-cache $T8 > $O/pmc_traffic_v8.log 2>&1
+bash $R/tools/pmc_traffic.sh ${tag}_v8_s64_d1 --views 8 --latent 64 --tune-cache $T864 > $O/pmc_traffic_v8s64.log 2>&1
+bash $R/tools/pmc_mfma.sh ${tag} --tune-cache $T4 > $O/pmc_mfma.log 2>&1
+# the bench line again, now that the traffic files of this session exist (roofline.traffic is read from profiles/, see README)
 ls $R/gpurun_out | grep pmc_${tag}
