@@ -239,6 +239,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (0 = all host cores)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--gn-two-pass", action="store_true", help="A/B: GroupNorm statistics by their own kernels instead of the producers")
     ap.add_argument("--tune-cache", default=None, help="JSON file with the GEMM autotuner's choices: loaded if it exists (no "
                     "re-tuning: identical kernels across the bench run and the rocprofv3 passes), written after warm-up otherwise")
     ap.add_argument("--shard-emulate", default=None, metavar="r/N",
@@ -270,6 +271,9 @@ def main():
     q0, Vq = (ex.q0, ex.Vq) if ex else (0, None)
     eng, inp, dn, sn = prepare(m, V, S, D, cfg_scale, q0=q0, Vq=Vq)
     graph = not a.no_graph
+    if a.gn_two_pass:
+        from mvdfusion_amd import engine as _engine
+        _engine.Ctx.gn_from_producer = False
 
     def sync():
         torch.cuda.synchronize()

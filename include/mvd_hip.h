@@ -49,7 +49,9 @@ const char* mvd_last_error(void);
 int mvd_operand_format(void);
 
 /* ------------------------------------------------------------------------------------------------
- * Weight packing (once per model load).  Packed image: [K/32][N/16][16 n][32 k hi | 32 k lo] bf16 (2 KiB micro-tiles),
+ * Weight packing (once per model load).  Packed image: [K/32][N/16][hi image | lo image] (2 KiB micro-tiles of 16 n x 32 k); an
+ * image (1 KiB) is the 16x16x32 MFMA B fragment as a wave holds it: lane l = (n & 15) + 16 * ((k & 31) >> 3) owns the 8 elements
+ * k & 7 = 0..7 at byte 16 l -- a granule of the LDS-DMA is one contiguous KiB and the fragment read from LDS is lane-contiguous.
  * K padded to 32, N padded to 16 with zeros.  Bytes = mvd_packed_weight_bytes(N, K).
  * Replaces nothing in the reference (its weights stay fp32 nn.Parameters); the Python mirrors keep the
  * fp32 parameters under the reference's state_dict keys and pack on first use. */
@@ -146,6 +148,12 @@ typedef struct mvd_gemm_desc {
    * The host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
    * winner from then on (mvdfusion_amd/hip.py: autotune). */
   int cfg;
+  /* GroupNorm statistics of the OUTPUT, emitted by the producer instead of a separate statistics kernel (MVD_EPI_STORE, n_store == N
+   * <= 2560, M % 16 == 0): gn_stats = [M / gn_hw images][gn_groups][2] int64, zeroed by the caller, receives {sum, sum of squares}
+   * of every (image, group) as 2^24 fixed point (integer atomics: deterministic); consumed by mvd_groupnorm_from_stats.  gn_hw =
+   * rows per image (multiple of 16).  NULL = off. */
+  long long* gn_stats;
+  int gn_hw, gn_groups;
 } mvd_gemm_desc;
 
 int mvd_gemm(const mvd_gemm_desc* d, mvd_stream_t stream);
@@ -172,6 +180,10 @@ int mvd_groupnorm_chunks(int HW);
 /* y_sp: the normalised activations in split-planes format (B*HW, C), C % 32 == 0 -- GroupNorm only feeds GEMMs / convs. */
 int mvd_groupnorm_nhwc(const float* x, void* y_sp, const float* gamma, const float* beta, int B, int HW, int C,
                        int groups, float eps, int silu, double* ws, size_t ws_elems, mvd_stream_t stream);
+/* GroupNorm whose statistics were emitted by the producer of x (mvd_gemm_desc.gn_stats, mvd_concat_channels): one launch
+ * (finalise mean / rstd per (image, group) from the fixed-point sums, apply, optional SiLU, write split planes). */
+int mvd_groupnorm_from_stats(const float* x, void* y_sp, const float* gamma, const float* beta, const long long* stats, int B, int HW,
+                             int C, int groups, float eps, int silu, mvd_stream_t stream);
 /* Row softmax: y[r, :] = out_scale * softmax(scale * x[r, :]) of an fp32 (rows, cols) matrix (row stride ldx), written as
  * split planes (rows, cols), cols % 32 == 0, cols <= 4096.  out_scale (a power of two, e.g. 1024) lifts the probabilities of
  * wide rows out of the fp16 subnormal range; the consumer GEMM divides it out through its weight's acc_scale.  Replaces
@@ -214,8 +226,10 @@ int mvd_pixel_cross_attn(const float* q, const float* k, const float* v, void* o
 int mvd_unet_input(const float* x, const float* input_latents, void* out_sp, int V, int S, int cpad, int cfg,
                    mvd_stream_t stream);
 /* out[r, 0:Ca] = a[r], out[r, Ca:Ca+Cb] = b[r]  (torch.cat([h, hs.pop()], dim=1), unet.py:550) */
-int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_sp, int rows,
-                        mvd_stream_t stream); /* out_sp optional: split planes for the 1x1 skip conv */
+int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_sp, int rows, long long* gn_stats,
+                        int gn_hw, int gn_groups, mvd_stream_t stream);
+/* out_sp optional: split planes for the 1x1 skip conv; gn_stats optional: GroupNorm statistics of `out` (as mvd_gemm_desc.gn_stats;
+ * rows % 16 == 0, gn_hw % 16 == 0, (Ca + Cb) % gn_groups == 0, Ca + Cb <= 2560) */
 /* area pooling by `factor` of vol (B, S, S, D, C) -> (B, S/f, S/f, D, C)  (unet.py:198-209).  Output: split planes with
  * ldp elements per row (0 = C): the pooled levels only feed GEMMs, and with D == 1 they are written straight into the
  * [attention output | volume features] operand of the merged to_out / cross-attention GEMM (out_sp then points at the

@@ -127,13 +127,13 @@ class _TransformerCore(nn.Module):
         """The (M, 5C) operand [g | t] of the merged ff-out / proj_out GEMM: the producer of t fills columns [4C, 5C)."""
         return ctx.ws.planes(tag + ".cat5", M, 5 * self.dim)
 
-    def feed_forward_proj(self, ctx, t2, cat5, w_merged, x, out, M, tag):
+    def feed_forward_proj(self, ctx, t2, cat5, w_merged, x, out, M, tag, gn=None):
         """out = proj_out(t2 + ff(norm3(t2))) + x with t2's planes already in cat5[:, 4C:] (see module docstring)."""
         C = self.dim
         ln = ctx.ws.planes(tag + ".ln", M, C)
         ctx.layernorm(t2, ln, self.norm3, M, C)
         ctx.gemm(ln, self.ff.packed_geglu(), None, epi=hip.EPI_GEGLU, out_planes=cat5)      # columns [0, 4C)
-        ctx.gemm(cat5, w_merged, out, res=x)
+        ctx.gemm(cat5, w_merged, out, res=x, gn=gn)
         return out
 
 
@@ -190,7 +190,7 @@ class SpatialTransformer(nn.Module):
         ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L, out_planes=cat5, out_planes_col=4 * C)
         if out is None:
             out = ctx.act((M, C))
-        return tb.feed_forward_proj(ctx, t2, cat5, w_ffproj, x, out, M, "tf")
+        return tb.feed_forward_proj(ctx, t2, cat5, w_ffproj, x, out, M, "tf", gn=(B, L))
 
 
 class ViewAlignedFeatureTransformer(nn.Module):
@@ -262,4 +262,4 @@ class ViewAlignedFeatureTransformer(nn.Module):
             ctx.gemm(o2, a2("out"), t2b, res=t2, out_planes=cat5, out_planes_col=4 * C)
         if out is None:
             out = ctx.act((M, C))
-        return tb.feed_forward_proj(ctx, t2b, cat5, w_ffproj, x, out, M, "tf")
+        return tb.feed_forward_proj(ctx, t2b, cat5, w_ffproj, x, out, M, "tf", gn=(B, L))

@@ -123,4 +123,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// GroupNorm statistics handed from a PRODUCER kernel (GEMM epilogue, split-K reduce, concat) to mvd_groupnorm_from_stats: per
+// (image, group) {sum, sum of squares} accumulated as 64-bit fixed point (value * 2^24) with integer atomics -- the order of the
+// contributions does not matter, so the result is deterministic; every contribution is an fp32 partial sum formed in a fixed
+// order, represented exactly down to 2^-24.  Capacity: |total| < 5.5e11.
+#define MVD_GN_FIXED_SCALE 16777216.0f
+__device__ __forceinline__ void gn_stats_add(long long* stats, int b, int g, int groups, float s, float q) {
+  unsigned long long* p = (unsigned long long*)(stats + ((size_t)b * groups + g) * 2);
+  atomicAdd(p, (unsigned long long)(long long)llrintf(s * MVD_GN_FIXED_SCALE));
+  atomicAdd(p + 1, (unsigned long long)(long long)llrintf(q * MVD_GN_FIXED_SCALE));
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

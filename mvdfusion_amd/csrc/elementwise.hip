@@ -93,6 +93,57 @@ __global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ 
   }
 }
 
+// concat + GroupNorm statistics of the result: one workgroup per 16-row slab, threads over the float4 columns, rows in order
+__global__ __launch_bounds__(256) void concat_stats_kernel(const float4* __restrict__ a, int ca4, const float4* __restrict__ b, int cb4,
+                                                           float4* __restrict__ out, u16* __restrict__ out_sp, long long* __restrict__ stats,
+                                                           int hw, int groups) {
+  // workgroup = (16-row slab, 256-column span); thread = (4 rows, one float4 column) -- see splitk_reduce_stats_kernel (gemm.hip)
+  __shared__ float cs[2][4][256];
+  const int c4n = ca4 + cb4, C = c4n * 4;
+  const size_t m0 = (size_t)blockIdx.x * 16;
+  const int n0 = blockIdx.y * 256;
+  const int c4 = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < c4n) {
+    float4 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = m0 + rg * 4 + r;
+      v[r] = c4 < ca4 ? a[row * ca4 + c4] : b[row * cb4 + (c4 - ca4)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = m0 + rg * 4 + r;
+      out[row * c4n + c4] = v[r];
+      if (out_sp) store_sp4(out_sp, row, C, c4 * 4, v[r].x, v[r].y, v[r].z, v[r].w);
+      s.x += v[r].x; s.y += v[r].y; s.z += v[r].z; s.w += v[r].w;
+      q.x += v[r].x * v[r].x; q.y += v[r].y * v[r].y; q.z += v[r].z * v[r].z; q.w += v[r].w * v[r].w;
+    }
+  }
+  *(float4*)&cs[0][rg][(threadIdx.x & 63) * 4] = s;
+  *(float4*)&cs[1][rg][(threadIdx.x & 63) * 4] = q;
+  __syncthreads();
+  const int c = threadIdx.x, nn = n0 + c;
+  const float cs_ = cs[0][0][c] + cs[0][1][c] + cs[0][2][c] + cs[0][3][c];
+  const float cq_ = cs[1][0][c] + cs[1][1][c] + cs[1][2][c] + cs[1][3][c];
+  __syncthreads();
+  cs[0][0][c] = cs_;
+  cs[1][0][c] = cq_;
+  __syncthreads();
+  if (nn >= C) return;
+  const int cg = C / groups;
+  const int g = nn / cg, pos = nn - g * cg;
+  if (c != 0 && pos != 0) return;
+  int len = cg - pos;
+  if (len > 256 - c) len = 256 - c;
+  float ss = 0.f, qq = 0.f;
+  for (int j = 0; j < len; ++j) {
+    ss += cs[0][0][c + j];
+    qq += cs[1][0][c + j];
+  }
+  gn_stats_add(stats, (int)(m0 / hw), g, groups, ss, qq);
+}
+
 // vol (B,S,S,D,C) -> out (B,S/f,S/f,D,C), mean over f x f windows (F.interpolate(mode='area') with integer ratio)
 __global__ __launch_bounds__(256) void area_pool_kernel(const float4* __restrict__ vol, u16* __restrict__ out_sp, int B, int S,
                                                         int D, int C4, int f, int ldp) {
@@ -209,10 +260,18 @@ extern "C" int mvd_unet_input(const float* x, const float* input_latents, void* 
 }
 
 extern "C" int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_sp, int rows,
-                                   mvd_stream_t stream) {
+                                   long long* gn_stats, int gn_hw, int gn_groups, mvd_stream_t stream) {
   if (out_sp) MVD_CHECK_ARG((Ca + Cb) % 32 == 0, "mvd_concat_channels: split-planes output needs (Ca+Cb) %% 32 == 0");
   MVD_CHECK_ARG(a && b && out && rows > 0 && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0,
                 "mvd_concat_channels: bad arguments (channel counts must be multiples of 4)");
+  if (gn_stats) {
+    MVD_CHECK_ARG(rows % 16 == 0 && gn_hw > 0 && gn_hw % 16 == 0 && gn_groups > 0 && (Ca + Cb) % gn_groups == 0,
+                  "mvd_concat_channels: gn_stats needs rows %% 16 == 0, gn_hw %% 16 == 0, C %% groups == 0");
+    hipLaunchKernelGGL(concat_stats_kernel, dim3(rows / 16, (Ca + Cb + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float4*)a, Ca / 4,
+                       (const float4*)b, Cb / 4, (float4*)out, (u16*)out_sp, gn_stats, gn_hw, gn_groups);
+    MVD_CHECK_LAUNCH("mvd_concat_channels/stats");
+    return 0;
+  }
   const size_t total = (size_t)rows * (Ca + Cb) / 4;
   hipLaunchKernelGGL(concat_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, Ca / 4,
                      (const float4*)b, Cb / 4, (float4*)out, (u16*)out_sp, (size_t)rows);

@@ -64,8 +64,8 @@ __device__ __forceinline__ void store_out(const mvd_gemm_desc& d, int m, int n, 
 }
 
 // scalar element path (split-K reduce kernel, ragged n_store edge)
-__device__ __forceinline__ void epi_store_elem(const mvd_gemm_desc& d, int m, int n, float v) {
-  if (d.epi == MVD_EPI_STORE && n >= d.n_store) return;  // padded columns (bias / res have n_store entries)
+__device__ __forceinline__ float epi_store_elem(const mvd_gemm_desc& d, int m, int n, float v) {
+  if (d.epi == MVD_EPI_STORE && n >= d.n_store) return 0.f;  // padded columns (bias / res have n_store entries)
   v *= d.acc_scale;
   if (d.bias) v += d.bias[n];
   if (d.bias_b) v += d.bias_b[(size_t)(m / d.rows_per_batch) * d.ldbb + n];
@@ -87,12 +87,13 @@ __device__ __forceinline__ void epi_store_elem(const mvd_gemm_desc& d, int m, in
       const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
       store_planes1((u16*)d.vt_hi, (u16*)d.vt_lo, idx, v);
     }
-    return;
+    return v;
   }
   v = apply_act(v, d.act);
   if (d.colscale) v *= d.colscale[n];
   if (d.res) v += d.res[(size_t)m * d.ldr + n];
   store_out(d, m, n, v);
+  return v;
 }
 
 // value / gate pair -> one output column (packed column p: block of 32 = 16 value + 16 gate)
@@ -108,8 +109,8 @@ __device__ __forceinline__ void epi_geglu_elem(const mvd_gemm_desc& d, int m, in
   store_out(d, m, col, v * gelu_erf(g));
 }
 
-// four consecutive columns n..n+3 of row m (all inside N): coalesced 16-byte traffic
-__device__ __forceinline__ void epi_store4(const mvd_gemm_desc& d, int m, int n, float4 v) {
+// four consecutive columns n..n+3 of row m (all inside N): coalesced 16-byte traffic; returns the final values
+__device__ __forceinline__ float4 epi_store4(const mvd_gemm_desc& d, int m, int n, float4 v) {
   v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
   if (d.bias) {
     const float4 b = *(const float4*)(d.bias + n);
@@ -132,6 +133,7 @@ __device__ __forceinline__ void epi_store4(const mvd_gemm_desc& d, int m, int n,
   }
   if (d.out) *(float4*)(d.out + (size_t)m * d.ldo + n) = v;
   if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, n, v.x, v.y, v.z, v.w);
+  return v;
 }
 
 // ------------------------------------------------------------------------------------------------ main kernel
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
-  constexpr int A_GRAN = BM / 8, B_GRAN = BN / 8;     // 1 KiB granules (8 rows x 128 B: hi and lo of one 32-k block)
+  constexpr int A_GRAN = BM / 8, B_GRAN = BN / 8;     // 1 KiB granules (A: 8 rows x 128 B; packed B: one hi or lo fragment image)
   constexpr int AI = A_GRAN / NW, BI = (B_GRAN + NW - 1) / NW;   // granules per wave per k-tile
   constexpr int B_GRAN_P = BI * NW;                   // B granules rounded up to a multiple of the wave count: every wave issues
                                                       // the same number of DMAs (counted vmcnt); the extra ones copy the zero page
@@ -258,18 +260,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     }
     __syncthreads();
   }
-  const u16* b_src[BI];     // per B granule: micro-tile rows at kt = 0 (+ this lane's chunk) or null (-> zero page)
+  const u16* b_src[BI];     // per B granule: its source at kt = 0 (+ this lane's 16 bytes) or null (-> zero page)
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int gi = wave + i * NW;            // B granule index = 8-row group
-    const int R = (gi & 1) * 8 + gr;
-    const int gc = (lane & 7) ^ ((R >> 1) & 7);
+    const int gi = wave + i * NW;            // B granule index: packed weight = image gi & 1 of micro-tile gi >> 1; planes = 8-row group
     const int nt = (n0 >> 4) + (gi >> 1);
     if (d.b_mode == MVD_B_PLANES) {           // B rows are rows of an activation matrix in split planes (same 128-byte lines as A)
+      const int R = (gi & 1) * 8 + gr;
+      const int gc = (lane & 7) ^ ((R >> 1) & 7);
       const int n = n0 + gi * 8 + gr;
       b_src[i] = (gi < B_GRAN && n < d.N) ? (const u16*)d.Wp + (size_t)n * 2 * d.ldb + gc * 8 : nullptr;
     } else {
-      b_src[i] = (gi < B_GRAN && nt < p.nt16) ? (const u16*)d.Wp + (size_t)nt * 1024 + R * 64 + gc * 8 : nullptr;
+      b_src[i] = (gi < B_GRAN && nt < p.nt16) ? (const u16*)d.Wp + (size_t)nt * 1024 + (gi & 1) * 512 + lane * 8 : nullptr;
     }
   }
   // elements between consecutive k-tiles: packed weight = one row of micro-tiles; planes = the next 128-byte line of the row
@@ -374,6 +376,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(ah[i], bh[j], acc[i][j], 0, 0, 0);
   };
+  // B fragments in LDS: a packed micro-tile is already two fragment images (lane l at byte 16 l); planes are laid out like A
+  const int boff_hi = d.b_mode == MVD_B_PLANES ? foff_hi : lane * 16;
+  const int boff_lo = d.b_mode == MVD_B_PLANES ? foff_lo : 1024 + lane * 16;
   auto read_frags = [&](int buf, bf16x8 (&ah)[TM], bf16x8 (&al)[TM], bf16x8 (&bh)[TN], bf16x8 (&bl)[TN]) {
     const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + A_GRAN * 1024;
@@ -384,8 +389,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      bh[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + foff_hi);
-      if (NS >= 3) bl[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + foff_lo);
+      bh[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + boff_hi);
+      if (NS >= 3) bl[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + boff_lo);
     }
   };
 
@@ -604,12 +609,59 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     if (idx >= WTM * C4 || m >= d.M || n >= d.N) continue;
     const float4 v = *(const float4*)(sC + row * LDW + col);
     if (n + 3 < d.n_store) {
-      epi_store4(d, m, n, v);
+      const float4 f = epi_store4(d, m, n, v);
+      if (d.gn_stats) *(float4*)(sC + row * LDW + col) = f;      // final values back into the staging tile for the statistics pass
     } else {
       epi_store_elem(d, m, n, v.x);
       epi_store_elem(d, m, n + 1, v.y);
       epi_store_elem(d, m, n + 2, v.z);
       epi_store_elem(d, m, n + 3, v.w);
+    }
+  }
+  if (d.gn_stats) {
+    // GroupNorm statistics of the tensor just produced, for the GroupNorm that consumes it (mvd_groupnorm_from_stats): one lane
+    // per column sums its 16-row slabs in row order, the first lane of every (group, slab) fragment adds up its columns in
+    // column order and hands the pair to the integer atomics.  (The wave owns its staging tile: LDS ops of one wave are ordered.)
+    const int cg = d.n_store / d.gn_groups;
+    const int jmax = cg < 64 ? cg : 64;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c0 = 0; c0 < WTN; c0 += 64) {
+      const int col = c0 + lane, n = wn0 + col;
+      const bool okc = col < WTN && n < d.n_store;
+      const int gidx = okc ? n / cg : 0, pos = okc ? n - gidx * cg : 0;
+      const bool leader = okc && (pos == 0 || lane == 0);
+      int len = 0;
+      if (leader) {
+        len = cg - pos;
+        if (len > 64 - lane) len = 64 - lane;
+        if (len > WTN - col) len = WTN - col;
+        if (len > d.n_store - n) len = d.n_store - n;
+      }
+#pragma unroll
+      for (int sl = 0; sl < WTM / 16; ++sl) {
+        const int ms = wm0 + sl * 16;
+        if (ms >= d.M) break;
+        float s1 = 0.f, q1 = 0.f;
+        if (okc) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = sC[(sl * 16 + r) * LDW + col];
+            s1 += v;
+            q1 += v * v;
+          }
+        }
+        float ss = s1, qq = q1;
+        for (int j = 1; j < jmax; ++j) {
+          const float ts = __shfl_down(s1, j, 64), tq = __shfl_down(q1, j, 64);
+          if (j < len) {
+            ss += ts;
+            qq += tq;
+          }
+        }
+        if (leader) gn_stats_add(d.gn_stats, ms / d.gn_hw, gidx, d.gn_groups, ss, qq);
+      }
     }
   }
 }
@@ -663,6 +715,64 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     const int n = (int)(e - (size_t)m * d.N);
     epi_store_elem(d, m, n, v);
   }
+}
+
+// Split-K reduce for a GEMM whose output feeds a GroupNorm: one workgroup per (16-row slab, 256-column span); thread = (4 rows,
+// one float4 column), same sums and epilogue as splitk_reduce_kernel.  The per-column {sum, sum of squares} of the slab are
+// combined over the rows, then per group in column order (a group cut by the span boundary contributes from both workgroups),
+// and added to the statistics of the consumer GroupNorm (gn_stats_add: integer atomics, order independent).  MVD_EPI_STORE,
+// n_store == N.
+template <int RPT>   // rows per thread: slabs of 4 * RPT rows (16, or 8 when the problem has too few slabs to fill the chip)
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmParams p) {
+  __shared__ float cs[2][4][256];
+  const mvd_gemm_desc& d = p.d;
+  const size_t MN = (size_t)d.M * d.N;
+  const int m0 = blockIdx.x * (4 * RPT), n0 = blockIdx.y * 256;
+  const int c4 = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = n0 + c4 * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < d.N) {
+    float4 v[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* w = d.workspace + (size_t)(m0 + rg * RPT) * d.N + n;
+#pragma unroll 2
+    for (int z = 0; z < p.splits; ++z) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const float4 t = *(const float4*)(w + z * MN + (size_t)r * d.N);
+        v[r].x += t.x; v[r].y += t.y; v[r].z += t.z; v[r].w += t.w;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const float4 f = epi_store4(d, m0 + rg * RPT + r, n, v[r]);
+      s.x += f.x; s.y += f.y; s.z += f.z; s.w += f.w;
+      q.x += f.x * f.x; q.y += f.y * f.y; q.z += f.z * f.z; q.w += f.w * f.w;
+    }
+  }
+  *(float4*)&cs[0][rg][c4 * 4] = s;
+  *(float4*)&cs[1][rg][c4 * 4] = q;
+  __syncthreads();
+  const int c = threadIdx.x, nn = n0 + c;
+  const float cs_ = cs[0][0][c] + cs[0][1][c] + cs[0][2][c] + cs[0][3][c];
+  const float cq_ = cs[1][0][c] + cs[1][1][c] + cs[1][2][c] + cs[1][3][c];
+  __syncthreads();
+  cs[0][0][c] = cs_;
+  cs[1][0][c] = cq_;
+  __syncthreads();
+  if (nn >= d.N) return;
+  const int cg = d.N / d.gn_groups;
+  const int g = nn / cg, pos = nn - g * cg;
+  if (c != 0 && pos != 0) return;
+  int len = cg - pos;
+  if (len > 256 - c) len = 256 - c;
+  float ss = 0.f, qq = 0.f;
+  for (int j = 0; j < len; ++j) {
+    ss += cs[0][0][c + j];
+    qq += cs[1][0][c + j];
+  }
+  gn_stats_add(d.gn_stats, m0 / d.gn_hw, g, d.gn_groups, ss, qq);
 }
 
 // Tile configurations (mvd_gemm_desc.cfg = 1 + 6 * tile + 2 * loop + order; 0 = built-in heuristic).
@@ -769,6 +879,11 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   } else {
     MVD_CHECK_ARG(false, "mvd_gemm: bad epilogue %d", d.epi);
   }
+  if (d.gn_stats)
+    MVD_CHECK_ARG(d.epi == MVD_EPI_STORE && d.n_store == d.N && d.M % 16 == 0 && d.gn_hw > 0 && d.gn_hw % 16 == 0 && d.gn_groups > 0 &&
+                      d.N % d.gn_groups == 0,
+                  "mvd_gemm: gn_stats needs MVD_EPI_STORE, n_store == N, M %% 16 == 0, gn_hw %% 16 == 0, N %% gn_groups == 0 (N=%d M=%d hw=%d)",
+                  d.N, d.M, d.gn_hw);
   if (d.b_mode == MVD_B_PLANES)
     MVD_CHECK_ARG(d.ldb >= d.K && d.ldb % 32 == 0, "mvd_gemm: B planes need ldb=%d >= K=%d, a multiple of 32", d.ldb, d.K);
   else
@@ -834,10 +949,18 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   }
   MVD_CHECK_LAUNCH("mvd_gemm");
   if (p.splits > 1) {
-    const size_t total = (size_t)d.M * d.N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+    if (d.gn_stats) {
+      const int spans = (d.N + 255) / 256;
+      if ((d.M / 16) * spans >= 1024)
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel<4>, dim3(d.M / 16, spans), dim3(256), 0, s, p);
+      else
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel<2>, dim3(d.M / 8, spans), dim3(256), 0, s, p);
+    } else {
+      const size_t total = (size_t)d.M * d.N;
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+    }
     MVD_CHECK_LAUNCH("mvd_gemm/splitk_reduce");
   }
   return 0;
@@ -871,10 +994,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
     }
     u16 hi, lo;
     split_bf16(v * scale, hi, lo);
+    // [kt][nt][hi image | lo image]; an image is the 16x16x32 MFMA B fragment of the micro-tile as the wave holds it: lane
+    // l = (n & 15) + 16 * (k-chunk of 8) owns 16 contiguous bytes -- one fully coalesced 1 KiB access per image
+    // (the LDS-DMA source of a granule is contiguous, and the fragment reads from LDS are lane-contiguous: no bank conflicts)
     const int kt = k >> 5, kk = k & 31, nt = n >> 4, nn = n & 15;
-    const size_t base = ((size_t)kt * (Np >> 4) + nt) * 1024 + nn * 64 + kk;   // [kt][nt][16 n][32 hi | 32 lo]
+    const size_t base = ((size_t)kt * (Np >> 4) + nt) * 1024 + (nn + 16 * (kk >> 3)) * 8 + (kk & 7);
     out[base] = hi;
-    out[base + 32] = lo;
+    out[base + 512] = lo;
   }
 }
 

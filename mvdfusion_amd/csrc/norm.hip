@@ -153,6 +153,65 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// GroupNorm apply with the statistics emitted by the producer of x (gn_stats_add: 2^24 fixed-point {sum, sum of squares} per
+// (image, group)): mean / rstd in fp64 exactly as gn_apply_kernel does from its partial sums, then the same apply loop.
+__global__ __launch_bounds__(256) void gn_apply_stats_kernel(const float* __restrict__ x, u16* __restrict__ y_sp,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const long long* __restrict__ stats, int HW, int C, int groups, int chunks,
+                                                             float eps, int silu) {
+  __shared__ float s_a[GN_MAX_C];
+  __shared__ float s_b[GN_MAX_C];
+  __shared__ float s_mean[64];
+  __shared__ float s_rstd[64];
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int rows = HW / chunks;
+  const int cg = C / groups;
+  if (threadIdx.x < groups) {
+    const long long* p = stats + ((size_t)b * groups + threadIdx.x) * 2;
+    const double inv = 1.0 / (double)MVD_GN_FIXED_SCALE;
+    const double n = (double)HW * cg;
+    const double mean = (double)p[0] * inv / n;
+    double var = (double)p[1] * inv / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[threadIdx.x] = (float)mean;
+    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cg;
+    const float a = s_rstd[g] * gamma[c];
+    s_a[c] = a;
+    s_b[c] = beta[c] - s_mean[g] * a;
+  }
+  __syncthreads();
+  const size_t row0 = (size_t)b * HW + (size_t)chunk * rows;
+  const int C4 = C >> 2;
+  const int n4 = rows * C4;
+  const float4* x4 = (const float4*)(x + row0 * C);
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const int r = i / C4;
+    const int c = (i - r * C4) * 4;
+    float4 v = x4[i];
+    v.x = v.x * s_a[c] + s_b[c];
+    v.y = v.y * s_a[c + 1] + s_b[c + 1];
+    v.z = v.z * s_a[c + 2] + s_b[c + 2];
+    v.w = v.w * s_a[c + 3] + s_b[c + 3];
+    if (silu & 2) {
+      v.x = (float)(_Float16)v.x;
+      v.y = (float)(_Float16)v.y;
+      v.z = (float)(_Float16)v.z;
+      v.w = (float)(_Float16)v.w;
+    }
+    if (silu & 1) {
+      v.x = silu_f(v.x);
+      v.y = silu_f(v.y);
+      v.z = silu_f(v.z);
+      v.w = silu_f(v.w);
+    }
+    store_sp4(y_sp, row0 + r, C, c, v.x, v.y, v.z, v.w);
+  }
+}
+
 // Row softmax of a (rows, cols) fp32 logit matrix, scaled first; probabilities written as split planes (the A operand of
 // the P*V GEMM).  One wave per row, cols <= 4096 held in registers (the VAE AttnBlock has one head over h*w <= 4096 keys).
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, u16* __restrict__ y_sp, int rows, int cols,
@@ -281,6 +340,18 @@ extern "C" int mvd_groupnorm_nhwc(const float* x, void* y_sp, const float* gamma
   hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, B), dim3(256), 0, s, x, (u16*)y_sp, gamma, beta, ws, HW, C, groups, chunks,
                      eps, silu);
   MVD_CHECK_LAUNCH("mvd_groupnorm_nhwc/apply");
+  return 0;
+}
+
+extern "C" int mvd_groupnorm_from_stats(const float* x, void* y_sp, const float* gamma, const float* beta, const long long* stats, int B,
+                                        int HW, int C, int groups, float eps, int silu, mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && y_sp && gamma && beta && stats, "mvd_groupnorm_from_stats: null pointer");
+  MVD_CHECK_ARG(C % 32 == 0 && B > 0 && HW > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C <= GN_MAX_C,
+                "mvd_groupnorm_from_stats: bad shape (C=%d groups=%d)", C, groups);
+  const int chunks = gn_chunks(HW);
+  hipLaunchKernelGGL(gn_apply_stats_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, x, (u16*)y_sp, gamma, beta, stats, HW, C,
+                     groups, chunks, eps, silu);
+  MVD_CHECK_LAUNCH("mvd_groupnorm_from_stats");
   return 0;
 }
 

@@ -12,6 +12,10 @@ import torch
 from . import hip
 
 
+GN_SLOTS = 256                  # GroupNorm'd tensors per step (the UNet has 61 + 16 + 16)
+GN_SLOT_ELEMS = 64 * 32 * 2     # up to 64 images per batch, 32 groups, {sum, sum of squares}
+
+
 class Workspace:
     """Named static buffers.  get(tag, shape) returns the same tensor (same address) on every call."""
 
@@ -54,6 +58,7 @@ class Workspace:
 
 class Ctx:
     """Per-model execution context handed down the module tree."""
+    gn_from_producer = True         # False: every GroupNorm runs its own statistics kernel (A/B measurement, bench.py --gn-two-pass)
 
     def __init__(self, device, prec=hip.PREC_X4):
         self.device = torch.device(device)
@@ -67,11 +72,29 @@ class Ctx:
         self._rot = {}
         self.capturing = False      # set by StepEngine around graph capture: no new workspace buffer may appear then
         self.gemm_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 256 MB split-K slabs
+        # GroupNorm statistics emitted by the producers of the normalised tensors (GEMM epilogue / split-K reduce / concat):
+        # one (B, 32, 2) int64 slot per produced tensor per step, zeroed in one launch at the start of the step.
+        self.gn_arena = torch.zeros(GN_SLOTS * GN_SLOT_ELEMS, dtype=torch.int64, device=self.device)
+        self._gn_next = 0
+        self._gn = {}               # data_ptr of a produced tensor -> (stats slot, B, HW, C)
 
     def begin_step(self):
         """Reset the rotation of the layer-output buffers: the eager warm-up step and the captured step then walk the
         SAME act{i} slots in the same order (capture never meets a slot the warm-up did not allocate)."""
         self._rot.clear()
+        self._gn.clear()
+        self._gn_next = 0
+        if self.gn_from_producer:
+            self.gn_arena.zero_()
+
+    def gn_slot(self, out, B, HW, C):
+        """Reserve the statistics slot of `out` (a (B*HW, C) tensor about to be produced) and remember it for ctx.groupnorm."""
+        n = B * 32 * 2
+        assert n <= GN_SLOT_ELEMS and self._gn_next < GN_SLOTS, (B, self._gn_next)
+        st = self.gn_arena[self._gn_next * GN_SLOT_ELEMS:self._gn_next * GN_SLOT_ELEMS + n]
+        self._gn_next += 1
+        self._gn[out.data_ptr()] = (st, B, HW, C)
+        return st
 
     def act(self, shape):
         """Rotating layer-output buffers (3 per shape): a layer's input stays valid while it writes its output."""
@@ -81,15 +104,33 @@ class Ctx:
         return self.ws.get(f"act{i}", key)
 
     # -- op helpers bound to this context
-    def gemm(self, A, W, out, **kw):
+    def gemm(self, A, W, out, gn=None, **kw):
+        """gn=(B, HW): `out` feeds a GroupNorm over (B, HW, N) -- the GEMM emits its statistics (see gn_slot)."""
         kw.setdefault("prec", self.prec)
         kw.setdefault("workspace", self.gemm_ws)
+        if out is not None:
+            self._gn.pop(out.data_ptr(), None)          # whatever statistics the buffer had are stale now
+            if gn is not None and self.gn_from_producer and gn[1] % 16 == 0 and out.shape[-1] % 32 == 0:
+                kw.update(gn_stats=self.gn_slot(out, gn[0], gn[1], out.shape[-1]), gn_hw=gn[1], gn_groups=32)
         return hip.gemm(A, W, out, **kw)
 
     def groupnorm(self, x, y, norm, B, HW, C, silu):
+        ent = self._gn.get(x.data_ptr())
+        if ent is not None and ent[1:] == (B, HW, C) and norm.num_groups == 32:
+            return hip.groupnorm_from_stats(x, y, norm.weight, norm.bias, ent[0], B, HW, C, norm.eps, silu)
         # partial-sum workspace sized for THIS call (B * chunks(HW) * groups * 2 doubles); the ABI checks the size
         ws = self.ws.get("gn_ws", (B * hip.lib().mvd_groupnorm_chunks(HW) * 32 * 2,), torch.float64)
         return hip.groupnorm(x, y, norm.weight, norm.bias, B, HW, C, norm.eps, silu, ws)
+
+    def concat(self, a, ca, b, cb, out, out_planes, B, HW):
+        """out = [a | b] along the channels (+ its split planes), with the GroupNorm statistics of the result."""
+        self._gn.pop(out.data_ptr(), None)
+        st = None
+        if self.gn_from_producer and HW % 16 == 0 and (ca + cb) % 32 == 0:
+            st = self.gn_slot(out, B, HW, ca + cb)
+        hip.check(hip.lib().mvd_concat_channels(hip.ptr(a), ca, hip.ptr(b), cb, hip.ptr(out), hip.ptr(out_planes), B * HW,
+                                                hip.ptr(st) if st is not None else None, HW, 32, hip.stream()))
+        return out
 
     def layernorm(self, x, y, norm, rows, C):
         return hip.layernorm(x, y, norm.weight, norm.bias, rows, C, norm.eps)

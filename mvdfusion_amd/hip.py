@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("q_hi", _vp), ("q_lo", _vp), ("k_hi", _vp), ("k_lo", _vp), ("vt_hi", _vp), ("vt_lo", _vp),
         ("heads", _i), ("dhead", _i), ("L", _i), ("Lpad", _i), ("qscale", _f),
         ("splitk", _i), ("workspace", _vp), ("workspace_elems", _sz), ("cfg", _i),
+        ("gn_stats", _vp), ("gn_hw", _i), ("gn_groups", _i),
     ]
 
 
@@ -63,7 +64,8 @@ SIGNATURES = {
     "mvd_attention": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_unet_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "mvd_groupnorm_from_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_fill_zero": (_i, [_vp, _sz, _vp]),
     "mvd_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
@@ -279,12 +281,14 @@ def split_planes(x, out=None, ldp=None):
 
 def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
          bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
-         out_planes=None, out_planes_col=0, cfg=None):
+         out_planes=None, out_planes_col=0, cfg=None, gn_stats=None, gn_hw=0, gn_groups=32):
     """out = epilogue(A @ W^T).  A: split planes (M, 2*K) int16 (dense) or the NHWC image rows (B*H*W, 2*C) with
     conv=dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
     out: fp32 tensor or None; out_planes: split-planes tensor or None (feeds the next GEMM); out_planes_col: first column
     (multiple of 32) of a WIDER planes buffer that receives the output -- the GEMM then fills columns
     [out_planes_col, out_planes_col + N) of every row and leaves the others alone (operand concatenation along K).
+    gn_stats: zeroed int64 (M / gn_hw, gn_groups, 2) tensor that receives the GroupNorm statistics of the output (consumed by
+    groupnorm_from_stats instead of a statistics kernel).
     """
     assert A.dtype == torch.int16, "A must be in split-planes format (see hip.split_planes)"
     d = GemmDesc()
@@ -333,6 +337,8 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.heads, d.dhead, d.L = qkv["heads"], qkv["dhead"], qkv["L"]
         d.Lpad = lib().mvd_attn_lpad(qkv["L"])
         d.qscale = float(qkv["dhead"]) ** -0.5 * 1.4426950408889634      # * log2(e): mvd_attention works in base 2
+    if gn_stats is not None:
+        d.gn_stats, d.gn_hw, d.gn_groups = gn_stats.data_ptr(), int(gn_hw), int(gn_groups)
     d.splitk = splitk
     if workspace is not None:
         d.workspace = workspace.data_ptr()
@@ -362,7 +368,7 @@ def _cfg_parts(cfg):
     return (cfg - 1) // 8, ((cfg - 1) % 8) >> 1, (cfg - 1) & 1          # tile, loop, order
 
 
-def _cfg_valid(cfg, epi):
+def _cfg_valid(cfg, epi, b_mode=0):
     tile, loop, _ = _cfg_parts(cfg)
     bm, bn, wm, wn = GEMM_TILES[tile]
     return (loop < 2 or wm * wn == 8) and (loop < 3 or tile == 1) and (tile < 2 or epi == EPI_STORE)
@@ -371,10 +377,10 @@ def _cfg_valid(cfg, epi):
 GEMM_CONFIGS = tuple(c for c in range(1, 8 * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
 
 
-def gemm_configs(epi=EPI_STORE):
-    """Kernel configurations valid for an epilogue (the 80-column tiles serve EPI_STORE only; the staggered loop needs an
-    8-wave tile)."""
-    return tuple(c for c in GEMM_CONFIGS if _cfg_valid(c, epi))
+def gemm_configs(epi=EPI_STORE, b_mode=0):
+    """Kernel configurations valid for an epilogue / B operand kind (the 80-column tiles serve EPI_STORE only; the staggered loop
+    needs an 8-wave tile; every configuration serves both B operand kinds)."""
+    return tuple(c for c in GEMM_CONFIGS if _cfg_valid(c, epi, b_mode))
 
 
 def kernel_symbol(cfg, prec, conv):
@@ -428,8 +434,9 @@ def _autotune(d, A=None, reps=4, trials=3):
     launch is preceded by a cache flush and a re-read of the A operand; min over `trials` single launches."""
     best, best_ms = (0, d.splitk), float("inf")
     e0, e1 = Event(), Event()
+    stats_ptr, d.gn_stats = d.gn_stats, None          # the statistics atomics must run exactly once: only in the real launch
     # split-K: the library's model (0 = auto) or none (1); the timed region includes the reduce kernel of a split GEMM
-    cands = [(c, sk) for c in gemm_configs(d.epi) for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]
+    cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode) for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]
     for cfg, sk in cands:
         d.cfg, d.splitk = cfg, sk
         check(lib().mvd_gemm(C.byref(d), stream()))
@@ -455,6 +462,7 @@ def _autotune(d, A=None, reps=4, trials=3):
             ms += 0.0015
         if ms < best_ms * 0.99:
             best, best_ms = (cfg, sk), ms
+    d.gn_stats = stats_ptr
     return best
 
 
@@ -470,6 +478,12 @@ def groupnorm(x, y, gamma, beta, B, HW, Cc, eps, silu, ws):
     """y: split planes (B*HW, 2*C)."""
     check(lib().mvd_groupnorm_nhwc(ptr(x), ptr(y), ptr(gamma), ptr(beta), B, HW, Cc, 32, eps, int(silu), ptr(ws), ws.numel(),
                                    stream()))
+    return y
+
+
+def groupnorm_from_stats(x, y, gamma, beta, stats, B, HW, Cc, eps, silu, groups=32):
+    """GroupNorm apply with producer-emitted statistics (see gemm(gn_stats=...)); y: split planes (B*HW, 2*C)."""
+    check(lib().mvd_groupnorm_from_stats(ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(stats), B, HW, Cc, groups, eps, int(silu), stream()))
     return y
 
 

@@ -47,7 +47,7 @@ class Upsample(nn.Module):
             out = ctx.act((ctx.B * 4 * H * W, self.out_channels))
         xp = hip.split_planes(x, ctx.ws.planes("updown.x", ctx.B * H * W, self.channels))   # raw residual stream -> planes
         ctx.gemm(xp, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=2 * H, Wout=2 * W,
-                                            stride=1, upsample=1))
+                                            stride=1, upsample=1), gn=(ctx.B, 4 * H * W))
         return out, 2 * H, 2 * W
 
 
@@ -66,7 +66,7 @@ class Downsample(nn.Module):
             out = ctx.act((ctx.B * Ho * Wo, self.out_channels))
         xp = hip.split_planes(x, ctx.ws.planes("updown.x", ctx.B * H * W, self.channels))
         ctx.gemm(xp, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=Ho, Wout=Wo, stride=2,
-                                            upsample=0))
+                                            upsample=0), gn=(ctx.B, Ho * Wo))
         return out, Ho, Wo
 
 
@@ -105,8 +105,7 @@ class ResBlock(TimestepBlock):
         ctx.groupnorm(x, a, self.in_layers[0], B, H * W, Ci, silu=True)
         h = ctx.ws.get("res.h", (M, Co))
         # conv bias + Linear(SiLU(emb)) are folded into one per-step bias vector (UNetModel._time_biases)
-        hip.gemm(a, w1, h, prec=ctx.prec, conv=dict(Cin=Ci, **geo), bias=False, colscale=None,
-                 res=None, workspace=ctx.gemm_ws, bias_b=ctx.emb_bias[self], rows_per_batch=M)
+        ctx.gemm(a, w1, h, conv=dict(Cin=Ci, **geo), bias=False, bias_b=ctx.emb_bias[self], rows_per_batch=M, gn=(B, H * W))
         a2 = ctx.ws.planes("res.a2", M, Co)
         ctx.groupnorm(h, a2, self.out_layers[0], B, H * W, Co, silu=True)
         skip = x
@@ -117,7 +116,7 @@ class ResBlock(TimestepBlock):
             ctx.gemm(x_planes, wsk, skip)
         if out is None:
             out = ctx.act((M, Co))
-        ctx.gemm(a2, w2, out, conv=dict(Cin=Co, **geo), res=skip)
+        ctx.gemm(a2, w2, out, conv=dict(Cin=Co, **geo), res=skip, gn=(B, H * W))
         return out
 
 
@@ -145,7 +144,7 @@ class _StemConv(nn.Conv2d):
         if self._p is None:
             self._p = hip.pack_conv3x3(self.weight, self.bias)
         ctx.gemm(x, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self._p.conv_cin, Hout=H, Wout=W, stride=1,
-                                            upsample=0))
+                                            upsample=0), gn=(ctx.B, H * W))
         return out
 
 
@@ -300,8 +299,7 @@ class UNetModel(nn.Module):
             ca, cb = h.shape[-1], sk.shape[-1]
             cat = ctx.ws.get("cat", (M, ca + cb))
             catp = ctx.ws.planes("catp", M, ca + cb)          # planes for the ResBlock's 1x1 skip conv
-            hip.check(hip.lib().mvd_concat_channels(hip.ptr(h), ca, hip.ptr(sk), cb, hip.ptr(cat), hip.ptr(catp), M,
-                                                    hip.stream()))
+            ctx.concat(h, ca, sk, cb, cat, catp, B, H * W)
             h, H, W = blk.run(ctx, cat, H, W, x_planes=catp)
         if self._head is None:
             self._head = hip.pack_conv3x3(self.out[2].weight, self.out[2].bias)

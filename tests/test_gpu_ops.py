@@ -229,6 +229,63 @@ def test_gemm_configurations_agree(hip, cfg, splitk):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("cfg", [0] + list(_hip.gemm_configs(_hip.EPI_STORE)))
+@pytest.mark.parametrize("splitk", [0, 1, 3])
+def test_gemm_groupnorm_statistics(hip, cfg, splitk):
+    """mvd_gemm_desc.gn_stats: the GEMM (tile epilogue or split-K reduce) emits the GroupNorm statistics of its output as integer
+    atomics; mvd_groupnorm_from_stats must then reproduce F.group_norm of the stored output, and the statistics must be identical
+    bit for bit across repeats (integer accumulation is order independent)."""
+    ws = torch.empty(16 * 1024 * 1024, device="cuda")
+    for B, HW, N, K in [(2, 256, 320, 320), (3, 64, 640, 1344), (2, 16, 1280, 96), (1, 1024, 96, 64), (4, 16, 32, 32)]:
+        M = B * HW
+        a = torch.randn(M, K, generator=g(50)) + 0.1
+        w = torch.randn(N, K, generator=g(51)) / math.sqrt(K)
+        b = torch.randn(N, generator=g(52))
+        r = torch.randn(M, N, generator=g(53))
+        gm, bt = torch.randn(N, generator=g(54)), torch.randn(N, generator=g(55))
+        Wp = hip.pack_linear(w.cuda(), b.cuda())
+        ap, rc, gc, bc = hip.split_planes(a.cuda()), r.cuda(), gm.cuda(), bt.cuda()
+        stats = []
+        for rep in range(2):
+            out = torch.full((M, N), float("nan"), device="cuda")
+            st = torch.zeros(B, 32, 2, dtype=torch.int64, device="cuda")
+            hip.gemm(ap, Wp, out, prec=4, workspace=ws, cfg=cfg, splitk=splitk, res=rc, gn_stats=st, gn_hw=HW)
+            stats.append(st.cpu())
+        assert torch.equal(stats[0], stats[1])
+        assert rel_err(out, a @ w.t() + b + r) < TOL[4]
+        x = out.cpu().view(B, HW, N)
+        xg = x.double().view(B, HW, 32, N // 32)
+        sums = torch.stack([xg.sum(dim=(1, 3)), (xg * xg).sum(dim=(1, 3))], -1)
+        mags = torch.stack([xg.abs().sum(dim=(1, 3)), (xg * xg).sum(dim=(1, 3))], -1)          # fp32 partial sums: error ~ sum |x|
+        got = stats[0].double() / 2.0 ** 24
+        assert float(((got - sums).abs() / (1.0 + mags)).max()) < 2e-6, (B, HW, N, K)
+        y = hip.planes_like(M, N, "cuda")
+        hip.groupnorm_from_stats(out, y, gc, bc, st, B, HW, N, 1e-5, True)
+        ref = F.silu(F.group_norm(x.permute(0, 2, 1), 32, gm, bt, eps=1e-5).permute(0, 2, 1))
+        assert rel_err(planes_to_float(y).view(B, HW, N), ref) < PL + 3e-6, (B, HW, N, K)
+
+
+def test_concat_groupnorm_statistics(hip):
+    for B, HW, ca, cb in [(2, 64, 1280, 1280), (4, 1024, 320, 320), (3, 16, 64, 32)]:
+        M = B * HW
+        a, b = torch.randn(M, ca, generator=g(56)) * 2, torch.randn(M, cb, generator=g(57)) + 0.5
+        C = ca + cb
+        gm, bt = torch.randn(C, generator=g(58)), torch.randn(C, generator=g(59))
+        ad, bd, gc, bc = a.cuda(), b.cuda(), gm.cuda(), bt.cuda()
+        out = torch.empty(M, C, device="cuda")
+        outp = hip.planes_like(M, C, "cuda")
+        st = torch.zeros(B, 32, 2, dtype=torch.int64, device="cuda")
+        hip.check(hip.lib().mvd_concat_channels(hip.ptr(ad), ca, hip.ptr(bd), cb, hip.ptr(out), hip.ptr(outp), M, hip.ptr(st), HW, 32,
+                                                hip.stream()))
+        cat = torch.cat([a, b], 1)
+        assert torch.equal(out.cpu(), cat)
+        assert rel_err(planes_to_float(outp), cat) < PL
+        y = hip.planes_like(M, C, "cuda")
+        hip.groupnorm_from_stats(out, y, gc, bc, st, B, HW, C, 1e-5, False)
+        ref = F.group_norm(cat.view(B, HW, C).permute(0, 2, 1), 32, gm, bt, eps=1e-5).permute(0, 2, 1)
+        assert rel_err(planes_to_float(y).view(B, HW, C), ref) < PL + 3e-6
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("B,HW,C,silu,eps", [(4, 1024, 320, True, 1e-5), (2, 256, 1920, True, 1e-5), (3, 64, 1280, False, 1e-6),
                                              (2, 16, 2560, True, 1e-5), (2, 1024, 32, False, 1e-6)])
@@ -396,7 +453,7 @@ def test_area_pool_concat_input(hip):
     out = torch.empty(100, 960, device="cuda")
     ac, bc = a.cuda(), b.cuda()
     outp = hip.planes_like(100, 960, "cuda")
-    hip.check(hip.lib().mvd_concat_channels(hip.ptr(ac), 320, hip.ptr(bc), 640, hip.ptr(out), hip.ptr(outp), 100, hip.stream()))
+    hip.check(hip.lib().mvd_concat_channels(hip.ptr(ac), 320, hip.ptr(bc), 640, hip.ptr(out), hip.ptr(outp), 100, None, 0, 0, hip.stream()))
     assert torch.equal(out.cpu(), torch.cat([a, b], 1))
     assert rel_err(planes_to_float(outp), torch.cat([a, b], 1)) < PL
     V, S = 3, 32
