@@ -109,7 +109,26 @@ __device__ __forceinline__ void store_planes1(u16* __restrict__ hi, u16* __restr
   lo[idx] = l;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf without branches: erf(|x|) = 1 - exp(-t(|x|)), t = -ln erfc fitted by |x| * P8(|x|) on [0, 4] (erfc(4) < 2^-25: erf == 1 in fp32
+// from there on).  Max absolute error 9.5e-8 over the whole line (the rounding of 1 - exp dominates), i.e. the level of an fp32
+// rounding of erf itself -- which is all the exact GELU 0.5 x (1 + erf(x / sqrt 2)) needs, down to x -> 0.  15 VALU operations and
+// one basic block (the library erff is two regimes behind a divergent branch: ~35 operations, and a scheduling boundary that keeps
+// MFMAs of the surrounding GEMM phases from overlapping it -- csrc/gridattn_fused.hip evaluates 448 GELUs per lane).
+__device__ __forceinline__ float erf_nobranch(float x) {
+  const float a = fminf(fabsf(x), 4.0f);
+  float p = -8.043882189667784e-06f;
+  p = __builtin_fmaf(p, a, 0.00010602718248264864f);
+  p = __builtin_fmaf(p, a, -0.0005879526142962277f);
+  p = __builtin_fmaf(p, a, 0.0015767638105899096f);
+  p = __builtin_fmaf(p, a, -5.878534648218192e-05f);
+  p = __builtin_fmaf(p, a, -0.01921714097261429f);
+  p = __builtin_fmaf(p, a, 0.10279920697212219f);
+  p = __builtin_fmaf(p, a, 0.6366161108016968f);
+  p = __builtin_fmaf(p, a, 1.1283793449401855f);
+  const float e = __builtin_amdgcn_exp2f(p * a * -1.4426950408889634f);
+  return copysignf(1.0f - e, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_nobranch(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -84,8 +84,8 @@ class Ctx:
         self._rot.clear()
         self._gn.clear()
         self._gn_next = 0
-        if self.gn_from_producer:
-            self.gn_arena.zero_()
+        if self.gn_from_producer:          # (one launch of the library's own fill kernel: the step contains no framework kernels)
+            hip.check(hip.lib().mvd_fill_zero(hip.ptr(self.gn_arena), self.gn_arena.numel() * 2, hip.stream()))
 
     def gn_slot(self, out, B, HW, C):
         """Reserve the statistics slot of `out` (a (B*HW, C) tensor about to be produced) and remember it for ctx.groupnorm."""
