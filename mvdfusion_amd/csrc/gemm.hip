@@ -639,11 +639,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         if (len > WTN - col) len = WTN - col;
         if (len > d.n_store - n) len = d.n_store - n;
       }
+      // images at least as tall as the wave tile (gn_hw % WTM == 0): one pair of atomics per wave tile and group fragment -- the
+      // 16-row slabs are summed in row order first; shorter images: one pair per slab
+      const bool whole = d.gn_hw % WTM == 0;
+      float s1 = 0.f, q1 = 0.f;
 #pragma unroll
       for (int sl = 0; sl < WTM / 16; ++sl) {
         const int ms = wm0 + sl * 16;
         if (ms >= d.M) break;
-        float s1 = 0.f, q1 = 0.f;
+        if (!whole) s1 = q1 = 0.f;
         if (okc) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -652,6 +656,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
             q1 += v * v;
           }
         }
+        if (whole && sl + 1 < WTM / 16 && ms + 16 < d.M) continue;
         float ss = s1, qq = q1;
         for (int j = 1; j < jmax; ++j) {
           const float ts = __shfl_down(s1, j, 64), tq = __shfl_down(q1, j, 64);
