@@ -14,7 +14,7 @@
  *   - return 0 on success, <0 on error; the message is available from mvd_last_error(); nothing throws;
  *   - activations are fp32, channels-last: an image tensor is (B, H, W, C) == a row-major (B*H*W, C) matrix;
  *   - GEMM-shaped math runs on 16-bit MFMA (fp16 by default, bf16 in the -DMVD_OPERAND_BF16 build; same rate).
- *     `prec` selects MVD_PREC_BF16 (= one product per operand pair) or MVD_PREC_BF16X3 (= operands split
+ *     `prec` selects MVD_PREC_X1 (= one product per operand pair) or MVD_PREC_X3 (= operands split
  *     x = hi + lo, three products hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2^-22 (fp16) / ~2^-17 (bf16) relative
  *     operand error; the 50-step stochastic trajectory amplifies operand error by ~10^3, so the split is what keeps it
  *     within the 1e-3 latent-RMSE budget).
@@ -38,8 +38,8 @@ extern "C" {
 typedef void* mvd_stream_t; /* hipStream_t */
 
 #define MVD_VERSION 100
-#define MVD_PREC_BF16 1   /* one product per operand pair (hi only) */
-#define MVD_PREC_BF16X3 3 /* hi*hi + hi*lo + lo*hi */
+#define MVD_PREC_X1 1   /* one product per operand pair (hi only) */
+#define MVD_PREC_X3 3 /* hi*hi + hi*lo + lo*hi */
 #define MVD_PREC_X4 4     /* all four partial products of the (hi+lo)(hi+lo) split: fp32-class products */
 
 int mvd_version(void);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
   const u16* vp[2] = {vt_hi + bh * DV * Lpad, vt_lo + bh * DV * Lpad};
 
   bool active[QT];
-  bf16x8 qh[QT][QS], ql[QT][QS];
+  op16x8 qh[QT][QS], ql[QT][QS];
 #pragma unroll
   for (int t2 = 0; t2 < QT; ++t2) {
     active[t2] = q0 + 16 * t2 < L;
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
     const size_t qoff = (bh * Lpad + q0 + 16 * t2 + c) * DQ + g * 8;
 #pragma unroll
     for (int ks = 0; ks < QS; ++ks) {
-      qh[t2][ks] = inb ? *(const bf16x8*)(q_hi + qoff + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (NS >= 3) ql[t2][ks] = inb ? *(const bf16x8*)(q_lo + qoff + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      qh[t2][ks] = inb ? *(const op16x8*)(q_hi + qoff + ks * 32) : (op16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (NS >= 3) ql[t2][ks] = inb ? *(const op16x8*)(q_lo + qoff + ks * 32) : (op16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
   f32x4 o[QT][DT];
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
         s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < QS; ++ks) {
-          const bf16x8 kh = *(const bf16x8*)&sK[buf][0][kt * 16 + c][ks * 32 + g * 8];
+          const op16x8 kh = *(const op16x8*)&sK[buf][0][kt * 16 + c][ks * 32 + g * 8];
           if (NS >= 3) {
-            const bf16x8 kl = *(const bf16x8*)&sK[buf][NPL - 1][kt * 16 + c][ks * 32 + g * 8];
+            const op16x8 kl = *(const op16x8*)&sK[buf][NPL - 1][kt * 16 + c][ks * 32 + g * 8];
             if (NS == 4) s[kt] = MVD_MFMA_16x16x32(kl, ql[t2][ks], s[kt], 0, 0, 0);
             s[kt] = MVD_MFMA_16x16x32(kl, qh[t2][ks], s[kt], 0, 0, 0);
             s[kt] = MVD_MFMA_16x16x32(kh, ql[t2][ks], s[kt], 0, 0, 0);
@@ -173,15 +173,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
 #pragma unroll
       for (int i = 0; i < DT; ++i) o[t2][i] *= alpha;
       // ---- P^T as MFMA B operand: k-slot (g, j): j<4 -> key 32u + 4g + j ; j>=4 -> key 32u + 16 + 4g + (j-4)
-      bf16x8 ph[2], pl2[2];
+      op16x8 ph[2], pl2[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        union { bf16x8 v; u16 e[8]; } H8, L8;
+        union { op16x8 v; u16 e[8]; } H8, L8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float pv = j < 4 ? s[2 * u][j] : s[2 * u + 1][j - 4];
           if (NS >= 3) {
-            split_bf16(pv, H8.e[j], L8.e[j]);
+            split_op16(pv, H8.e[j], L8.e[j]);
           } else {
             H8.e[j] = to_op_bits(pv);
           }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
       for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          union { bf16x8 v; uint2 h2[2]; } VH, VL;
+          union { op16x8 v; uint2 h2[2]; } VH, VL;
           VH.h2[0] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 4 * g];
           VH.h2[1] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 16 + 4 * g];
           if (NS >= 3) {
@@ -438,14 +438,14 @@ extern "C" int mvd_attention(const void* q_hi, const void* q_lo, const void* k_h
   MVD_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out_sp, "mvd_attention: null pointer");
   MVD_CHECK_ARG(B > 0 && heads > 0 && L > 0 && dhead > 0 && dhead % 4 == 0, "mvd_attention: bad shape (dhead %% 4 == 0)");
   MVD_CHECK_ARG(ldo % 32 == 0 && ((uintptr_t)out_sp & 127) == 0, "mvd_attention: out must be split planes (ldo %% 32 == 0, 128-byte aligned)");
-  MVD_CHECK_ARG(prec == MVD_PREC_BF16 || prec == MVD_PREC_BF16X3 || prec == MVD_PREC_X4, "mvd_attention: bad prec");
+  MVD_CHECK_ARG(prec == MVD_PREC_X1 || prec == MVD_PREC_X3 || prec == MVD_PREC_X4, "mvd_attention: bad prec");
   const int Lpad = mvd_attn_lpad(L);
   const int Lk = Lkeys > 0 ? Lkeys : L;
   MVD_CHECK_ARG(Lk <= L, "mvd_attention: Lkeys=%d must be <= L=%d", Lk, L);
   int rc;
   if (prec == MVD_PREC_X4)
     rc = launch_attn<4>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lk, Lpad, dhead, (hipStream_t)stream);
-  else if (prec == MVD_PREC_BF16X3)
+  else if (prec == MVD_PREC_X3)
     rc = launch_attn<3>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lk, Lpad, dhead, (hipStream_t)stream);
   else
     rc = launch_attn<1>(q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_sp, ldo, B, heads, L, Lk, Lpad, dhead, (hipStream_t)stream);

@@ -16,7 +16,7 @@ typedef _Float16 op_t;
 #define MVD_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define MVD_OPERAND_FORMAT 0xf16
 #endif
-typedef __attribute__((ext_vector_type(8))) op_t bf16x8;   // 8 MFMA operand elements (historical name)
+typedef __attribute__((ext_vector_type(8))) op_t op16x8;   // 8 MFMA operand elements (fp16 or bf16: MVD_OPERAND_F16)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short u16;
 
@@ -55,7 +55,7 @@ __device__ __forceinline__ u16 f32_to_bf16_rne(float f) {
 }
 __device__ __forceinline__ float bf16_to_f32(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-__device__ __forceinline__ void split_bf16(float x, u16& hi, u16& lo) {
+__device__ __forceinline__ void split_op16(float x, u16& hi, u16& lo) {
   // x ~= hi + lo in the operand type; compiler-native conversions (v_cvt_pk_*), round-to-nearest-even
   const op_t h = (op_t)x;
   const op_t l = (op_t)(x - (float)h);
@@ -75,17 +75,17 @@ __device__ __forceinline__ size_t sp_index(size_t row, int ld, int k) { return r
 // four consecutive elements k..k+3 (k % 4 == 0) of one row
 __device__ __forceinline__ void store_sp4(u16* __restrict__ base, size_t row, int ld, int k, float a, float b, float c, float d) {
   u16 h[4], l[4];
-  split_bf16(a, h[0], l[0]);
-  split_bf16(b, h[1], l[1]);
-  split_bf16(c, h[2], l[2]);
-  split_bf16(d, h[3], l[3]);
+  split_op16(a, h[0], l[0]);
+  split_op16(b, h[1], l[1]);
+  split_op16(c, h[2], l[2]);
+  split_op16(d, h[3], l[3]);
   u16* p = base + sp_index(row, ld, k);
   *(uint2*)p = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
   *(uint2*)(p + 32) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 __device__ __forceinline__ void store_sp1(u16* __restrict__ base, size_t row, int ld, int k, float a) {
   u16 h, l;
-  split_bf16(a, h, l);
+  split_op16(a, h, l);
   u16* p = base + sp_index(row, ld, k);
   p[0] = h;
   p[32] = l;
@@ -95,16 +95,16 @@ __device__ __forceinline__ void store_sp1(u16* __restrict__ base, size_t row, in
 __device__ __forceinline__ void store_planes4(u16* __restrict__ hi, u16* __restrict__ lo, size_t idx, float a, float b,
                                               float c, float d) {
   u16 h[4], l[4];
-  split_bf16(a, h[0], l[0]);
-  split_bf16(b, h[1], l[1]);
-  split_bf16(c, h[2], l[2]);
-  split_bf16(d, h[3], l[3]);
+  split_op16(a, h[0], l[0]);
+  split_op16(b, h[1], l[1]);
+  split_op16(c, h[2], l[2]);
+  split_op16(d, h[3], l[3]);
   *(uint2*)(hi + idx) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
   *(uint2*)(lo + idx) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 __device__ __forceinline__ void store_planes1(u16* __restrict__ hi, u16* __restrict__ lo, size_t idx, float a) {
   u16 h, l;
-  split_bf16(a, h, l);
+  split_op16(a, h, l);
   hi[idx] = h;
   lo[idx] = l;
 }

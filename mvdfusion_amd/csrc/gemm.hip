@@ -352,7 +352,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   const int foff_hi = fbase + (((lane >> 4)) ^ fsw) * 16;
   const int foff_lo = fbase + ((4 + (lane >> 4)) ^ fsw) * 16;
 
-  auto mfma_tile = [&](const bf16x8 (&ah)[TM], const bf16x8 (&al)[TM], const bf16x8 (&bh)[TN], const bf16x8 (&bl)[TN]) {
+  auto mfma_tile = [&](const op16x8 (&ah)[TM], const op16x8 (&al)[TM], const op16x8 (&bh)[TN], const op16x8 (&bl)[TN]) {
     // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependency); every accumulator
     // still receives lo*lo, lo*hi, hi*lo, hi*hi in that order per k-tile (the summation order is part of the numerics).
     if (NS == 4) {
@@ -379,18 +379,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   // B fragments in LDS: a packed micro-tile is already two fragment images (lane l at byte 16 l); planes are laid out like A
   const int boff_hi = d.b_mode == MVD_B_PLANES ? foff_hi : lane * 16;
   const int boff_lo = d.b_mode == MVD_B_PLANES ? foff_lo : 1024 + lane * 16;
-  auto read_frags = [&](int buf, bf16x8 (&ah)[TM], bf16x8 (&al)[TM], bf16x8 (&bh)[TN], bf16x8 (&bl)[TN]) {
+  auto read_frags = [&](int buf, op16x8 (&ah)[TM], op16x8 (&al)[TM], op16x8 (&bh)[TN], op16x8 (&bl)[TN]) {
     const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + A_GRAN * 1024;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      ah[i] = *(const bf16x8*)(sA + (wm * TM + i) * 2048 + foff_hi);
-      if (NS >= 3) al[i] = *(const bf16x8*)(sA + (wm * TM + i) * 2048 + foff_lo);
+      ah[i] = *(const op16x8*)(sA + (wm * TM + i) * 2048 + foff_hi);
+      if (NS >= 3) al[i] = *(const op16x8*)(sA + (wm * TM + i) * 2048 + foff_lo);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      bh[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + boff_hi);
-      if (NS >= 3) bl[j] = *(const bf16x8*)(sB + (wn * TN + j) * 2048 + boff_lo);
+      bh[j] = *(const op16x8*)(sB + (wn * TN + j) * 2048 + boff_hi);
+      if (NS >= 3) bl[j] = *(const op16x8*)(sB + (wn * TN + j) * 2048 + boff_lo);
     }
   };
 
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     //        MFMA(t) : the TM x TN x NS MFMAs on the fragments read in the previous phase
     //      so at any time one wave of a SIMD feeds the MFMA pipe while the other one issues memory instructions.
     const int grp = wave >> 2;
-    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    op16x8 ah[TM], al[TM], bh[TN], bl[TN];
     // prologue: k-tiles 0 .. LEAD-1 in flight, k-tile 0 landed for everybody
 #pragma unroll
     for (int q = 0; q < LEAD; ++q) {
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     //      the wave reads k-tile t+1 from LDS into the other set and issues the DMA of k-tile t+2 into the buffer that
     //      tile t occupied (its fragments are already in registers).  One barrier per k-tile; the DMA it waits for was
     //      issued a whole iteration earlier, so neither LDS nor L2 latency sits between two MFMA bursts.
-    bf16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+    op16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
     stage(0);
     advance_tap();
     if (nkt > 1) {
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         stage(buf ^ 1);
         advance_tap();
       }
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      op16x8 ah[TM], al[TM], bh[TN], bl[TN];
       read_frags(buf, ah, al, bh, bl);
       mfma_tile(ah, al, bh, bl);
       wait_vm_and_barrier<0>();   // k-tile it+1 landed (all waves); nobody still reads buffer `buf`
@@ -847,7 +847,7 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   MVD_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "mvd_gemm: bad sizes M=%d N=%d K=%d", d.M, d.N, d.K);
   MVD_CHECK_ARG(d.K % 32 == 0, "mvd_gemm: K=%d must be a multiple of 32 (pad the packed weight)", d.K);
   MVD_CHECK_ARG(d.N % 16 == 0, "mvd_gemm: N=%d must be a multiple of 16 (pad the packed weight)", d.N);
-  MVD_CHECK_ARG(d.prec == MVD_PREC_BF16 || d.prec == MVD_PREC_BF16X3 || d.prec == MVD_PREC_X4, "mvd_gemm: bad prec %d", d.prec);
+  MVD_CHECK_ARG(d.prec == MVD_PREC_X1 || d.prec == MVD_PREC_X3 || d.prec == MVD_PREC_X4, "mvd_gemm: bad prec %d", d.prec);
   MVD_CHECK_ARG(d.A && d.Wp, "mvd_gemm: null operand");
   MVD_CHECK_ARG(((uintptr_t)d.A & 127) == 0 && ((uintptr_t)d.Wp & 127) == 0, "mvd_gemm: operands must be 128-byte aligned");
   if (d.a_mode == MVD_A_CONV3X3) {
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
       }
     }
     u16 hi, lo;
-    split_bf16(v * scale, hi, lo);
+    split_op16(v * scale, hi, lo);
     // [kt][nt][hi image | lo image]; an image is the 16x16x32 MFMA B fragment of the micro-tile as the wave holds it: lane
     // l = (n & 15) + 16 * (k-chunk of 8) owns 16 contiguous bytes -- one fully coalesced 1 KiB access per image
     // (the LDS-DMA source of a granule is contiguous, and the fragment reads from LDS are lane-contiguous: no bank conflicts)

@@ -51,14 +51,14 @@ struct G4Params {
 };
 
 struct Frag {   // one MFMA operand fragment (8 elements) as hi + lo
-  bf16x8 hi, lo;
+  op16x8 hi, lo;
 };
 
 __device__ __forceinline__ Frag make_frag(const float (&v)[8]) {
   Frag f;
-  union { bf16x8 v; u16 e[8]; } H, L;
+  union { op16x8 v; u16 e[8]; } H, L;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) split_bf16(v[j], H.e[j], L.e[j]);
+  for (int j = 0; j < 8; ++j) split_op16(v[j], H.e[j], L.e[j]);
   f.hi = H.v;
   f.lo = L.v;
   return f;
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
   const int foff_lo = fbase + ((4 + g) ^ fsw) * 16;
   auto read_w = [&](const unsigned char* slot, int mt) -> Frag {
     Frag f;
-    f.hi = *(const bf16x8*)(slot + mt * 2048 + foff_hi);
-    f.lo = *(const bf16x8*)(slot + mt * 2048 + foff_lo);
+    f.hi = *(const op16x8*)(slot + mt * 2048 + foff_hi);
+    f.lo = *(const op16x8*)(slot + mt * 2048 + foff_lo);
     return f;
   };
 
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
       {
         union { op4_t v; u16 e[4]; } H, L;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) split_bf16(st[r] / den, H.e[r], L.e[r]);
+        for (int r = 0; r < 4; ++r) split_op16(st[r] / den, H.e[r], L.e[r]);
         ph = H.v;
         pl = L.v;
       }
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
       for (int j = 0; j < 2; ++j) {
         union { op4_t v; u16 e[4]; } H, L;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) split_bf16(qkv[4 + j][r], H.e[r], L.e[r]);
+        for (int r = 0; r < 4; ++r) split_op16(qkv[4 + j][r], H.e[r], L.e[r]);
         ot[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         ot[j] = MVD_MFMA_16x16x16(L.v, pl, ot[j]);
         ot[j] = MVD_MFMA_16x16x16(L.v, ph, ot[j]);

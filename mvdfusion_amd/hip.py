@@ -14,7 +14,7 @@ LIB_PATHS = {"f16": os.path.join(_HERE, "csrc", "libmvd_hip.so"), "bf16": os.pat
 LIB_PATH = LIB_PATHS["f16"]
 OPERAND_FORMAT = os.environ.get("MVD_OPERAND_FORMAT", "f16")   # chosen before the first call, fixed per process
 
-PREC_BF16, PREC_BF16X3, PREC_X4 = 1, 3, 4
+PREC_X1, PREC_X3, PREC_X4 = 1, 3, 4
 A_DENSE, A_CONV3X3 = 0, 1
 EPI_STORE, EPI_GEGLU, EPI_QKV = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_QUICKGELU = 0, 1, 2, 3

@@ -199,7 +199,7 @@ class ViewFusion(nn.Module):
         # flavour and is fixed per process.
         hip.set_operand_format("bf16" if precision.startswith("bf16") else "f16")
         self.precision_name = precision
-        self.precision = {"x3": hip.PREC_BF16X3, "x4": hip.PREC_X4}.get(precision[-2:], hip.PREC_BF16)
+        self.precision = {"x3": hip.PREC_X3, "x4": hip.PREC_X4}.get(precision[-2:], hip.PREC_X1)
 
         def params(cfg):
             return dict(cfg.get("params", cfg)) if hasattr(cfg, "get") else dict(cfg)
