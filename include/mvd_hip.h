@@ -311,6 +311,26 @@ int mvd_event_record(void* ev, mvd_stream_t stream);
 int mvd_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int mvd_event_destroy(void* ev);
 
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the conv / linear / GroupNorm family (training step, reference train.py:90-95 `loss.backward()`; SURVEY.md
+ * section 8(f) rank 4).  The products run on mvd_gemm:  dgrad = mvd_gemm(planes of dY, packed W^T / rotated 3x3 filter);
+ * wgrad = mvd_gemm(A = (dY)^T planes, B = MVD_B_PLANES (X)^T or (im2col X)^T planes) -> the parameter's own memory layout.
+ * These entries produce the transposed operands, the bias gradient and the GroupNorm(+SiLU) backward.  Deterministic. */
+/* x: fp32 (rows, ldx) [src_planes = 0] or split planes (rows, 2*ldx) [1]  ->  out_sp: split planes of x^T, (cols, 2*ldo),
+ * ldo % 32 == 0, ldo >= rows rounded up to 32 (columns [rows, ceil32(rows)) are written as zeros). */
+int mvd_transpose_planes(const void* x, int src_planes, int rows, int cols, int ldx, void* out_sp, int ldo, mvd_stream_t stream);
+/* x_sp: channels-last (B,H,W,Cin) activation in split planes, Cin % 32 == 0  ->  out_sp (9*Cin, 2*ldo): row ci*9 + ky*3 + kx,
+ * column = output pixel of the 3x3 / stride 1 / pad 1 conv (F.unfold order, transposed). */
+int mvd_im2col3x3_t_planes(const void* x_sp, int B, int H, int W, int Cin, void* out_sp, int ldo, mvd_stream_t stream);
+/* out[c] = sum_r x[r][c] (bias gradient): fp64 partials, fixed order.  ws: mvd_col_sum_workspace_doubles(rows, cols) doubles. */
+size_t mvd_col_sum_workspace_doubles(int rows, int cols);
+int mvd_col_sum(const float* x, int rows, int cols, int ldx, float* out, double* ws, size_t ws_doubles, mvd_stream_t stream);
+/* Backward of y = act(GroupNorm(x)) (act = SiLU when silu != 0; torch.nn.GroupNorm semantics, openaimodel.py GroupNorm32):
+ * dy = dL/dy  ->  dx (B,HW,C), dgamma (C), dbeta (C).  ws: B*groups*2 + B*C*2 floats. */
+int mvd_groupnorm_backward(const float* x, const float* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
+                           float eps, int silu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_floats,
+                           mvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

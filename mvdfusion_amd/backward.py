@@ -1,0 +1,131 @@
+"""Backward of the conv / linear / GroupNorm family on the HIP path -- the first slice of the training step
+(reference train.py:90-95 ``loss.backward()``).
+
+Every matrix product runs on the forward's split-operand MFMA GEMM (csrc/gemm.hip):
+
+  dgrad  dX = dY W        mvd_gemm(planes(dY), packed W^T)                        (linear)
+                          mvd_gemm conv mode over planes(dY) with the 180-degree rotated, channel-swapped filter   (3x3 / s1 / p1)
+  wgrad  dW = dY^T X      mvd_gemm(A = planes(dY^T), B = MVD_B_PLANES planes(X^T))       -> (N, K)          nn.Linear.weight layout
+                          ... B = planes(im2col(X)^T), rows ordered ci*9 + tap           -> (Cout, Cin*9)   nn.Conv2d.weight layout
+  bgrad  db = column sums of dY (fp64 partials, fixed order)
+
+plus ``GroupNorm(+SiLU)`` backward (csrc/backward.hip).  Weights change every optimizer step, so the transposed / rotated images
+are packed per call (4 B per parameter, a fraction of the GEMM's own traffic).
+
+What exists: these ops (op-level gradient tests against torch autograd in fp32) and the UNet output head chained on them
+(`unet_head_backward`: MSE -> conv3x3 head -> SiLU -> GroupNorm32), whose parameter gradients are pinned to the REFERENCE's
+``loss.backward()`` (tests/golden/train_grads_*.npz).  What does not exist yet: LayerNorm / attention / GEGLU backward, so the
+gradient stops at the input of the head; ``ViewFusion.forward(...).backward()`` still raises.
+"""
+import torch
+
+from . import hip
+
+
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def transpose_planes(x, rows, cols, src_planes=False, ldx=None):
+    """(rows, cols) matrix -- fp32 tensor, or split planes when `src_planes` -- to the split planes of its transpose:
+    int16 (cols rounded up to 16, 2 * rows rounded up to 32); rows past `cols` stay zero (they are GEMM padding)."""
+    ldo = _pad32(rows)
+    out = torch.zeros(_pad16(cols), 2 * ldo, dtype=torch.int16, device=x.device)
+    if ldx is None:
+        ldx = x.shape[-1] // 2 if src_planes else x.shape[-1]
+    hip.check(hip.lib().mvd_transpose_planes(hip.ptr(x), int(bool(src_planes)), rows, cols, ldx, hip.ptr(out), ldo, hip.stream()))
+    return out
+
+
+def col_sum(x, rows, cols):
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    n = hip.lib().mvd_col_sum_workspace_doubles(rows, cols)
+    ws = torch.empty(n, dtype=torch.float64, device=x.device)
+    hip.check(hip.lib().mvd_col_sum(hip.ptr(x), rows, cols, x.shape[-1], hip.ptr(out), hip.ptr(ws), n, hip.stream()))
+    return out
+
+
+def _planes_padded(x, cols):
+    """fp32 (rows, cols) -> split planes (rows, 2 * ceil32(cols)), padded columns zero."""
+    return hip.split_planes(x.contiguous(), ldp=_pad32(cols))
+
+
+def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True, prec=hip.PREC_X4):
+    """y = x W^T + b  (nn.Linear / 1x1 conv).  x_planes: the forward's A operand, split planes (M, 2*ceil32(K)); weight (N, K) fp32;
+    dy (M, N) fp32.  Returns (dx (M, K) | None, dW (N, K), db (N) | None)."""
+    M, N = dy.shape
+    K = weight.shape[1]
+    dev = dy.device
+    dx = None
+    if need_dx:
+        wt = hip.pack_linear(weight.detach().t().contiguous())                # (K, N): dX = dY W
+        dx_full = torch.empty(M, wt.N, dtype=torch.float32, device=dev)
+        hip.gemm(_planes_padded(dy, N), wt, dx_full, prec=prec, bias=False, workspace=workspace)
+        dx = dx_full[:, :K]
+    # dW = dY^T X : both operands activations, reduction over the M rows
+    a = transpose_planes(dy, M, N)                                            # (ceil16(N), M) planes
+    b = transpose_planes(x_planes, M, K, src_planes=True)                     # (ceil16(K), M) planes
+    dw_full = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=dev)
+    hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M)), dw_full, prec=prec, bias=False, workspace=workspace)
+    dW = dw_full[:N, :K]
+    db = col_sum(dy, M, N) if need_db else None
+    return dx, dW, db
+
+
+def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, need_db=True, prec=hip.PREC_X4):
+    """y = conv3x3(x), stride 1, padding 1, channels-last.  x_planes: the forward's A operand (B*H*W, 2*ceil32(Cin)) split planes;
+    weight (Cout, Cin, 3, 3) fp32; dy (B*H*W, Cout) fp32.  Returns (dx (M, Cin) | None, dW (Cout, Cin, 3, 3), db | None)."""
+    M, Cout = dy.shape
+    Cin = weight.shape[1]
+    cin_p = x_planes.shape[-1] // 2
+    dev = dy.device
+    assert M == B * H * W and cin_p % 32 == 0 and cin_p >= Cin
+    dx = None
+    if need_dx:
+        # dX = conv3x3(dY, W') with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]  (full correlation with the rotated filter)
+        wr = hip.pack_conv3x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous())
+        dx_full = torch.empty(M, wr.N, dtype=torch.float32, device=dev)
+        hip.gemm(_planes_padded(dy, Cout), wr, dx_full, prec=prec, bias=False, workspace=workspace,
+                 conv=dict(B=B, Hin=H, Win=W, Cin=_pad32(Cout), Hout=H, Wout=W, stride=1, upsample=0))
+        dx = dx_full[:, :Cin]
+    a = transpose_planes(dy, M, Cout)                                         # (ceil16(Cout), M)
+    ldo = _pad32(M)
+    cols_t = torch.zeros(9 * cin_p, 2 * ldo, dtype=torch.int16, device=dev)     # (im2col X)^T, rows ci*9 + tap
+    hip.check(hip.lib().mvd_im2col3x3_t_planes(hip.ptr(x_planes), B, H, W, cin_p, hip.ptr(cols_t), ldo, hip.stream()))
+    dw_full = torch.empty(a.shape[0], 9 * cin_p, dtype=torch.float32, device=dev)
+    hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo), dw_full, prec=prec, bias=False, workspace=workspace)
+    dW = dw_full[:Cout, :9 * Cin].reshape(Cout, Cin, 3, 3)
+    db = col_sum(dy, M, Cout) if need_db else None
+    return dx, dW, db
+
+
+def groupnorm_backward(x, dy, gamma, beta, B, HW, C, eps, silu, groups=32):
+    """Backward of y = act(GroupNorm(x)), act = SiLU when `silu`.  x, dy: fp32 (B*HW, C).  Returns (dx, dgamma, dbeta)."""
+    dev = x.device
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=dev)
+    db = torch.empty(C, dtype=torch.float32, device=dev)
+    n = B * groups * 2 + B * C * 2
+    ws = torch.empty(n, dtype=torch.float32, device=dev)
+    hip.check(hip.lib().mvd_groupnorm_backward(hip.ptr(x), hip.ptr(dy.contiguous()), hip.ptr(gamma), hip.ptr(beta), B, HW, C, groups,
+                                               float(eps), int(bool(silu)), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), hip.ptr(ws), n,
+                                               hip.stream()))
+    return dx, dg, db
+
+
+def unet_head_backward(unet, h, a_planes, pred_rows, target_rows, B, S, workspace):
+    """MSE(pred, target) through the UNet output head ``out = [GroupNorm32, SiLU, conv3x3]`` (mvdfusion/unet.py:496-500).
+
+    h: fp32 (B*S*S, mc) input of the head (output of the last output block); a_planes: split planes of SiLU(GN(h)) kept by the
+    forward; pred_rows / target_rows: (B*S*S, Cout) channels-last prediction and target.  Returns ({parameter name: gradient},
+    dh) with the names relative to the UNetModel (``out.0.weight`` ...) and dh = dL/dh, where the backward currently stops."""
+    gn, conv = unet.out[0], unet.out[2]
+    M, Cout = pred_rows.shape
+    dy = (pred_rows - target_rows) * (2.0 / pred_rows.numel())                # d mean((pred - target)^2) / d pred
+    da, dW, db = conv3x3_backward(a_planes, conv.weight, dy.contiguous(), B, S, S, workspace)
+    dh, dg, dbeta = groupnorm_backward(h, da.contiguous(), gn.weight, gn.bias, B, S * S, h.shape[-1], gn.eps, True)
+    return {"out.2.weight": dW, "out.2.bias": db, "out.0.weight": dg, "out.0.bias": dbeta}, dh

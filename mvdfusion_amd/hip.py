@@ -65,6 +65,11 @@ SIGNATURES = {
     "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_unet_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "mvd_transpose_planes": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mvd_im2col3x3_t_planes": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mvd_col_sum_workspace_doubles": (_sz, [_i, _i]),
+    "mvd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "mvd_groupnorm_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mvd_groupnorm_from_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_fill_zero": (_i, [_vp, _sz, _vp]),
@@ -143,7 +148,7 @@ def _req(t, dtype=torch.float32):
 # weights
 # ---------------------------------------------------------------------------------------------
 class PackedWeight:
-    """A weight in the MFMA operand image (split bf16, [K/32][N/16][hi,lo][16][32]) plus its fp32 bias."""
+    """A weight in the MFMA operand image ([K/32][N/16][hi image | lo image], include/mvd_hip.h) plus its fp32 bias."""
 
     __slots__ = ("data", "N", "K", "n_real", "bias", "geglu", "conv_cin", "acc_scale")
 

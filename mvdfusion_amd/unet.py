@@ -210,6 +210,7 @@ class UNetModel(nn.Module):
         self._head = None
         self._temb = None
         self._xattn = None
+        self._head_saved = None
 
     # ------------------------------------------------------------------ reference API (unet.py:558-576)
     def get_cross_attn_parameters(self, finetune_cross_attn, finetune_view_attn):
@@ -309,6 +310,7 @@ class UNetModel(nn.Module):
         y = ctx.ws.get("head", (M, 8))
         ctx.gemm(a, self._head, y, conv=dict(B=B, Hin=H, Win=W, Cin=self.model_channels, Hout=H, Wout=W, stride=1,
                                              upsample=0), ldo=8)
+        self._head_saved = (h, a)          # input of the head and planes of SiLU(GN(h)): what backward.unet_head_backward needs
         return y
 
 

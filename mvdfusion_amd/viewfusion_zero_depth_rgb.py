@@ -382,7 +382,7 @@ class ViewFusion(nn.Module):
         return res
 
     @torch.no_grad()
-    def p_losses(self, batch, trainer_config, noise_source=None):
+    def p_losses(self, batch, trainer_config, noise_source=None, _aux=None):
         """viewfusion_zero_depth_rgb.py:362-392 -- the training objective's FORWARD pass on the HIP path: prepare_batch, shared
         random timestep, q_sample, apply_model (cfg 1, condition dropout when self.training), MSE against the noise.
         The value is a plain tensor: there are no backward kernels yet, so it serves validation /
@@ -412,7 +412,29 @@ class ViewFusion(nn.Module):
         else:
             raise AssertionError(f"objective {self.objective} not implemented")
         assert self.loss_type == "l2", "loss_type 'l2' is the only one the reference implements (:86-87)"
-        return torch.nn.functional.mse_loss(target, pred).mean()
+        loss = torch.nn.functional.mse_loss(target, pred).mean()
+        if _aux is not None:
+            _aux.update(pred=pred, target=target)
+        return loss
+
+    @torch.no_grad()
+    def head_gradients(self, batch, trainer_config, noise_source=None):
+        """First slice of train.py:90-95 (`loss.backward()`) on the HIP path: the training forward (p_losses) followed by the
+        backward of MSE -> UNet output head (conv3x3 <- SiLU <- GroupNorm32) with the backward kernels of mvdfusion_amd/backward.py.
+        Returns (loss, {state_dict key: gradient} for the four head parameters, dL/dh at the head's input (V, mc, S, S) -- where the
+        backward currently stops: LayerNorm / attention / GEGLU backward do not exist yet)."""
+        from . import backward
+        aux = {}
+        loss = self.p_losses(batch, trainer_config, noise_source=noise_source, _aux=aux)
+        unet = self.unet_model.unet_model
+        pred, target = aux["pred"], aux["target"]
+        V, C, S, _ = pred.shape
+        h, a = unet._head_saved
+        rows = lambda t: t.permute(0, 2, 3, 1).reshape(V * S * S, C).contiguous()
+        eng = self.engine(V, S, self.view_attn.n_pts_per_ray, False)
+        grads, dh = backward.unet_head_backward(unet, h, a, rows(pred), rows(target), V, S, eng.ctx.gemm_ws)
+        grads = {"unet_model.unet_model." + k: v for k, v in grads.items()}
+        return loss, grads, dh.view(V, S, S, -1).permute(0, 3, 1, 2).contiguous()
 
     def forward(self, batch, trainer_config):
         """viewfusion_zero_depth_rgb.py:394-397.  Forward value only -- see p_losses; .backward() on it raises."""

@@ -496,7 +496,7 @@ def gold_prepare_batch(tag, random_views, with_depths, seed):
     save(tag, seed=np.int64(seed), batch_latents=bl, input_latents=il, clip_v_embed=cv, bc_R=bc.R, bc_T=bc.T,
          bc_f=bc.focal_length, bc_p=bc.principal_point, ic_R=ic.R, ic_T=ic.T, ic_f=ic.focal_length, ic_p=ic.principal_point)
 
-def gold_train_loss(model_channels, V, D, tag, seed, S_img=256):
+def gold_train_loss(model_channels, V, D, tag, seed, S_img=256, grads_tag=None):
     """The REAL ViewFusion.forward / p_losses (viewfusion_zero_depth_rgb.py:362-397) -- prepare_batch (reference VAE ch=32,
     stub CLIP), shared random timestep, q_sample, GridAttn + UNetWrapper.forward(is_train=True) WITH the condition dropout
     of unet.py:109-151, MSE -- on a seeded 16-view GSO batch.  The seed is chosen so that the dropout masks are not all-keep.
@@ -577,6 +577,26 @@ def gold_train_loss(model_channels, V, D, tag, seed, S_img=256):
         return out
 
     Facade.apply_model = spy
+    if grads_tag is not None:
+        # the same call with autograd on: loss.backward() as train.py:90-95 does.  Stored: the gradients of the UNet output head
+        # (GroupNorm32 affine + conv3x3), the gradient that reaches the head's input (strided), and the L2 norm of EVERY
+        # parameter gradient (later backward slices pin against those).
+        head = m.unet_model.unet_model.out
+        grabbed = {}
+        head.register_full_backward_hook(lambda mod, gin, gout: grabbed.__setitem__("dh", gin[0].detach().clone()))
+        torch.manual_seed(draw_seed)
+        loss_g = m(batch, cfg)
+        loss_g.backward()
+        named = [(n, p) for n, p in m.named_parameters() if p.grad is not None]
+        hp = "unet_model.unet_model.out."
+        g = {n: p.grad.detach().clone() for n, p in named if n.startswith(hp)}
+        dh = grabbed["dh"]                                     # (V, mc, S, S)
+        save(grads_tag, loss=loss_g.detach(), out0_weight=g[hp + "0.weight"], out0_bias=g[hp + "0.bias"], out2_weight=g[hp + "2.weight"],
+             out2_bias=g[hp + "2.bias"], dh_strided=dh[:, :, ::3, ::5].contiguous(), dh_norm=dh.norm(),
+             grad_names=np.array([n for n, _ in named]), grad_norms=np.array([float(p.grad.norm()) for _, p in named], dtype=np.float64),
+             batch_seed=np.int64(seed), draw_seed=np.int64(draw_seed), t=t_draw, drop_rand=drop_rand)
+        print(f"  train grads: loss {float(loss_g):.6f}, |dh| {float(dh.norm()):.4e}, {len(named)} parameter gradients")
+        m.zero_grad(set_to_none=True)
     torch.manual_seed(draw_seed)
     t0 = time.time()
     with torch.no_grad():
@@ -674,7 +694,7 @@ ALL = {
     "ckpt_remap": gold_ckpt_remap,
     "clip_tiny": lambda: gold_clip("tiny-test", "clip_tiny"),
     "clip_l14": lambda: gold_clip("ViT-L/14", "clip_vit_l14"),
-    "train32_d3": lambda: gold_train_loss(32, 4, 3, "train_loss_mc32_v4_d3", seed=31),
+    "train32_d3": lambda: gold_train_loss(32, 4, 3, "train_loss_mc32_v4_d3", seed=31, grads_tag="train_grads_mc32_v4_d3"),
     "traj32": lambda: gold_trajectory(32, 4, 1, "traj_mc32_v4_d1", steps=5),
     "traj320": lambda: gold_trajectory(320, 4, 1, "traj_mc320_v4_d1_50steps", steps=50),
     "traj320_f64": lambda: gold_trajectory_f64(320, 4, 1, "traj_mc320_v4_d1_50steps_f64", steps=50),

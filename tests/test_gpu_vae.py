@@ -175,16 +175,11 @@ def test_sample_then_decode_end_to_end():
     assert bool(torch.isfinite(img).all())
 
 
-def test_training_forward_loss_vs_reference_golden():
-    """ViewFusion.forward / p_losses (viewfusion_zero_depth_rgb.py:362-397) on the HIP path against the REAL reference's loss:
-    prepare_batch (HIP VAE encode, stub CLIP), shared timestep, q_sample, GridAttn with D = 3 depth samples, the UNet's training
-    call WITH per-view condition dropout (unet.py:109-151: view 2 of this draw drops its concat latents), MSE.  The random
-    draws are replayed in the reference's order from the fixture's seed (oracle/make_golden.py: train32_d3).  Forward value
-    only: the product has no backward kernels yet."""
+def _training_setup(gd):
+    """The model / batch / random draws of the reference's training fixtures (oracle/make_golden.py: train32_d3)."""
     from conftest import model_config
     from mvdfusion_amd import synthetic as syn
     from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
-    gd = load_golden("train_loss_mc32_v4_d3")
     V, D, S = 4, 3, 32
     dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
               num_res_blocks=2, attn_resolutions=[], dropout=0.0)
@@ -211,6 +206,17 @@ def test_training_forward_loss_vs_reference_golden():
         assert torch.equal(dr, gd["drop_rand"]) and int(t[0]) == int(gd["t"][0])
         return dict(t=t, noise=noise, depth_noise=dn, drop_rand=dr)
 
+    return m, batch, tc, draws
+
+
+def test_training_forward_loss_vs_reference_golden():
+    """ViewFusion.forward / p_losses (viewfusion_zero_depth_rgb.py:362-397) on the HIP path against the REAL reference's loss:
+    prepare_batch (HIP VAE encode, stub CLIP), shared timestep, q_sample, GridAttn with D = 3 depth samples, the UNet's training
+    call WITH per-view condition dropout (unet.py:109-151: view 2 of this draw drops its concat latents), MSE.  The random
+    draws are replayed in the reference's order from the fixture's seed (oracle/make_golden.py: train32_d3)."""
+    gd = load_golden("train_loss_mc32_v4_d3")
+    m, batch, tc, draws = _training_setup(gd)
+
     pred_box = {}
     real_apply = m.apply_model
 
@@ -229,6 +235,25 @@ def test_training_forward_loss_vs_reference_golden():
     m.eval()
     loss_eval = m.p_losses(batch, tc, noise_source=draws)
     assert abs(float(loss_eval) - float(loss)) > 1e-6 and not loss.requires_grad
+
+
+def test_training_head_gradients_vs_reference_golden():
+    """First slice of `loss.backward()` (train.py:90-95) on the HIP path: MSE -> conv3x3 head -> SiLU -> GroupNorm32 with the
+    backward kernels (dgrad / wgrad on the split-operand MFMA GEMM, bias column sums, GroupNorm+SiLU backward), against the
+    gradients the REAL reference's autograd produced for the same batch and draws (oracle/make_golden.py: train32_d3 ->
+    train_grads_mc32_v4_d3): the four head parameters and the gradient that reaches the head's input."""
+    gd = load_golden("train_grads_mc32_v4_d3")
+    m, batch, tc, draws = _training_setup(gd)
+    loss, grads, dh = m.head_gradients(batch, tc, noise_source=draws)
+    assert abs(float(loss) - float(gd["loss"])) / float(gd["loss"]) < 1e-4
+    pre = "unet_model.unet_model.out."
+    for key, gk in ((pre + "2.weight", "out2_weight"), (pre + "2.bias", "out2_bias"), (pre + "0.weight", "out0_weight"),
+                    (pre + "0.bias", "out0_bias")):
+        e = rel_err(grads[key].cpu(), gd[gk])
+        print(f"grad {key}: rel err {e:.2e}")
+        assert grads[key].shape == gd[gk].shape and e < 5e-4, (key, e)
+    assert rel_err(dh.cpu()[:, :, ::3, ::5], gd["dh_strided"]) < 5e-4
+    assert abs(float(dh.norm()) - float(gd["dh_norm"])) / float(gd["dh_norm"]) < 5e-4
 
 
 @pytest.mark.parametrize("name,model", [("clip_tiny", "tiny-test"), ("clip_vit_l14", "ViT-L/14")])
