@@ -331,6 +331,20 @@ int mvd_groupnorm_backward(const float* x, const float* dy, const float* gamma, 
                            float eps, int silu, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_floats,
                            mvd_stream_t stream);
 
+/* Backward of y = LayerNorm(x) * w + b (last dimension, w may be null): dx, and dyxhat = dy * xhat so that
+ * dw = mvd_col_sum(dyxhat), db = mvd_col_sum(dy).  dyxhat may be null. */
+int mvd_layernorm_backward(const float* x, const float* dy, const float* w, int rows, int C, float eps, float* dx, float* dyxhat,
+                           mvd_stream_t stream);
+/* Backward of GEGLU y = a * gelu(g), [a | g] = h (rows, 2*half) (sd1 attention.py:43-44): dh (rows, 2*half). */
+int mvd_geglu_backward(const float* h, const float* dy, int rows, int half, float* dh, mvd_stream_t stream);
+/* Backward of the self-attention core softmax(Q K^T / sqrt(d)) V per (batch, head); q, k, v, dout, dq, dk, dv: token-major
+ * (B*L, heads*dhead) fp32.  stats: B*heads*L*3 floats of scratch.  fp32 VALU (training path), deterministic. */
+int mvd_attention_backward(const float* q, const float* k, const float* v, const float* dout, int B, int heads, int L, int dhead,
+                           float* dq, float* dk, float* dv, float* stats, size_t stats_floats, mvd_stream_t stream);
+/* Backward of mvd_pixel_cross_attn (D context tokens per pixel): q, dout, dq (P, C); k, v, dk, dv (P*D, C). */
+int mvd_pixel_cross_attn_backward(const float* q, const float* k, const float* v, const float* dout, int P, int D, int heads, int dhead,
+                                  float* dq, float* dk, float* dv, mvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

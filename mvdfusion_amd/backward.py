@@ -12,10 +12,12 @@ Every matrix product runs on the forward's split-operand MFMA GEMM (csrc/gemm.hi
 plus ``GroupNorm(+SiLU)`` backward (csrc/backward.hip).  Weights change every optimizer step, so the transposed / rotated images
 are packed per call (4 B per parameter, a fraction of the GEMM's own traffic).
 
-What exists: these ops (op-level gradient tests against torch autograd in fp32) and the UNet output head chained on them
-(`unet_head_backward`: MSE -> conv3x3 head -> SiLU -> GroupNorm32), whose parameter gradients are pinned to the REFERENCE's
-``loss.backward()`` (tests/golden/train_grads_*.npz).  What does not exist yet: LayerNorm / attention / GEGLU backward, so the
-gradient stops at the input of the head; ``ViewFusion.forward(...).backward()`` still raises.
+What exists: these ops plus LayerNorm / GEGLU / self-attention / per-pixel cross-attention backward (op-level gradient tests against
+torch autograd in fp32), the UNet output head chained on them (`unet_head_backward`: MSE -> conv3x3 head -> SiLU -> GroupNorm32) and
+the block-level backwards of mvdfusion_amd/backward_blocks.py (ResBlock, SpatialTransformer, ViewAlignedFeatureTransformer), whose
+parameter gradients are pinned to the REFERENCE's ``loss.backward()`` (tests/golden/train_grads_*.npz: the head and all of
+`output_blocks.11`).  What does not exist yet: the strided / upsampling conv backward, the GridAttn backward and the walk over the
+whole UNet with an optimizer, so ``ViewFusion.forward(...).backward()`` still raises.
 """
 import torch
 
@@ -49,6 +51,17 @@ def col_sum(x, rows, cols):
     return out
 
 
+def _pow2_scale(t):
+    """Power of two that brings max|t| to [1024, 2048).  Gradients are small (1e-4 ... 1e-8): below 6e-5 the fp16 hi + lo operand
+    split only has an ABSOLUTE resolution of 2^-25 (include/mvd_hip.h, operand range contract), so they are scaled into the
+    normal range before the split and the GEMM undoes it exactly through its accumulator scale (as the packed weights do)."""
+    import math
+    mx = float(t.abs().max())
+    if not (mx > 0.0) or not math.isfinite(mx):
+        return 1.0
+    return 2.0 ** (10 - math.floor(math.log2(mx)))
+
+
 def _planes_padded(x, cols):
     """fp32 (rows, cols) -> split planes (rows, 2 * ceil32(cols)), padded columns zero."""
     return hip.split_planes(x.contiguous(), ldp=_pad32(cols))
@@ -60,17 +73,20 @@ def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True,
     M, N = dy.shape
     K = weight.shape[1]
     dev = dy.device
+    sc = _pow2_scale(dy)
+    dys = dy * sc                                                             # exact (power of two)
     dx = None
     if need_dx:
         wt = hip.pack_linear(weight.detach().t().contiguous())                # (K, N): dX = dY W
+        wt.acc_scale /= sc
         dx_full = torch.empty(M, wt.N, dtype=torch.float32, device=dev)
-        hip.gemm(_planes_padded(dy, N), wt, dx_full, prec=prec, bias=False, workspace=workspace)
+        hip.gemm(_planes_padded(dys, N), wt, dx_full, prec=prec, bias=False, workspace=workspace)
         dx = dx_full[:, :K]
     # dW = dY^T X : both operands activations, reduction over the M rows
-    a = transpose_planes(dy, M, N)                                            # (ceil16(N), M) planes
+    a = transpose_planes(dys, M, N)                                           # (ceil16(N), M) planes
     b = transpose_planes(x_planes, M, K, src_planes=True)                     # (ceil16(K), M) planes
     dw_full = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=dev)
-    hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M)), dw_full, prec=prec, bias=False, workspace=workspace)
+    hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M), acc_scale=1.0 / sc), dw_full, prec=prec, bias=False, workspace=workspace)
     dW = dw_full[:N, :K]
     db = col_sum(dy, M, N) if need_db else None
     return dx, dW, db
@@ -84,20 +100,23 @@ def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, nee
     cin_p = x_planes.shape[-1] // 2
     dev = dy.device
     assert M == B * H * W and cin_p % 32 == 0 and cin_p >= Cin
+    sc = _pow2_scale(dy)
+    dys = dy * sc
     dx = None
     if need_dx:
         # dX = conv3x3(dY, W') with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]  (full correlation with the rotated filter)
         wr = hip.pack_conv3x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous())
+        wr.acc_scale /= sc
         dx_full = torch.empty(M, wr.N, dtype=torch.float32, device=dev)
-        hip.gemm(_planes_padded(dy, Cout), wr, dx_full, prec=prec, bias=False, workspace=workspace,
+        hip.gemm(_planes_padded(dys, Cout), wr, dx_full, prec=prec, bias=False, workspace=workspace,
                  conv=dict(B=B, Hin=H, Win=W, Cin=_pad32(Cout), Hout=H, Wout=W, stride=1, upsample=0))
         dx = dx_full[:, :Cin]
-    a = transpose_planes(dy, M, Cout)                                         # (ceil16(Cout), M)
+    a = transpose_planes(dys, M, Cout)                                        # (ceil16(Cout), M)
     ldo = _pad32(M)
     cols_t = torch.zeros(9 * cin_p, 2 * ldo, dtype=torch.int16, device=dev)     # (im2col X)^T, rows ci*9 + tap
     hip.check(hip.lib().mvd_im2col3x3_t_planes(hip.ptr(x_planes), B, H, W, cin_p, hip.ptr(cols_t), ldo, hip.stream()))
     dw_full = torch.empty(a.shape[0], 9 * cin_p, dtype=torch.float32, device=dev)
-    hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo), dw_full, prec=prec, bias=False, workspace=workspace)
+    hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo, acc_scale=1.0 / sc), dw_full, prec=prec, bias=False, workspace=workspace)
     dW = dw_full[:Cout, :9 * Cin].reshape(Cout, Cin, 3, 3)
     db = col_sum(dy, M, Cout) if need_db else None
     return dx, dW, db
@@ -115,6 +134,44 @@ def groupnorm_backward(x, dy, gamma, beta, B, HW, C, eps, silu, groups=32):
                                                float(eps), int(bool(silu)), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), hip.ptr(ws), n,
                                                hip.stream()))
     return dx, dg, db
+
+
+def layernorm_backward(x, dy, weight, eps):
+    """Backward of y = LayerNorm(x) * weight + bias over the last dimension.  x, dy: fp32 (rows, C).  Returns (dx, dweight, dbias)."""
+    rows, C = x.shape
+    dx, t = torch.empty_like(x), torch.empty_like(x)
+    dy = dy.contiguous()
+    hip.check(hip.lib().mvd_layernorm_backward(hip.ptr(x), hip.ptr(dy), hip.ptr(weight), rows, C, float(eps), hip.ptr(dx), hip.ptr(t),
+                                               hip.stream()))
+    return dx, col_sum(t, rows, C), col_sum(dy, rows, C)
+
+
+def geglu_backward(h, dy):
+    """Backward of GEGLU y = a * gelu(g), [a | g] = h (rows, 2*half): dh (rows, 2*half)."""
+    rows, half = dy.shape
+    assert h.shape == (rows, 2 * half)
+    dh = torch.empty_like(h)
+    hip.check(hip.lib().mvd_geglu_backward(hip.ptr(h), hip.ptr(dy.contiguous()), rows, half, hip.ptr(dh), hip.stream()))
+    return dh
+
+
+def attention_backward(q, k, v, dout, B, heads, L, dhead):
+    """Backward of softmax(Q K^T / sqrt(d)) V per (batch, head); all tensors token-major fp32 (B*L, heads*dhead).
+    Returns (dq, dk, dv)."""
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    n = B * heads * L * 3
+    stats = torch.empty(n, dtype=torch.float32, device=q.device)
+    hip.check(hip.lib().mvd_attention_backward(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(dout.contiguous()), B, heads, L, dhead,
+                                               hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(stats), n, hip.stream()))
+    return dq, dk, dv
+
+
+def pixel_cross_attn_backward(q, k, v, dout, P, D, heads, dhead):
+    """Backward of the per-pixel cross attention over D context tokens (mvd_pixel_cross_attn): q, dout (P, C); k, v (P*D, C)."""
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    hip.check(hip.lib().mvd_pixel_cross_attn_backward(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(dout.contiguous()), P, D, heads, dhead,
+                                                      hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.stream()))
+    return dq, dk, dv
 
 
 def unet_head_backward(unet, h, a_planes, pred_rows, target_rows, B, S, workspace):

@@ -231,6 +231,249 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
   dbeta[c] = (float)be;
 }
 
+// ---------------------------------------------------------------------------------------------- LayerNorm backward
+// y = xhat * w + b over the last dimension (eps inside the sqrt), one wave per row (C <= 1280):
+//   dx = rstd * (dz - mean(dz) - xhat * mean(dz * xhat)), dz = dy * w;  t = dy * xhat is written out so that dw = column sums of t and
+//   db = column sums of dy come from mvd_col_sum (fixed order).
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                                                     int rows, int C, float eps, float* __restrict__ dx, float* __restrict__ t) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * C;
+  const float* dr = dy + (size_t)row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float a = xr[c] - mean;
+    q += a * a;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  float m1 = 0.f, m2 = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float xh = (xr[c] - mean) * rstd;
+    const float dz = dr[c] * (w ? w[c] : 1.f);
+    m1 += dz;
+    m2 += dz * xh;
+  }
+  m1 = wave_sum(m1) / (float)C;
+  m2 = wave_sum(m2) / (float)C;
+  for (int c = lane; c < C; c += 64) {
+    const float xh = (xr[c] - mean) * rstd;
+    const float dz = dr[c] * (w ? w[c] : 1.f);
+    dx[(size_t)row * C + c] = rstd * (dz - m1 - xh * m2);
+    if (t) t[(size_t)row * C + c] = dr[c] * xh;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- GEGLU backward
+// y = a * gelu(g) with [a | g] = h (rows, 2 * half) (attention.py:43-44, exact erf GELU):  dh = [dy * gelu(g) | dy * a * gelu'(g)],
+// gelu'(g) = Phi(g) + g * phi(g).
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dy, int rows, int half,
+                                                        float* __restrict__ dh) {
+  const size_t total = (size_t)rows * half;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t r = e / half;
+    const int c = (int)(e - r * half);
+    const float a = h[r * 2 * half + c], g = h[r * 2 * half + half + c], d = dy[e];
+    const float cdf = 0.5f * (1.0f + erf_nobranch(g * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * g * g);
+    dh[r * 2 * half + c] = d * (g * cdf);
+    dh[r * 2 * half + half + c] = d * a * (cdf + g * pdf);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- self-attention backward (fp32 VALU)
+// CrossAttention(context=None) core (attention.py:170-193): per (batch, head), O = softmax(Q K^T * scale) V over L tokens of width d.
+// q, k, v, o-grad are token-major (B*L, heads*d) fp32 as the forward's projections produce them.  Two kernels, both deterministic:
+//   attn_bwd_stats : per query row  m = max_j s_ij, l = sum_j exp(s_ij - m), delta = sum_d dO_id O_id   (O recomputed on the fly)
+//   attn_bwd_dq    : dQ_i = scale * sum_j P_ij (dP_ij - delta_i) K_j               (one wave per query row, lanes over keys)
+//   attn_bwd_dkv   : dK_j = scale * sum_i P_ij (dP_ij - delta_i) Q_i,  dV_j = sum_i P_ij dO_i   (one wave per key row, lanes over queries)
+// with P_ij = exp(s_ij - m_i) / l_i and dP_ij = dO_i . V_j.  Work 5 x 2 L^2 d per head on the VALU: a training-path kernel, not a
+// roofline one (the MFMA version follows the forward's attn_kernel tiling).
+constexpr int AB_MAXD = 160;
+__device__ __forceinline__ float dot_row(const float* __restrict__ a, const float* __restrict__ b, int d) {
+  float s = 0.f;
+  for (int e = 0; e < d; e += 4) {
+    const float4 x = *(const float4*)(a + e), y = *(const float4*)(b + e);
+    s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+  }
+  return s;
+}
+
+// grid (L / 4... rows, heads, B); one wave per query row: lanes stride over keys.  stats: (B, heads, L, 3) = m, l, delta
+__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, const float* __restrict__ dout, int L, int H, int d,
+                                                             float scale, float* __restrict__ stats) {
+  __shared__ float sq[4][AB_MAXD], sd[4][AB_MAXD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w, hd = blockIdx.y, b = blockIdx.z;
+  const int C = H * d;
+  if (i >= L) return;
+  const size_t rowi = ((size_t)b * L + i) * C + hd * d;
+  for (int e = lane; e < d; e += 64) {
+    sq[w][e] = q[rowi + e];
+    sd[w][e] = dout[rowi + e];
+  }
+  // (wave-private LDS rows: in-order within the wave)
+  float m = -INFINITY;
+  for (int j = lane; j < L; j += 64) m = fmaxf(m, dot_row(sq[w], k + ((size_t)b * L + j) * C + hd * d, d) * scale);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float l = 0.f, dl = 0.f;
+  for (int j = lane; j < L; j += 64) {
+    const size_t rowj = ((size_t)b * L + j) * C + hd * d;
+    const float p = __expf(dot_row(sq[w], k + rowj, d) * scale - m);
+    l += p;
+    dl += p * dot_row(sd[w], v + rowj, d);        // sum_j p_ij dP_ij = l * (dO_i . O_i)
+  }
+  l = wave_sum(l);
+  dl = wave_sum(dl);
+  if (lane == 0) {
+    float* st = stats + (((size_t)b * H + hd) * L + i) * 3;
+    st[0] = m;
+    st[1] = l;
+    st[2] = dl / l;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const float* __restrict__ dout,
+                                                          const float* __restrict__ stats, int L, int H, int d, float scale,
+                                                          float* __restrict__ dq) {
+  __shared__ float sq[4][AB_MAXD], sd[4][AB_MAXD], acc[4][AB_MAXD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w, hd = blockIdx.y, b = blockIdx.z;
+  const int C = H * d;
+  if (i >= L) return;
+  const size_t rowi = ((size_t)b * L + i) * C + hd * d;
+  for (int e = lane; e < d; e += 64) {
+    sq[w][e] = q[rowi + e];
+    sd[w][e] = dout[rowi + e];
+  }
+  const float* st = stats + (((size_t)b * H + hd) * L + i) * 3;
+  const float m = st[0], inv_l = 1.0f / st[1], delta = st[2];
+  // every lane accumulates its keys' contributions for all d in registers (d <= 160: 160 floats would spill; go by chunks of 32)
+  for (int e0 = 0; e0 < d; e0 += 32) {
+    float a[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) a[e] = 0.f;
+    for (int j = lane; j < L; j += 64) {
+      const size_t rowj = ((size_t)b * L + j) * C + hd * d;
+      const float p = __expf(dot_row(sq[w], k + rowj, d) * scale - m) * inv_l;
+      const float ds = p * (dot_row(sd[w], v + rowj, d) - delta) * scale;
+#pragma unroll
+      for (int e = 0; e < 32; ++e)
+        if (e0 + e < d) a[e] += ds * k[rowj + e0 + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const float t = wave_sum(a[e]);
+      if (lane == 0 && e0 + e < d) acc[w][e0 + e] = t;
+    }
+  }
+  for (int e = lane; e < d; e += 64) dq[rowi + e] = acc[w][e];
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const float* __restrict__ dout,
+                                                           const float* __restrict__ stats, int L, int H, int d, float scale,
+                                                           float* __restrict__ dk, float* __restrict__ dv) {
+  __shared__ float sk[4][AB_MAXD], sv[4][AB_MAXD], ak[4][AB_MAXD], av[4][AB_MAXD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + w, hd = blockIdx.y, b = blockIdx.z;
+  const int C = H * d;
+  if (j >= L) return;
+  const size_t rowj = ((size_t)b * L + j) * C + hd * d;
+  for (int e = lane; e < d; e += 64) {
+    sk[w][e] = k[rowj + e];
+    sv[w][e] = v[rowj + e];
+  }
+  for (int e0 = 0; e0 < d; e0 += 32) {
+    float a[32], c[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) a[e] = c[e] = 0.f;
+    for (int i = lane; i < L; i += 64) {
+      const size_t rowi = ((size_t)b * L + i) * C + hd * d;
+      const float* st = stats + (((size_t)b * H + hd) * L + i) * 3;
+      const float p = __expf(dot_row(sk[w], q + rowi, d) * scale - st[0]) / st[1];
+      const float ds = p * (dot_row(sv[w], dout + rowi, d) - st[2]) * scale;
+#pragma unroll
+      for (int e = 0; e < 32; ++e)
+        if (e0 + e < d) {
+          a[e] += ds * q[rowi + e0 + e];
+          c[e] += p * dout[rowi + e0 + e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const float t1 = wave_sum(a[e]), t2 = wave_sum(c[e]);
+      if (lane == 0 && e0 + e < d) {
+        ak[w][e0 + e] = t1;
+        av[w][e0 + e] = t2;
+      }
+    }
+  }
+  for (int e = lane; e < d; e += 64) {
+    dk[rowj + e] = ak[w][e];
+    dv[rowj + e] = av[w][e];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- per-pixel cross-attention backward
+// DualAttnetionBlock.attn2 with D context tokens per pixel (mvdfusion/attention.py:52-62; forward: pixel_xattn_kernel): one wave per
+// (pixel, head).  q (P, C), k / v (P*D, C), dout (P, C) -> dq (P, C), dk / dv (P*D, C).  D <= 8.
+__global__ __launch_bounds__(256) void pixel_xattn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, const float* __restrict__ dout, int P, int D,
+                                                              int heads, int dhead, float* __restrict__ dq, float* __restrict__ dk,
+                                                              float* __restrict__ dv) {
+  const int lane = threadIdx.x & 63;
+  const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (size_t)P * heads) return;
+  const size_t pix = item / heads;
+  const int h = (int)(item - pix * heads);
+  const int C = heads * dhead;
+  const float scale = rsqrtf((float)dhead);
+  const float* qr = q + pix * C + h * dhead;
+  const float* dor = dout + pix * C + h * dhead;
+  float sc[8], dp[8];
+  float mx = -INFINITY;
+  for (int j = 0; j < D; ++j) {
+    const float* kr = k + (pix * D + j) * C + h * dhead;
+    const float* vr = v + (pix * D + j) * C + h * dhead;
+    float a = 0.f, c = 0.f;
+    for (int e = lane; e < dhead; e += 64) {
+      a += qr[e] * kr[e];
+      c += dor[e] * vr[e];
+    }
+    sc[j] = wave_sum(a) * scale;
+    dp[j] = wave_sum(c);
+    mx = fmaxf(mx, sc[j]);
+  }
+  float den = 0.f;
+  for (int j = 0; j < D; ++j) {
+    sc[j] = expf(sc[j] - mx);
+    den += sc[j];
+  }
+  float delta = 0.f;
+  for (int j = 0; j < D; ++j) {
+    sc[j] /= den;
+    delta += sc[j] * dp[j];
+  }
+  for (int e = lane; e < dhead; e += 64) {
+    float gq = 0.f;
+    for (int j = 0; j < D; ++j) {
+      const size_t rj = (pix * D + j) * C + h * dhead + e;
+      const float ds = sc[j] * (dp[j] - delta) * scale;
+      gq += ds * k[rj];
+      dk[rj] = ds * qr[e];
+      dv[rj] = sc[j] * dor[e];
+    }
+    dq[pix * C + h * dhead + e] = gq;
+  }
+}
+
 }  // namespace
 
 extern "C" int mvd_transpose_planes(const void* x, int src_planes, int rows, int cols, int ldx, void* out_sp, int ldo,
@@ -295,5 +538,51 @@ extern "C" int mvd_groupnorm_backward(const float* x, const float* dy, const flo
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks, B), dim3(256), 0, s, x, dy, gamma, beta, mom, sums, HW, C, groups, chunks, silu, dx);
   hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, B, C, dgamma, dbeta);
   MVD_CHECK_LAUNCH("mvd_groupnorm_backward");
+  return 0;
+}
+
+extern "C" int mvd_layernorm_backward(const float* x, const float* dy, const float* w, int rows, int C, float eps, float* dx, float* dyxhat,
+                                      mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && dy && dx && rows > 0 && C > 0, "mvd_layernorm_backward: bad arguments");
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dy, w, rows, C, eps, dx, dyxhat);
+  MVD_CHECK_LAUNCH("mvd_layernorm_backward");
+  return 0;
+}
+
+extern "C" int mvd_geglu_backward(const float* h, const float* dy, int rows, int half, float* dh, mvd_stream_t stream) {
+  MVD_CHECK_ARG(h && dy && dh && rows > 0 && half > 0, "mvd_geglu_backward: bad arguments");
+  const size_t total = (size_t)rows * half;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h, dy, rows, half, dh);
+  MVD_CHECK_LAUNCH("mvd_geglu_backward");
+  return 0;
+}
+
+extern "C" int mvd_attention_backward(const float* q, const float* k, const float* v, const float* dout, int B, int heads, int L, int dhead,
+                                      float* dq, float* dk, float* dv, float* stats, size_t stats_floats, mvd_stream_t stream) {
+  MVD_CHECK_ARG(q && k && v && dout && dq && dk && dv && stats, "mvd_attention_backward: null pointer");
+  MVD_CHECK_ARG(B > 0 && heads > 0 && L > 0 && dhead > 0 && dhead % 4 == 0 && dhead <= AB_MAXD,
+                "mvd_attention_backward: dhead=%d must be a multiple of 4 and <= %d", dhead, AB_MAXD);
+  MVD_CHECK_ARG(stats_floats >= (size_t)B * heads * L * 3, "mvd_attention_backward: stats workspace too small");
+  MVD_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) & 15) == 0, "mvd_attention_backward: 16-byte alignment");
+  const float scale = 1.0f / sqrtf((float)dhead);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((L + 3) / 4, heads, B);
+  hipLaunchKernelGGL(attn_bwd_stats_kernel, grid, dim3(256), 0, s, q, k, v, dout, L, heads, dhead, scale, stats);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, q, k, v, dout, stats, L, heads, dhead, scale, dq);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, q, k, v, dout, stats, L, heads, dhead, scale, dk, dv);
+  MVD_CHECK_LAUNCH("mvd_attention_backward");
+  return 0;
+}
+
+extern "C" int mvd_pixel_cross_attn_backward(const float* q, const float* k, const float* v, const float* dout, int P, int D, int heads,
+                                             int dhead, float* dq, float* dk, float* dv, mvd_stream_t stream) {
+  MVD_CHECK_ARG(q && k && v && dout && dq && dk && dv && P > 0 && D > 0 && D <= 8 && heads > 0 && dhead > 0,
+                "mvd_pixel_cross_attn_backward: bad arguments (D <= 8)");
+  const size_t items = (size_t)P * heads;
+  hipLaunchKernelGGL(pixel_xattn_bwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, dout, P, D,
+                     heads, dhead, dq, dk, dv);
+  MVD_CHECK_LAUNCH("mvd_pixel_cross_attn_backward");
   return 0;
 }

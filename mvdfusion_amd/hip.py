@@ -69,6 +69,10 @@ SIGNATURES = {
     "mvd_im2col3x3_t_planes": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "mvd_col_sum_workspace_doubles": (_sz, [_i, _i]),
     "mvd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "mvd_layernorm_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "mvd_geglu_backward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "mvd_attention_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mvd_pixel_cross_attn_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mvd_groupnorm_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mvd_groupnorm_from_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

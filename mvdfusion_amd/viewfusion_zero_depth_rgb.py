@@ -418,6 +418,31 @@ class ViewFusion(nn.Module):
         return loss
 
     @torch.no_grad()
+    def tail_gradients(self, batch, trainer_config, noise_source=None):
+        """head_gradients continued through the LAST output block (ResBlock + SpatialTransformer + ViewAlignedFeatureTransformer,
+        `output_blocks.11`): every operator kind of the UNet has a backward on the HIP path (mvdfusion_amd/backward_blocks.py).
+        Returns (loss, {state_dict key: gradient}, dcat = dL/d(input of that block) (V, 2 mc, S, S))."""
+        from . import backward_blocks as bb
+        loss, grads, dh = self.head_gradients(batch, trainer_config, noise_source=noise_source)
+        unet = self.unet_model.unet_model
+        V, mc, S, _ = dh.shape
+        D = self.view_attn.n_pts_per_ray
+        eng = self.engine(V, S, D, False)
+        ctx = eng.ctx
+        M = V * S * S
+        blk = unet.output_blocks[len(unet.output_blocks) - 1]
+        cin = blk[0].channels
+        cat, catp = ctx.ws.get("cat", (M, cin)), ctx.ws.planes("catp", M, cin)
+        emb = ctx.ws.get("temb.emb", (1, unet.model_channels * 4))
+        tape = bb.Tape(dh.device, prec=ctx.prec, workspace=ctx.gemm_ws)
+        dh_rows = dh.permute(0, 2, 3, 1).reshape(M, mc).contiguous()
+        dcat, g, dcontext, dvol, demb = bb.output_block_backward(tape, ctx, blk, cat, catp, emb, eng.context[:V], eng.vol.view(M * D, -1),
+                                                                 dh_rows, V, S, S, D)
+        pre = f"unet_model.unet_model.output_blocks.{len(unet.output_blocks) - 1}."
+        grads.update({pre + k: v for k, v in g.items()})
+        return loss, grads, dcat.view(V, S, S, cin).permute(0, 3, 1, 2).contiguous()
+
+    @torch.no_grad()
     def head_gradients(self, batch, trainer_config, noise_source=None):
         """First slice of train.py:90-95 (`loss.backward()`) on the HIP path: the training forward (p_losses) followed by the
         backward of MSE -> UNet output head (conv3x3 <- SiLU <- GroupNorm32) with the backward kernels of mvdfusion_amd/backward.py.

@@ -584,6 +584,8 @@ def gold_train_loss(model_channels, V, D, tag, seed, S_img=256, grads_tag=None):
         head = m.unet_model.unet_model.out
         grabbed = {}
         head.register_full_backward_hook(lambda mod, gin, gout: grabbed.__setitem__("dh", gin[0].detach().clone()))
+        last = m.unet_model.unet_model.output_blocks[11]       # ResBlock + SpatialTransformer + ViewAlignedFeatureTransformer
+        last.register_full_backward_hook(lambda mod, gin, gout: grabbed.__setitem__("dcat", gin[0].detach().clone()))
         torch.manual_seed(draw_seed)
         loss_g = m(batch, cfg)
         loss_g.backward()
@@ -591,7 +593,12 @@ def gold_train_loss(model_channels, V, D, tag, seed, S_img=256, grads_tag=None):
         hp = "unet_model.unet_model.out."
         g = {n: p.grad.detach().clone() for n, p in named if n.startswith(hp)}
         dh = grabbed["dh"]                                     # (V, mc, S, S)
-        save(grads_tag, loss=loss_g.detach(), out0_weight=g[hp + "0.weight"], out0_bias=g[hp + "0.bias"], out2_weight=g[hp + "2.weight"],
+        bp = "unet_model.unet_model.output_blocks.11."
+        blk = [(n, p.grad.detach().clone()) for n, p in named if n.startswith(bp)]
+        dcat = grabbed["dcat"]                                 # gradient at the input of the last output block (V, 2 mc, S, S)
+        extra = {f"blk11_g{i}": gr for i, (_, gr) in enumerate(blk)}
+        save(grads_tag, blk11_names=np.array([n for n, _ in blk]), dcat_strided=dcat[:, :, ::3, ::5].contiguous(), dcat_norm=dcat.norm(),
+             **extra, loss=loss_g.detach(), out0_weight=g[hp + "0.weight"], out0_bias=g[hp + "0.bias"], out2_weight=g[hp + "2.weight"],
              out2_bias=g[hp + "2.bias"], dh_strided=dh[:, :, ::3, ::5].contiguous(), dh_norm=dh.norm(),
              grad_names=np.array([n for n, _ in named]), grad_norms=np.array([float(p.grad.norm()) for _, p in named], dtype=np.float64),
              batch_seed=np.int64(seed), draw_seed=np.int64(draw_seed), t=t_draw, drop_rand=drop_rand)

@@ -57,6 +57,29 @@ def test_linear_backward(hip, M, N, K):
     assert rel_err(db.cpu(), b.grad) < 2e-6
 
 
+def test_backward_gradients_far_below_fp16_normal_range(hip):
+    """Real gradients are 1e-5 ... 1e-8: below 6e-5 the fp16 operand split only resolves 2^-25 absolutely, so the backward scales dY by
+    a power of two before the split (exactly undone by the GEMM's accumulator scale).  Same relative accuracy as at unit scale."""
+    from mvdfusion_amd import backward as bw
+    M, N, K = 1024, 96, 320
+    x = torch.randn(M, K, generator=g(2), requires_grad=True)
+    w = (torch.randn(N, K, generator=g(3)) / math.sqrt(K)).requires_grad_()
+    dy = torch.randn(M, N, generator=g(5)) * 3e-7
+    F.linear(x, w).backward(dy)
+    ws = torch.empty(16 * 1024 * 1024, device="cuda")
+    dx, dW, _ = bw.linear_backward(hip.split_planes(x.detach().cuda()), w.detach().cuda(), dy.cuda(), ws, need_db=False)
+    assert rel_err(dx.cpu(), x.grad) < 3e-6 and rel_err(dW.cpu(), w.grad) < 3e-6
+    B, H, Cin, Cout = 2, 16, 64, 32
+    xc = torch.randn(B, Cin, H, H, generator=g(6), requires_grad=True)
+    wc = (torch.randn(Cout, Cin, 3, 3, generator=g(7)) / math.sqrt(9 * Cin)).requires_grad_()
+    dyc = torch.randn(B, Cout, H, H, generator=g(9)) * 3e-7
+    F.conv2d(xc, wc, None, padding=1).backward(dyc)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(B * H * H, -1).contiguous()
+    dxc, dWc, _ = bw.conv3x3_backward(hip.split_planes(rows(xc.detach()).cuda()), wc.detach().cuda(), rows(dyc).cuda(), B, H, H, ws,
+                                      need_db=False)
+    assert rel_err(dxc.cpu(), rows(xc.grad)) < 3e-6 and rel_err(dWc.cpu(), wc.grad) < 3e-6
+
+
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 64, 96), (4, 32, 32, 5), (1, 8, 320, 64), (2, 8, 10, 32)])
 def test_conv3x3_backward(hip, B, H, Cin, Cout):
     from mvdfusion_amd import backward as bw
@@ -94,3 +117,62 @@ def test_groupnorm_backward(hip, B, HW, C, silu, eps):
     dx2, dg2, db2 = bw.groupnorm_backward(x.detach().reshape(B * HW, C).cuda(), dy.reshape(B * HW, C).cuda(), gm.detach().cuda(),
                                           bt.detach().cuda(), B, HW, C, eps, silu)
     assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (64, 1280), (4096, 32), (37, 640)])
+def test_layernorm_backward(hip, rows, C):
+    from mvdfusion_amd import backward as bw
+    x = (torch.randn(rows, C, generator=g(20)) * 3 + 1).requires_grad_()
+    w = torch.randn(C, generator=g(21), requires_grad=True)
+    b = torch.randn(C, generator=g(22), requires_grad=True)
+    dy = torch.randn(rows, C, generator=g(23))
+    F.layer_norm(x, (C,), w, b, eps=1e-5).backward(dy)
+    dx, dw, db = bw.layernorm_backward(x.detach().cuda(), dy.cuda(), w.detach().cuda(), 1e-5)
+    assert rel_err(dx.cpu(), x.grad) < 5e-6
+    assert rel_err(dw.cpu(), w.grad) < 5e-6
+    assert rel_err(db.cpu(), b.grad) < 2e-6
+
+
+def test_geglu_backward(hip):
+    from mvdfusion_amd import backward as bw
+    rows, half = 512, 1280
+    h = (torch.randn(rows, 2 * half, generator=g(24)) * 2).requires_grad_()
+    dy = torch.randn(rows, half, generator=g(25))
+    a, gt = h.chunk(2, dim=-1)
+    (a * F.gelu(gt)).backward(dy)
+    dh = bw.geglu_backward(h.detach().cuda(), dy.cuda())
+    assert rel_err(dh.cpu(), h.grad) < 3e-6
+
+
+@pytest.mark.parametrize("B,H,L,d", [(2, 8, 256, 40), (1, 8, 1024, 4), (2, 4, 64, 160), (2, 8, 100, 80)])
+def test_attention_backward(hip, B, H, L, d):
+    from mvdfusion_amd import backward as bw
+    C = H * d
+    q, k, v = [(torch.randn(B * L, C, generator=g(26 + i)) * (1.5 if i < 2 else 1.0)).requires_grad_() for i in range(3)]
+    dout = torch.randn(B * L, C, generator=g(30))
+    heads = lambda t: t.view(B, L, H, d).permute(0, 2, 1, 3)
+    o = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * d ** -0.5, dim=-1) @ heads(v)
+    o.permute(0, 2, 1, 3).reshape(B * L, C).backward(dout)
+    dq, dk, dv = bw.attention_backward(q.detach().cuda(), k.detach().cuda(), v.detach().cuda(), dout.cuda(), B, H, L, d)
+    assert rel_err(dq.cpu(), q.grad) < 1e-5
+    assert rel_err(dk.cpu(), k.grad) < 1e-5
+    assert rel_err(dv.cpu(), v.grad) < 1e-5
+
+
+@pytest.mark.parametrize("D", [1, 3, 8])
+def test_pixel_cross_attn_backward(hip, D):
+    from mvdfusion_amd import backward as bw
+    P, H, d = 300, 8, 40
+    C = H * d
+    q = torch.randn(P, C, generator=g(31), requires_grad=True)
+    k = torch.randn(P * D, C, generator=g(32), requires_grad=True)
+    v = torch.randn(P * D, C, generator=g(33), requires_grad=True)
+    dout = torch.randn(P, C, generator=g(34))
+    qh = q.view(P, 1, H, d).permute(0, 2, 1, 3)
+    kh, vh = k.view(P, D, H, d).permute(0, 2, 1, 3), v.view(P, D, H, d).permute(0, 2, 1, 3)
+    o = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1) @ vh
+    o.permute(0, 2, 1, 3).reshape(P, C).backward(dout)
+    dq, dk, dv = bw.pixel_cross_attn_backward(q.detach().cuda(), k.detach().cuda(), v.detach().cuda(), dout.cuda(), P, D, H, d)
+    assert rel_err(dq.cpu(), q.grad) < 5e-6
+    assert rel_err(dk.cpu(), k.grad) < 5e-6
+    assert rel_err(dv.cpu(), v.grad) < 5e-6

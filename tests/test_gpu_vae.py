@@ -251,9 +251,38 @@ def test_training_head_gradients_vs_reference_golden():
                     (pre + "0.bias", "out0_bias")):
         e = rel_err(grads[key].cpu(), gd[gk])
         print(f"grad {key}: rel err {e:.2e}")
-        assert grads[key].shape == gd[gk].shape and e < 5e-4, (key, e)
-    assert rel_err(dh.cpu()[:, :, ::3, ::5], gd["dh_strided"]) < 5e-4
-    assert abs(float(dh.norm()) - float(gd["dh_norm"])) / float(gd["dh_norm"]) < 5e-4
+        assert grads[key].shape == gd[gk].shape and e < 2e-5, (key, e)
+    assert rel_err(dh.cpu()[:, :, ::3, ::5], gd["dh_strided"]) < 2e-5
+    assert abs(float(dh.norm()) - float(gd["dh_norm"])) / float(gd["dh_norm"]) < 2e-5
+
+
+def test_training_last_block_gradients_vs_reference_golden():
+    """`loss.backward()` continued through the last output block -- ResBlock + SpatialTransformer (length-1 CLIP cross-attention) +
+    ViewAlignedFeatureTransformer (self-attention, per-pixel cross-attention over D = 3 depth samples, GEGLU) -- i.e. every operator
+    kind of the UNet, on the HIP backward kernels; all 64 parameter gradients of `output_blocks.11` and the gradient at the block's
+    input against the REAL reference's autograd (train_grads_mc32_v4_d3).  Gradients that are pure rounding noise in the reference
+    (a conv bias in front of a GroupNorm: |g| ~ 1e-9) are compared on an absolute scale."""
+    gd = load_golden("train_grads_mc32_v4_d3")
+    m, batch, tc, draws = _training_setup(gd)
+    loss, grads, dcat = m.tail_gradients(batch, tc, noise_source=draws)
+    names = [str(n) for n in gd["blk11_names"]]
+    assert len(names) == 64
+    worst, bad = 0.0, []
+    for i, n in enumerate(names):
+        ref = gd[f"blk11_g{i}"]
+        got = grads[n].detach().cpu().reshape(ref.shape)
+        scale = float(ref.abs().max())
+        err = float((got.double() - ref.double()).abs().max())
+        rel = err / (scale + 1e-30)
+        print(f"{n.split('output_blocks.11.')[1]:60s} |ref| {scale:.2e}  err {err:.2e}")
+        bad += [(n, err, scale)] if err > 5e-5 * scale + 1e-8 else []
+        if scale > 1e-6:
+            worst = max(worst, rel)
+    print(f"worst relative error over the non-noise gradients: {worst:.2e}")
+    assert not bad, bad
+    assert worst < 5e-5
+    assert rel_err(dcat.cpu()[:, :, ::3, ::5], gd["dcat_strided"]) < 5e-5
+    assert abs(float(dcat.norm()) - float(gd["dcat_norm"])) / float(gd["dcat_norm"]) < 5e-5
 
 
 @pytest.mark.parametrize("name,model", [("clip_tiny", "tiny-test"), ("clip_vit_l14", "ViT-L/14")])
