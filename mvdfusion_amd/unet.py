@@ -211,6 +211,7 @@ class UNetModel(nn.Module):
         self._temb = None
         self._xattn = None
         self._head_saved = None
+        self._record = None
 
     # ------------------------------------------------------------------ reference API (unet.py:558-576)
     def get_cross_attn_parameters(self, finetune_cross_attn, finetune_view_attn):
@@ -282,7 +283,10 @@ class UNetModel(nn.Module):
         hs = []
         H = W = S
         h = x_in
+        rec = self._record          # training: a list that receives (block, copy of the block input, H, W, h width of a cat input)
         for bi, blk in enumerate(self.input_blocks):
+            if rec is not None:
+                rec.append((blk, h.clone(), H, W, 0))
             if bi == 0:
                 o = ctx.ws.get("hs0", (B * H * W, self.model_channels))
                 h = blk[0].run(ctx, h, H, W, o)
@@ -293,6 +297,8 @@ class UNetModel(nn.Module):
                 o = ctx.ws.get(f"hs{bi}", (B * Ho * Wo, co))      # skip tensors get their own static buffers
                 h, H, W = blk.run(ctx, h, H, W, out=o)
             hs.append((h, H, W))
+        if rec is not None:
+            rec.append((self.middle_block, h.clone(), H, W, 0))
         h, H, W = self.middle_block.run(ctx, h, H, W)
         for blk in self.output_blocks:
             sk, _, _ = hs.pop()
@@ -301,6 +307,8 @@ class UNetModel(nn.Module):
             cat = ctx.ws.get("cat", (M, ca + cb))
             catp = ctx.ws.planes("catp", M, ca + cb)          # planes for the ResBlock's 1x1 skip conv
             ctx.concat(h, ca, sk, cb, cat, catp, B, H * W)
+            if rec is not None:
+                rec.append((blk, cat.clone(), H, W, ca))
             h, H, W = blk.run(ctx, cat, H, W, x_planes=catp)
         if self._head is None:
             self._head = hip.pack_conv3x3(self.out[2].weight, self.out[2].bias)

@@ -365,8 +365,9 @@ class ViewFusion(nn.Module):
             drop_clip, drop_vol = (r > 0.15) & (r <= 0.2), (r > 0.1) & (r <= 0.15)          # get_drop_scheme 'default' (unet.py:109-117)
             drop_cat, drop_all = (r > 0.05) & (r <= 0.1), r <= 0.05
             eng.drop_masks = tuple(1.0 - (dm | drop_all).float() for dm in (drop_clip, drop_vol, drop_cat))
+        self._last_drop_masks = eng.drop_masks
         try:
-            eng.step(cfg_scale, do_update=False, use_graph=eng.drop_masks is None)
+            eng.step(cfg_scale, do_update=False, use_graph=eng.drop_masks is None and not getattr(self, "_force_eager", False))
         finally:
             eng.drop_masks = None
         return hip.check_finite(eng.eps.clone(), "ViewFusion.apply_model")
@@ -416,6 +417,40 @@ class ViewFusion(nn.Module):
         if _aux is not None:
             _aux.update(pred=pred, target=target)
         return loss
+
+    @torch.no_grad()
+    def unet_gradients(self, batch, trainer_config, noise_source=None):
+        """`loss.backward()` (train.py:90-95) through the WHOLE UNet and the per-step vector paths on the HIP backward kernels
+        (mvdfusion_amd/backward_unet.py): gradients of every `unet_model.unet_model.*` and `cc_projection.*` parameter, plus the
+        gradient w.r.t. the volume features that GridAttn produced (GridAttn's own backward -- `view_attn.*`, `time_embed.*` -- is
+        not built yet).  Returns (loss, {state_dict key: gradient}, dvol (V, S, S, D, 768))."""
+        from . import backward_blocks as bb
+        from . import backward_unet as bu
+        unet = self.unet_model.unet_model
+        unet._record, self._force_eager = [], True
+        try:
+            loss, grads, dh = self.head_gradients(batch, trainer_config, noise_source=noise_source)
+            record = unet._record
+        finally:
+            unet._record, self._force_eager = None, False
+        V, mc, S, _ = dh.shape
+        D = self.view_attn.n_pts_per_ray
+        eng = self.engine(V, S, D, False)
+        ctx = eng.ctx
+        M = V * S * S
+        emb = ctx.ws.get("temb.emb", (1, unet.model_channels * 4))
+        t_sin = ctx.ws.get("vf.tsin_unet", (1, unet.model_channels))
+        tape = bb.Tape(dh.device, prec=ctx.prec, workspace=ctx.gemm_ws)
+        dh_rows = dh.permute(0, 2, 3, 1).reshape(M, mc).contiguous()
+        context = eng.context[:V].clone()
+        g, dcontext, dvol = bu.unet_backward(unet, ctx, tape, record, dh_rows, V, S, D, emb, t_sin, context, eng.vol.view(V, S, S, D, -1))
+        grads.update({"unet_model.unet_model." + k: v for k, v in g.items()})
+        masks = getattr(self, "_last_drop_masks", None)
+        if masks is not None:                      # the conditions were multiplied by the keep masks after their producers
+            dcontext = dcontext * masks[0][:, None]
+            dvol = dvol * masks[1].view(V, 1, 1, 1, 1)
+        grads.update({"cc_projection." + k: v for k, v in bu.cc_projection_backward(self.cc_projection, eng.clip_v_embed[:V], dcontext).items()})
+        return loss, grads, dvol
 
     @torch.no_grad()
     def tail_gradients(self, batch, trainer_config, noise_source=None):

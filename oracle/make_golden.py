@@ -601,6 +601,10 @@ def gold_train_loss(model_channels, V, D, tag, seed, S_img=256, grads_tag=None):
              **extra, loss=loss_g.detach(), out0_weight=g[hp + "0.weight"], out0_bias=g[hp + "0.bias"], out2_weight=g[hp + "2.weight"],
              out2_bias=g[hp + "2.bias"], dh_strided=dh[:, :, ::3, ::5].contiguous(), dh_norm=dh.norm(),
              grad_names=np.array([n for n, _ in named]), grad_norms=np.array([float(p.grad.norm()) for _, p in named], dtype=np.float64),
+             # projection of every gradient onto a seeded N(0,1) direction (CPU generator, seed 1000 + index): with the norm, a
+             # two-number fingerprint per parameter that a wrong layout / sign / missing term cannot match
+             grad_projs=np.array([float((p.grad.double().flatten() * torch.randn(p.numel(), generator=torch.Generator().manual_seed(1000 + i))
+                                         .double()).sum()) for i, (_, p) in enumerate(named)], dtype=np.float64),
              batch_seed=np.int64(seed), draw_seed=np.int64(draw_seed), t=t_draw, drop_rand=drop_rand)
         print(f"  train grads: loss {float(loss_g):.6f}, |dh| {float(dh.norm()):.4e}, {len(named)} parameter gradients")
         m.zero_grad(set_to_none=True)
