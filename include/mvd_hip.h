@@ -345,6 +345,14 @@ int mvd_attention_backward(const float* q, const float* k, const float* v, const
 int mvd_pixel_cross_attn_backward(const float* q, const float* k, const float* v, const float* dout, int P, int D, int heads, int dhead,
                                   float* dq, float* dk, float* dv, mvd_stream_t stream);
 
+/* Backward of mvd_gridattn_tokens w.r.t. the feature maps (grid_sample backward, view_attn_efficient2.py:320-341): dtok (T, ldt)
+ * fp32 token gradients (columns [0,256) reference-view samples, [256,512) input-view samples) are scattered with the forward's
+ * taps into 64-bit fixed-point accumulators dfeat_acc (V,S,S,256) / din_feat_acc (S,S,256) (value * scale; zeroed by the caller). */
+int mvd_gridattn_tokens_backward(const float* x, const float* depth_noise, const float* steps, const int* iter, const float* grid_lin,
+                                 const float* cams, const float* in_cam, const float* dtok, int ldt, long long* dfeat_acc,
+                                 long long* din_feat_acc, float scale, int V, int q0, int Vq, int S, int D, float depth_scale,
+                                 float depth_shift, mvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

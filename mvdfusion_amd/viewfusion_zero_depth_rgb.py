@@ -453,6 +453,26 @@ class ViewFusion(nn.Module):
         return loss, grads, dvol
 
     @torch.no_grad()
+    def gradients(self, batch, trainer_config, noise_source=None):
+        """The complete `loss.backward()` of train.py:90-95 on the HIP path: unet_gradients continued through GridAttn
+        (mvdfusion_amd/backward_gridattn.py: final layer, softmax-over-V pooling, 3 DiT blocks, pre layer, grid_sample backward,
+        z-embedding) and ViewFusion.time_embed.  Returns (loss, {state_dict key: gradient}) for every trainable parameter the loss
+        depends on."""
+        from . import backward_blocks as bb
+        from . import backward_gridattn as bg
+        loss, grads, dvol = self.unet_gradients(batch, trainer_config, noise_source=noise_source)
+        V, S, _, D, _ = dvol.shape
+        eng = self.engine(V, S, D, False)
+        ctx = eng.ctx
+        tape = bb.Tape(dvol.device, prec=ctx.prec, workspace=ctx.gemm_ws)
+        c = ctx.ws.get("vf.c", (1, 256))
+        g, dc = bg.gridattn_backward(self.view_attn, tape, eng, c, dvol.reshape(V * S * S * D, -1).contiguous(), V, S, D)
+        grads.update({"view_attn." + k: v for k, v in g.items()})
+        t_sin = ctx.ws.get("vf.tsin", (1, 256))
+        grads.update({"time_embed." + k: v for k, v in bg.time_embed_backward(self.time_embed, t_sin, dc).items()})
+        return loss, grads
+
+    @torch.no_grad()
     def tail_gradients(self, batch, trainer_config, noise_source=None):
         """head_gradients continued through the LAST output block (ResBlock + SpatialTransformer + ViewAlignedFeatureTransformer,
         `output_blocks.11`): every operator kind of the UNet has a backward on the HIP path (mvdfusion_amd/backward_blocks.py).

@@ -320,6 +320,38 @@ def test_training_unet_gradients_vs_reference_golden():
     assert bool(torch.isfinite(dvol).all()) and float(dvol.abs().max()) > 0
 
 
+def test_training_all_gradients_vs_reference_golden():
+    """The complete `loss.backward()` (train.py:90-95) on the HIP path: UNet + cc_projection + GridAttn (final layer, softmax-over-V
+    pooling, 3 adaLN-Zero DiT blocks with attention over the V views, pre layer, grid_sample backward into the z-embedded latents)
+    + time_embed: ALL 994 parameter gradients the reference's autograd produces, fingerprinted by L2 norm and a seeded random
+    projection (train_grads_mc32_v4_d3)."""
+    gd = load_golden("train_grads_mc32_v4_d3")
+    m, batch, tc, draws = _training_setup(gd)
+    loss, grads = m.gradients(batch, tc, noise_source=draws)
+    names = [str(n) for n in gd["grad_names"]]
+    norms, projs = gd["grad_norms"].double(), gd["grad_projs"].double()
+    assert len(names) == 994
+    missing, bad, worst = [], [], 0.0
+    for i, n in enumerate(names):
+        if n not in grads:
+            missing.append(n)
+            continue
+        gq = grads[n].detach().double().cpu().flatten()
+        r = torch.randn(gq.numel(), generator=torch.Generator().manual_seed(1000 + i)).double()
+        nr, pr = float(norms[i]), float(projs[i])
+        e_n, e_p = abs(float(gq.norm()) - nr), abs(float((gq * r).sum()) - pr)
+        tol = 1e-4 * nr + 2e-8 * gq.numel() ** 0.5
+        if e_n > tol or e_p > tol:
+            bad.append((n, nr, e_n, e_p))
+        if nr > 1e-6:
+            worst = max(worst, e_n / nr, e_p / nr)
+        if n.startswith(("view_attn.", "time_embed.")):
+            print(f"{n:75s} |g| {nr:.3e}  d|g| {e_n:.1e}  dproj {e_p:.1e}")
+    print(f"all {len(names)} parameter gradients compared, worst relative deviation {worst:.2e}")
+    assert not missing, missing[:10]
+    assert not bad, bad[:10]
+
+
 @pytest.mark.parametrize("name,model", [("clip_tiny", "tiny-test"), ("clip_vit_l14", "ViT-L/14")])
 def test_clip_image_encoder_vs_reference_golden(name, model):
     """FrozenCLIPImageEmbedder.encode on the HIP path (patch-embedding GEMM, 24 x [LN, QKV GEMM + bias, flash attention over 257
