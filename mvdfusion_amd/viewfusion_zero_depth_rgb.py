@@ -179,6 +179,23 @@ class StepEngine:
         g.launch()
 
 
+class _HipTrainingLoss(torch.autograd.Function):
+    """Bridges ViewFusion.gradients (forward + hand-written backward kernels) into torch autograd: forward computes the loss AND the
+    parameter gradients (the HIP buffers of the step are only valid until the next step), backward scales and returns them."""
+
+    @staticmethod
+    def forward(ctx, model, batch, trainer_config, names, *params):
+        loss, grads = model.gradients(batch, trainer_config, noise_source=getattr(model, "_noise_source", None))
+        ctx.grads = [grads.get(n) for n in names]
+        ctx.shapes = [p.shape for p in params]
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        outs = [None if g is None else (g.reshape(s) * grad_out) for g, s in zip(ctx.grads, ctx.shapes)]
+        return (None, None, None, None, *outs)
+
+
 class ViewFusion(nn.Module):
     def __init__(self, view_attn_config, unet_config, ddpm_config, vae_config=None, unet_path="", vae_path="",
                  clip_path="", unet_cc_path="", z_scale_factor=0.18215, vae_max_batch=8, objective="noise",
@@ -517,8 +534,15 @@ class ViewFusion(nn.Module):
         return loss, grads, dh.view(V, S, S, -1).permute(0, 3, 1, 2).contiguous()
 
     def forward(self, batch, trainer_config):
-        """viewfusion_zero_depth_rgb.py:394-397.  Forward value only -- see p_losses; .backward() on it raises."""
-        return self.p_losses(batch, trainer_config)
+        """viewfusion_zero_depth_rgb.py:394-397: the training loss.  With autograd enabled and trainable parameters the returned
+        scalar carries a graph node whose backward hands the HIP-computed gradients (self.gradients) to the parameters, so the
+        reference's loop ``loss = model(batch, cfg); optimizer.zero_grad(); loss.backward(); optimizer.step()`` (train.py:86-95) runs
+        unchanged -- under torch's DistributedDataParallel too: the parameters are inputs of that node, so DDP's gradient hooks fire and
+        all-reduce over RCCL as usual.  Without autograd (torch.no_grad / eval): the plain loss value."""
+        params = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        if not torch.is_grad_enabled() or not params:
+            return self.p_losses(batch, trainer_config, noise_source=getattr(self, "_noise_source", None))
+        return _HipTrainingLoss.apply(self, batch, trainer_config, tuple(n for n, _ in params), *[p for _, p in params])
 
     def configure_optimizers(self, lr=None, verbose=False):
         lr = self.learning_rate if lr is None else lr

@@ -352,6 +352,51 @@ def test_training_all_gradients_vs_reference_golden():
     assert not bad, bad[:10]
 
 
+def test_training_loop_drop_in_loss_backward_optimizer_step():
+    """The reference's training loop verbatim (train.py:86-95): ``loss = model(batch, cfg); optimizer.zero_grad(); loss.backward();
+    optimizer.step()`` with the optimizer of configure_optimizers (AdamW).  `.grad` of every parameter after loss.backward() equals
+    the reference's autograd (fingerprints of train_grads_mc32_v4_d3); after the optimizer step the packed MFMA operand images are
+    rebuilt from the updated parameters (the next forward gives a different, lower loss on the same batch and draws), and a few more
+    steps keep lowering it."""
+    gd = load_golden("train_grads_mc32_v4_d3")
+    m, batch, tc, draws = _training_setup(gd)
+    m._noise_source = draws                                    # replay the fixture's random draws in every forward
+    for p in m.vae.parameters():
+        p.requires_grad_(False)                                # the frozen VAE / CLIP encoders are not optimised (load_model.py)
+    for p in m.clip_image_encoder.parameters():
+        p.requires_grad_(False)
+    opt = m.configure_optimizers(lr=2e-4)
+    loss0 = m(batch, tc)
+    assert loss0.requires_grad and abs(float(loss0.detach()) - float(gd["loss"])) / float(gd["loss"]) < 1e-4
+    opt.zero_grad()
+    loss0.backward()
+    names = [str(n) for n in gd["grad_names"]]
+    pd = dict(m.named_parameters())
+    norms = gd["grad_norms"].double()
+    checked = 0
+    for i, n in enumerate(names):
+        if pd[n].grad is None:
+            continue
+        gq = pd[n].grad.detach().double().cpu().flatten()
+        assert abs(float(gq.norm()) - float(norms[i])) <= 1e-4 * float(norms[i]) + 2e-8 * gq.numel() ** 0.5, n
+        checked += 1
+    n_train = sum(1 for p in m.parameters() if p.requires_grad)
+    print(f"{checked} of {n_train} trainable parameters received a gradient that matches the reference")
+    assert checked >= 300 and checked >= n_train - 8          # (view_attn.t_embedder is present but unused: no gradient, as in the reference)
+    w_before = m.view_attn.final_layer_b.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(w_before, m.view_attn.final_layer_b.weight.detach())
+    losses = [float(loss0.detach())]
+    for _ in range(3):
+        loss = m(batch, tc)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    print("losses over 4 AdamW steps on one batch:", [f"{v:.5f}" for v in losses])
+    assert losses[1] < losses[0] and losses[-1] < losses[1]
+
+
 @pytest.mark.parametrize("name,model", [("clip_tiny", "tiny-test"), ("clip_vit_l14", "ViT-L/14")])
 def test_clip_image_encoder_vs_reference_golden(name, model):
     """FrozenCLIPImageEmbedder.encode on the HIP path (patch-embedding GEMM, 24 x [LN, QKV GEMM + bias, flash attention over 257
