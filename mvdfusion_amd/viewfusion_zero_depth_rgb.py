@@ -192,7 +192,8 @@ class _HipTrainingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        outs = [None if g is None else (g.reshape(s) * grad_out) for g, s in zip(ctx.grads, ctx.shapes)]
+        outs = [torch.zeros(s, dtype=grad_out.dtype, device=grad_out.device) if g is None else (g.reshape(s) * grad_out)
+                for g, s in zip(ctx.grads, ctx.shapes)]
         return (None, None, None, None, *outs)
 
 
@@ -539,7 +540,9 @@ class ViewFusion(nn.Module):
         reference's loop ``loss = model(batch, cfg); optimizer.zero_grad(); loss.backward(); optimizer.step()`` (train.py:86-95) runs
         unchanged -- under torch's DistributedDataParallel too: the parameters are inputs of that node, so DDP's gradient hooks fire and
         all-reduce over RCCL as usual.  Without autograd (torch.no_grad / eval): the plain loss value."""
-        params = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        # (view_attn.t_embedder exists in the reference's module tree but its forward never calls it: those parameters stay outside
+        #  the graph, exactly like the reference -- DDP(find_unused_parameters=True) treats them as unused)
+        params = [(n, p) for n, p in self.named_parameters() if p.requires_grad and not n.startswith("view_attn.t_embedder.")]
         if not torch.is_grad_enabled() or not params:
             return self.p_losses(batch, trainer_config, noise_source=getattr(self, "_noise_source", None))
         return _HipTrainingLoss.apply(self, batch, trainer_config, tuple(n for n, _ in params), *[p for _, p in params])

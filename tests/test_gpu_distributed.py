@@ -22,12 +22,22 @@ def _free_port():
     return p
 
 
-def _run(backend, V, steps):
+def _run(backend, V, steps, worker="_dist_gpu_worker.py"):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), backend, str(V), str(steps)]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", worker), backend, str(V), str(steps)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    recs = [json.loads(l.split("DISTJSON ", 1)[1]) for l in r.stdout.splitlines() if "DISTJSON " in l]
+    recs, dec, pos = [], json.JSONDecoder(), 0          # (the two ranks' lines may interleave on one line)
+    while True:
+        pos = r.stdout.find("DISTJSON ", pos)
+        if pos < 0:
+            break
+        pos += len("DISTJSON ")
+        try:
+            obj, _ = dec.raw_decode(r.stdout, pos)
+            recs.append(obj)
+        except json.JSONDecodeError:
+            pass
     return r, recs
 
 
@@ -48,3 +58,23 @@ def test_two_rank_view_parallel_on_one_gpu(V):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         json.dump({"backend": used, "records": recs}, open(os.path.join(out, "dist_2rank_one_gpu.json"), "w"))
+
+
+def test_two_rank_ddp_training_step():
+    """BASELINE configs[4] in miniature: the reference's DDP recipe (train.py:38, 86-95) with the HIP forward + backward: two ranks,
+    a different scene each, torch's DistributedDataParallel around the model; after loss.backward() every rank's `.grad` equals the
+    mean of the two ranks' local gradients (RCCL when it accepts two ranks on one device, else gloo)."""
+    r, recs = _run("nccl", 0, 0, worker="_dist_ddp_worker.py")
+    used = "nccl"
+    if r.returncode != 0 or len(recs) != 2:
+        r, recs = _run("gloo", 0, 0, worker="_dist_ddp_worker.py")
+        used = "gloo"
+    assert r.returncode == 0 and len(recs) == 2, (r.stderr[-3000:], r.stdout[-1500:])
+    print(f"DDP training step carried by backend: {used}: {recs}")
+    for x in recs:
+        assert x["max_rel_err_vs_mean_of_local_grads"] < 1e-5, x
+        assert abs(x["loss_local"] - x["loss_ddp"]) < 1e-6 and x["n_grads"] >= 300
+    assert abs(recs[0]["losses"][0] - recs[0]["losses"][1]) > 1e-6          # the ranks really trained on different scenes
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"backend": used, "records": recs}, open(os.path.join(out, "dist_ddp_2rank_one_gpu.json"), "w"))
