@@ -407,7 +407,10 @@ class ViewFusion(nn.Module):
         The value is a plain tensor: there are no backward kernels yet, so it serves validation /
         loss monitoring, not optimisation.  ``noise_source(V, D, S) -> dict(t, noise, depth_noise, drop_rand)`` injects the
         reference's random draws (parity tests); default: torch's device generator in the reference's order."""
-        batch_latents, batch_cameras, input_latents, input_cameras, clip_v_embed = self.prepare_batch(batch, trainer_config)
+        if isinstance(batch, dict) and "_prepared" in batch:      # (batch_latents, batch_cameras, input_latents, input_cameras,
+            batch_latents, batch_cameras, input_latents, input_cameras, clip_v_embed = batch["_prepared"]      # clip_v_embed): benches
+        else:
+            batch_latents, batch_cameras, input_latents, input_cameras, clip_v_embed = self.prepare_batch(batch, trainer_config)
         V, _, S, _ = batch_latents.shape
         D = self.view_attn.n_pts_per_ray
         dev = batch_latents.device

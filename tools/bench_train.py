@@ -1,0 +1,62 @@
+"""Training-step timing on one GPU (BASELINE.json configs[4] in miniature: fwd + bwd + AdamW on one scene of V views):
+the reference's loop ``loss = model(batch, cfg); optimizer.zero_grad(); loss.backward(); optimizer.step()`` on the HIP forward
+and the hand-written backward kernels (mvdfusion_amd/backward*.py), full-width SD1.x UNet, synthetic prepared batch.
+
+    python tools/bench_train.py [--views 8] [--depth-samples 3] [--steps 3] [--width 320]
+Prints one JSON line (not the headline metric: bench.py measures denoising steps/s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--depth-samples", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--width", type=int, default=320)
+    a = ap.parse_args()
+    from conftest import load_spec, model_config
+    from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
+    V, D, S = a.views, a.depth_samples, 32
+    m = ViewFusion(**model_config(a.width, D=D, S=S))
+    m.load_state_dict(syn.det_fill_state_dict(load_spec(a.width)), strict=False)
+    m = m.cuda().train()
+    for n, p in m.named_parameters():
+        if n.startswith(("vae.", "clip_image_encoder.")):
+            p.requires_grad_(False)
+    inp = syn.make_inputs(V, S, seed=0)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(V, 5, S, S, generator=g).cuda()
+    batch = {"_prepared": (lat, inp["batch_cameras"], inp["input_latents"].cuda(), inp["input_cameras"], inp["clip_v_embed"].cuda())}
+    opt = m.configure_optimizers(lr=1e-5)
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    times, losses = [], []
+    for i in range(a.steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = m(batch, {})
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        losses.append(float(loss.detach()))
+    dt = sum(times[1:]) / a.steps
+    print(json.dumps({"metric": "training-steps/sec (fwd + bwd + AdamW, one scene)", "value": 1.0 / dt, "s_per_step": dt, "first_step_s": times[0],
+                      "views": V, "depth_samples": D, "latent": S, "model_channels": a.width, "trainable_parameters": n_train,
+                      "losses": losses, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
+                      "note": "backward = recompute-per-block + dgrad/wgrad on the split-operand MFMA GEMM, fp32 VALU attention "
+                              "backward; a functional training path, not yet tuned (no graph capture, fresh allocations)"}))
+
+
+if __name__ == "__main__":
+    main()
