@@ -287,138 +287,215 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------- self-attention backward (fp32 VALU)
 // CrossAttention(context=None) core (attention.py:170-193): per (batch, head), O = softmax(Q K^T * scale) V over L tokens of width d.
-// q, k, v, o-grad are token-major (B*L, heads*d) fp32 as the forward's projections produce them.  Two kernels, both deterministic:
-//   attn_bwd_stats : per query row  m = max_j s_ij, l = sum_j exp(s_ij - m), delta = sum_d dO_id O_id   (O recomputed on the fly)
-//   attn_bwd_dq    : dQ_i = scale * sum_j P_ij (dP_ij - delta_i) K_j               (one wave per query row, lanes over keys)
-//   attn_bwd_dkv   : dK_j = scale * sum_i P_ij (dP_ij - delta_i) Q_i,  dV_j = sum_i P_ij dO_i   (one wave per key row, lanes over queries)
-// with P_ij = exp(s_ij - m_i) / l_i and dP_ij = dO_i . V_j.  Work 5 x 2 L^2 d per head on the VALU: a training-path kernel, not a
-// roofline one (the MFMA version follows the forward's attn_kernel tiling).
+// q, k, v, o-grad are token-major (B*L, heads*d) fp32 as the forward's projections produce them.  One LDS-tiled kernel, three modes:
+//   MODE 2  stats : per query row  m = max_j s_ij, l = sum_j exp(s_ij - m), delta = sum_j P_ij dP_ij      (two sweeps over the keys)
+//   MODE 0  dQ    : dQ_i = scale * sum_j P_ij (dP_ij - delta_i) K_j
+//   MODE 1  dK,dV : dK_j = scale * sum_i P_ij (dP_ij - delta_i) Q_i,   dV_j = sum_i P_ij dO_i
+// with P_ij = exp(s_ij - m_i) / l_i, dP_ij = dO_i . V_j.  A workgroup keeps TQ "stationary" rows (queries for modes 0 / 2, keys for
+// mode 1: both of their operand rows) in LDS and streams tiles of TK rows of the other side; the 16 x 16 thread grid owns an
+// (TQ/16) x (TK/16) block of the score tile, the dS / P tiles go through LDS for the second product.  Everything is accumulated in a
+// fixed order: deterministic.  ~5 x 2 L^2 d FLOP per head on the VALU (the MFMA version would follow the forward's attn_kernel).
 constexpr int AB_MAXD = 160;
-__device__ __forceinline__ float dot_row(const float* __restrict__ a, const float* __restrict__ b, int d) {
-  float s = 0.f;
-  for (int e = 0; e < d; e += 4) {
-    const float4 x = *(const float4*)(a + e), y = *(const float4*)(b + e);
-    s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-  }
-  return s;
-}
 
-// grid (L / 4... rows, heads, B); one wave per query row: lanes stride over keys.  stats: (B, heads, L, 3) = m, l, delta
-__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                             const float* __restrict__ v, const float* __restrict__ dout, int L, int H, int d,
-                                                             float scale, float* __restrict__ stats) {
-  __shared__ float sq[4][AB_MAXD], sd[4][AB_MAXD];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + w, hd = blockIdx.y, b = blockIdx.z;
+template <int TQ, int TK, int DMAX, int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_tile_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const float* __restrict__ dout,
+                                                            float* __restrict__ stats, int L, int H, int d, float scale,
+                                                            float* __restrict__ out1, float* __restrict__ out2) {
+  constexpr int DP = DMAX + 1, RI = TQ / 16, RJ = TK / 16, EC = DMAX / 16;
+  __shared__ float A1[TQ][DP], A2[TQ][DP], B1[TK][DP], B2[TK][DP];
+  __shared__ float DSs[TQ][TK + 1];
+  __shared__ float PSs[MODE == 1 ? TQ : 1][MODE == 1 ? TK + 1 : 1];
+  __shared__ float stB[3][TK];             // mode 1: statistics of the streamed query rows
+  __shared__ float red[2][TQ][17];         // mode 2: row reductions across the 16 column threads
+  __shared__ float rowm[TQ];
+  const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
+  const int r0 = blockIdx.x * TQ, hd = blockIdx.y, b = blockIdx.z;
   const int C = H * d;
-  if (i >= L) return;
-  const size_t rowi = ((size_t)b * L + i) * C + hd * d;
-  for (int e = lane; e < d; e += 64) {
-    sq[w][e] = q[rowi + e];
-    sd[w][e] = dout[rowi + e];
+  const float* sA1 = MODE == 1 ? k : q;
+  const float* sA2 = MODE == 1 ? v : dout;
+  const float* sB1 = MODE == 1 ? q : k;
+  const float* sB2 = MODE == 1 ? dout : v;
+  const size_t base = (size_t)b * L * C + (size_t)hd * d;
+  for (int idx = t; idx < TQ * d; idx += 256) {
+    const int r = idx / d, e = idx - r * d;
+    const bool ok = r0 + r < L;
+    A1[r][e] = ok ? sA1[base + (size_t)(r0 + r) * C + e] : 0.f;
+    A2[r][e] = ok ? sA2[base + (size_t)(r0 + r) * C + e] : 0.f;
   }
-  // (wave-private LDS rows: in-order within the wave)
-  float m = -INFINITY;
-  for (int j = lane; j < L; j += 64) m = fmaxf(m, dot_row(sq[w], k + ((size_t)b * L + j) * C + hd * d, d) * scale);
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  float l = 0.f, dl = 0.f;
-  for (int j = lane; j < L; j += 64) {
-    const size_t rowj = ((size_t)b * L + j) * C + hd * d;
-    const float p = __expf(dot_row(sq[w], k + rowj, d) * scale - m);
-    l += p;
-    dl += p * dot_row(sd[w], v + rowj, d);        // sum_j p_ij dP_ij = l * (dO_i . O_i)
-  }
-  l = wave_sum(l);
-  dl = wave_sum(dl);
-  if (lane == 0) {
-    float* st = stats + (((size_t)b * H + hd) * L + i) * 3;
-    st[0] = m;
-    st[1] = l;
-    st[2] = dl / l;
-  }
-}
-
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                          const float* __restrict__ v, const float* __restrict__ dout,
-                                                          const float* __restrict__ stats, int L, int H, int d, float scale,
-                                                          float* __restrict__ dq) {
-  __shared__ float sq[4][AB_MAXD], sd[4][AB_MAXD], acc[4][AB_MAXD];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + w, hd = blockIdx.y, b = blockIdx.z;
-  const int C = H * d;
-  if (i >= L) return;
-  const size_t rowi = ((size_t)b * L + i) * C + hd * d;
-  for (int e = lane; e < d; e += 64) {
-    sq[w][e] = q[rowi + e];
-    sd[w][e] = dout[rowi + e];
-  }
-  const float* st = stats + (((size_t)b * H + hd) * L + i) * 3;
-  const float m = st[0], inv_l = 1.0f / st[1], delta = st[2];
-  // every lane accumulates its keys' contributions for all d in registers (d <= 160: 160 floats would spill; go by chunks of 32)
-  for (int e0 = 0; e0 < d; e0 += 32) {
-    float a[32];
+  float m_i[RI], il_i[RI], de_i[RI];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) a[e] = 0.f;
-    for (int j = lane; j < L; j += 64) {
-      const size_t rowj = ((size_t)b * L + j) * C + hd * d;
-      const float p = __expf(dot_row(sq[w], k + rowj, d) * scale - m) * inv_l;
-      const float ds = p * (dot_row(sd[w], v + rowj, d) - delta) * scale;
-#pragma unroll
-      for (int e = 0; e < 32; ++e)
-        if (e0 + e < d) a[e] += ds * k[rowj + e0 + e];
-    }
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-      const float t = wave_sum(a[e]);
-      if (lane == 0 && e0 + e < d) acc[w][e0 + e] = t;
-    }
-  }
-  for (int e = lane; e < d; e += 64) dq[rowi + e] = acc[w][e];
-}
-
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                           const float* __restrict__ v, const float* __restrict__ dout,
-                                                           const float* __restrict__ stats, int L, int H, int d, float scale,
-                                                           float* __restrict__ dk, float* __restrict__ dv) {
-  __shared__ float sk[4][AB_MAXD], sv[4][AB_MAXD], ak[4][AB_MAXD], av[4][AB_MAXD];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int j = blockIdx.x * 4 + w, hd = blockIdx.y, b = blockIdx.z;
-  const int C = H * d;
-  if (j >= L) return;
-  const size_t rowj = ((size_t)b * L + j) * C + hd * d;
-  for (int e = lane; e < d; e += 64) {
-    sk[w][e] = k[rowj + e];
-    sv[w][e] = v[rowj + e];
-  }
-  for (int e0 = 0; e0 < d; e0 += 32) {
-    float a[32], c[32];
-#pragma unroll
-    for (int e = 0; e < 32; ++e) a[e] = c[e] = 0.f;
-    for (int i = lane; i < L; i += 64) {
-      const size_t rowi = ((size_t)b * L + i) * C + hd * d;
-      const float* st = stats + (((size_t)b * H + hd) * L + i) * 3;
-      const float p = __expf(dot_row(sk[w], q + rowi, d) * scale - st[0]) / st[1];
-      const float ds = p * (dot_row(sv[w], dout + rowi, d) - st[2]) * scale;
-#pragma unroll
-      for (int e = 0; e < 32; ++e)
-        if (e0 + e < d) {
-          a[e] += ds * q[rowi + e0 + e];
-          c[e] += p * dout[rowi + e0 + e];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-      const float t1 = wave_sum(a[e]), t2 = wave_sum(c[e]);
-      if (lane == 0 && e0 + e < d) {
-        ak[w][e0 + e] = t1;
-        av[w][e0 + e] = t2;
+  for (int a = 0; a < RI; ++a) {
+    m_i[a] = 0.f;
+    il_i[a] = 0.f;
+    de_i[a] = 0.f;
+    if (MODE == 0) {
+      const int row = r0 + ti * RI + a;
+      if (row < L) {
+        const float* st = stats + (((size_t)b * H + hd) * L + row) * 3;
+        m_i[a] = st[0];
+        il_i[a] = 1.0f / st[1];
+        de_i[a] = st[2];
       }
     }
   }
-  for (int e = lane; e < d; e += 64) {
-    dk[rowj + e] = ak[w][e];
-    dv[rowj + e] = av[w][e];
+  float acc1[RI][EC], acc2[RI][EC];
+#pragma unroll
+  for (int a = 0; a < RI; ++a)
+#pragma unroll
+    for (int c = 0; c < EC; ++c) acc1[a][c] = acc2[a][c] = 0.f;
+  float mx[RI], ls[RI], dl[RI];
+#pragma unroll
+  for (int a = 0; a < RI; ++a) {
+    mx[a] = -INFINITY;
+    ls[a] = 0.f;
+    dl[a] = 0.f;
   }
+  const int sweeps = MODE == 2 ? 2 : 1;
+  for (int sweep = 0; sweep < sweeps; ++sweep) {
+    for (int c0 = 0; c0 < L; c0 += TK) {
+      __syncthreads();
+      for (int idx = t; idx < TK * d; idx += 256) {
+        const int r = idx / d, e = idx - r * d;
+        const bool ok = c0 + r < L;
+        B1[r][e] = ok ? sB1[base + (size_t)(c0 + r) * C + e] : 0.f;
+        B2[r][e] = ok ? sB2[base + (size_t)(c0 + r) * C + e] : 0.f;
+      }
+      if (MODE == 1 && t < TK) {
+        const int row = c0 + t;
+        const float* st = stats + (((size_t)b * H + hd) * L + (row < L ? row : 0)) * 3;
+        stB[0][t] = st[0];
+        stB[1][t] = 1.0f / st[1];
+        stB[2][t] = st[2];
+      }
+      __syncthreads();
+      // ---- score block: s = A1 . B1, dp = A2 . B2
+      float s[RI][RJ], dp[RI][RJ];
+#pragma unroll
+      for (int a = 0; a < RI; ++a)
+#pragma unroll
+        for (int c = 0; c < RJ; ++c) s[a][c] = dp[a][c] = 0.f;
+      for (int e = 0; e < d; ++e) {
+        float a1[RI], a2[RI], b1[RJ], b2[RJ];
+#pragma unroll
+        for (int a = 0; a < RI; ++a) {
+          a1[a] = A1[ti * RI + a][e];
+          a2[a] = A2[ti * RI + a][e];
+        }
+#pragma unroll
+        for (int c = 0; c < RJ; ++c) {
+          b1[c] = B1[tj * RJ + c][e];
+          b2[c] = B2[tj * RJ + c][e];
+        }
+#pragma unroll
+        for (int a = 0; a < RI; ++a)
+#pragma unroll
+          for (int c = 0; c < RJ; ++c) {
+            s[a][c] += a1[a] * b1[c];
+            if (!(MODE == 2 && sweep == 0)) dp[a][c] += a2[a] * b2[c];
+          }
+      }
+      if (MODE == 2) {
+#pragma unroll
+        for (int a = 0; a < RI; ++a)
+#pragma unroll
+          for (int c = 0; c < RJ; ++c) {
+            const bool okc = c0 + tj * RJ + c < L;
+            const float sv = s[a][c] * scale;
+            if (sweep == 0) {
+              if (okc) mx[a] = fmaxf(mx[a], sv);
+            } else if (okc) {
+              const float pu = __expf(sv - rowm[ti * RI + a]);
+              ls[a] += pu;
+              dl[a] += pu * dp[a][c];
+            }
+          }
+        continue;
+      }
+      // ---- dS (and P) tiles -> LDS
+#pragma unroll
+      for (int a = 0; a < RI; ++a)
+#pragma unroll
+        for (int c = 0; c < RJ; ++c) {
+          const int col = tj * RJ + c;
+          const bool okc = c0 + col < L;
+          const float m = MODE == 1 ? stB[0][col] : m_i[a];
+          const float il = MODE == 1 ? stB[1][col] : il_i[a];
+          const float de = MODE == 1 ? stB[2][col] : de_i[a];
+          const float pr = okc ? __expf(s[a][c] * scale - m) * il : 0.f;
+          DSs[ti * RI + a][col] = pr * (dp[a][c] - de) * scale;
+          if (MODE == 1) PSs[ti * RI + a][col] = pr;
+        }
+      __syncthreads();
+      // ---- second product: acc1[row][e] += sum_col dS[row][col] * B1[col][e]   (mode 1 also acc2 += P * B2)
+#pragma unroll
+      for (int a = 0; a < RI; ++a) {
+        const int row = ti * RI + a;
+        for (int col = 0; col < TK; ++col) {
+          const float dsv = DSs[row][col];
+          const float pv = MODE == 1 ? PSs[row][col] : 0.f;
+#pragma unroll
+          for (int c = 0; c < EC; ++c) {
+            const int e = tj + 16 * c;
+            acc1[a][c] += dsv * B1[col][e < DMAX ? e : 0];
+            if (MODE == 1) acc2[a][c] += pv * B2[col][e < DMAX ? e : 0];
+          }
+        }
+      }
+    }
+    if (MODE == 2) {   // reduce this sweep's row quantities across the 16 column threads (fixed order)
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < RI; ++a) {
+        red[0][ti * RI + a][tj] = sweep == 0 ? mx[a] : ls[a];
+        red[1][ti * RI + a][tj] = dl[a];
+      }
+      __syncthreads();
+      if (t < TQ) {
+        if (sweep == 0) {
+          float mm = -INFINITY;
+          for (int c = 0; c < 16; ++c) mm = fmaxf(mm, red[0][t][c]);
+          rowm[t] = mm;
+        } else {
+          float l = 0.f, dd = 0.f;
+          for (int c = 0; c < 16; ++c) {
+            l += red[0][t][c];
+            dd += red[1][t][c];
+          }
+          if (r0 + t < L) {
+            float* st = stats + (((size_t)b * H + hd) * L + r0 + t) * 3;
+            st[0] = rowm[t];
+            st[1] = l;
+            st[2] = dd / l;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (MODE == 2) return;
+#pragma unroll
+  for (int a = 0; a < RI; ++a) {
+    const int row = r0 + ti * RI + a;
+    if (row >= L) continue;
+#pragma unroll
+    for (int c = 0; c < EC; ++c) {
+      const int e = tj + 16 * c;
+      if (e < d) {
+        out1[base + (size_t)row * C + e] = acc1[a][c];
+        if (MODE == 1) out2[base + (size_t)row * C + e] = acc2[a][c];
+      }
+    }
+  }
+}
+
+template <int TQ, int TK, int DMAX>
+void launch_attn_bwd(const float* q, const float* k, const float* v, const float* dout, int B, int H, int L, int d, float scale, float* dq,
+                     float* dk, float* dv, float* stats, hipStream_t s) {
+  const dim3 grid((L + TQ - 1) / TQ, H, B);
+  hipLaunchKernelGGL((attn_bwd_tile_kernel<TQ, TK, DMAX, 2>), grid, dim3(256), 0, s, q, k, v, dout, stats, L, H, d, scale, nullptr, nullptr);
+  hipLaunchKernelGGL((attn_bwd_tile_kernel<TQ, TK, DMAX, 0>), grid, dim3(256), 0, s, q, k, v, dout, stats, L, H, d, scale, dq, nullptr);
+  hipLaunchKernelGGL((attn_bwd_tile_kernel<TQ, TK, DMAX, 1>), grid, dim3(256), 0, s, q, k, v, dout, stats, L, H, d, scale, dk, dv);
 }
 
 // ---------------------------------------------------------------------------------------------- per-pixel cross-attention backward
@@ -566,12 +643,17 @@ extern "C" int mvd_attention_backward(const float* q, const float* k, const floa
                 "mvd_attention_backward: dhead=%d must be a multiple of 4 and <= %d", dhead, AB_MAXD);
   MVD_CHECK_ARG(stats_floats >= (size_t)B * heads * L * 3, "mvd_attention_backward: stats workspace too small");
   MVD_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) & 15) == 0, "mvd_attention_backward: 16-byte alignment");
+  MVD_CHECK_ARG(B <= 65535 && heads <= 65535, "mvd_attention_backward: batch / heads exceed the grid limits");
   const float scale = 1.0f / sqrtf((float)dhead);
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((L + 3) / 4, heads, B);
-  hipLaunchKernelGGL(attn_bwd_stats_kernel, grid, dim3(256), 0, s, q, k, v, dout, L, heads, dhead, scale, stats);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, q, k, v, dout, stats, L, heads, dhead, scale, dq);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, q, k, v, dout, stats, L, heads, dhead, scale, dk, dv);
+  if (L <= 16 && dhead <= 48)            // the sequences over the V reference views of GridAttn
+    launch_attn_bwd<16, 16, 48>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
+  else if (dhead <= 48)
+    launch_attn_bwd<64, 32, 48>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
+  else if (dhead <= 96)
+    launch_attn_bwd<32, 32, 96>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
+  else
+    launch_attn_bwd<16, 16, 160>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
   MVD_CHECK_LAUNCH("mvd_attention_backward");
   return 0;
 }
