@@ -52,14 +52,15 @@ def col_sum(x, rows, cols):
 
 
 def _pow2_scale(t):
-    """Power of two that brings max|t| to [1024, 2048).  Gradients are small (1e-4 ... 1e-8): below 6e-5 the fp16 hi + lo operand
-    split only has an ABSOLUTE resolution of 2^-25 (include/mvd_hip.h, operand range contract), so they are scaled into the
-    normal range before the split and the GEMM undoes it exactly through its accumulator scale (as the packed weights do)."""
-    import math
-    mx = float(t.abs().max())
-    if not (mx > 0.0) or not math.isfinite(mx):
-        return 1.0
-    return 2.0 ** (10 - math.floor(math.log2(mx)))
+    """Device scalars (s, 1/s), s the power of two that brings max|t| to [1024, 2048).  Gradients are small (1e-4 ... 1e-8): below 6e-5
+    the fp16 hi + lo operand split only has an ABSOLUTE resolution of 2^-25 (include/mvd_hip.h, operand range contract), so they are
+    scaled into the normal range before the split and the result is scaled back -- both exact (powers of two), both on the device:
+    no host synchronisation."""
+    mx = torch.linalg.vector_norm(t.reshape(-1), ord=float("inf")).float()
+    ok = torch.isfinite(mx) & (mx > 0)
+    e = torch.floor(torch.log2(torch.where(ok, mx, torch.ones_like(mx))))
+    s = torch.where(ok, torch.exp2(10.0 - e), torch.ones_like(mx))
+    return s, 1.0 / s
 
 
 def _planes_padded(x, cols):
@@ -73,20 +74,21 @@ def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True,
     M, N = dy.shape
     K = weight.shape[1]
     dev = dy.device
-    sc = _pow2_scale(dy)
+    sc, isc = _pow2_scale(dy)
     dys = dy * sc                                                             # exact (power of two)
     dx = None
     if need_dx:
         wt = hip.pack_linear(weight.detach().t().contiguous())                # (K, N): dX = dY W
-        wt.acc_scale /= sc
         dx_full = torch.empty(M, wt.N, dtype=torch.float32, device=dev)
         hip.gemm(_planes_padded(dys, N), wt, dx_full, prec=prec, bias=False, workspace=workspace)
+        dx_full *= isc
         dx = dx_full[:, :K]
     # dW = dY^T X : both operands activations, reduction over the M rows
     a = transpose_planes(dys, M, N)                                           # (ceil16(N), M) planes
     b = transpose_planes(x_planes, M, K, src_planes=True)                     # (ceil16(K), M) planes
     dw_full = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=dev)
-    hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M), acc_scale=1.0 / sc), dw_full, prec=prec, bias=False, workspace=workspace)
+    hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M)), dw_full, prec=prec, bias=False, workspace=workspace)
+    dw_full *= isc
     dW = dw_full[:N, :K]
     db = col_sum(dy, M, N) if need_db else None
     return dx, dW, db
@@ -100,23 +102,24 @@ def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, nee
     cin_p = x_planes.shape[-1] // 2
     dev = dy.device
     assert M == B * H * W and cin_p % 32 == 0 and cin_p >= Cin
-    sc = _pow2_scale(dy)
+    sc, isc = _pow2_scale(dy)
     dys = dy * sc
     dx = None
     if need_dx:
         # dX = conv3x3(dY, W') with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]  (full correlation with the rotated filter)
         wr = hip.pack_conv3x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous())
-        wr.acc_scale /= sc
         dx_full = torch.empty(M, wr.N, dtype=torch.float32, device=dev)
         hip.gemm(_planes_padded(dys, Cout), wr, dx_full, prec=prec, bias=False, workspace=workspace,
                  conv=dict(B=B, Hin=H, Win=W, Cin=_pad32(Cout), Hout=H, Wout=W, stride=1, upsample=0))
+        dx_full *= isc
         dx = dx_full[:, :Cin]
     a = transpose_planes(dys, M, Cout)                                        # (ceil16(Cout), M)
     ldo = _pad32(M)
     cols_t = torch.zeros(9 * cin_p, 2 * ldo, dtype=torch.int16, device=dev)     # (im2col X)^T, rows ci*9 + tap
     hip.check(hip.lib().mvd_im2col3x3_t_planes(hip.ptr(x_planes), B, H, W, cin_p, hip.ptr(cols_t), ldo, hip.stream()))
     dw_full = torch.empty(a.shape[0], 9 * cin_p, dtype=torch.float32, device=dev)
-    hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo, acc_scale=1.0 / sc), dw_full, prec=prec, bias=False, workspace=workspace)
+    hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo), dw_full, prec=prec, bias=False, workspace=workspace)
+    dw_full *= isc
     dW = dw_full[:Cout, :9 * Cin].reshape(Cout, Cin, 3, 3)
     db = col_sum(dy, M, Cout) if need_db else None
     return dx, dW, db

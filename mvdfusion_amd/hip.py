@@ -199,7 +199,8 @@ def pack_linear(weight, bias=None, geglu=False):
     if bias is not None:
         b = torch.zeros(Np, dtype=torch.float32, device=w.device)
         b[:N] = bias.detach().float()
-    torch.cuda.current_stream().synchronize()  # w may be a temporary
+    # (w may be a temporary: the pack kernel runs on torch's current stream, and the caching allocator re-uses a freed block only
+    #  for work enqueued later on that stream -- no host synchronisation needed)
     return PackedWeight(data, Np, Kp, N, b, geglu, acc_scale=1.0 / scale)
 
 
@@ -220,7 +221,6 @@ def pack_conv3x3(weight, bias=None):
     if bias is not None:
         b = torch.zeros(Np, dtype=torch.float32, device=w.device)
         b[:Cout] = bias.detach().float()
-    torch.cuda.current_stream().synchronize()
     return PackedWeight(data, Np, 9 * cin_pad, Cout, b, conv_cin=cin_pad, acc_scale=1.0 / scale)
 
 
