@@ -11,6 +11,6 @@ Parity pinning: the reference has no tests / golden vectors of its own (SURVEY.m
 restatement in ``oracle/ref_torch.py`` is pinned against the reference *itself*, imported in the build
 container from ``/root/reference`` by ``oracle/make_golden.py`` (third-party deps that are absent from
 the reference tree -- pytorch3d, timm, omegaconf -- are restated in ``oracle/shims.py``; their algebra
-is pinned by the known-answer tests in ``tests/test_oracle_known_answers.py``).  The resulting input /
+is pinned by the known-answer tests in ``tests/test_cpu_oracle_and_host.py`` (test_kat_*)).  The resulting input /
 output vectors are committed under ``tests/golden/`` and are what the GPU box checks against.
 """

@@ -6,7 +6,7 @@ file:line it restates.  No pytorch3d / timm / omegaconf dependency: the camera a
 closed form (pinned against the reference import by oracle/make_golden.py and by the known-answer tests).
 
 Parity status: PINNED -- checked against the imported reference on the fixtures under tests/golden/
-(tests/test_oracle_vs_golden.py, tolerance 1e-5 relative-to-max per tensor).
+(tests/test_cpu_oracle_and_host.py, tolerance 1e-5 relative-to-max per tensor).
 """
 import math
 
