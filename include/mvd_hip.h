@@ -200,7 +200,7 @@ int mvd_layernorm(const float* x, void* y_sp, float* y_f32, const float* w, cons
 /* ------------------------------------------------------------------------------------------------
  * Self-attention over the tokens of one view (CrossAttention with context=None, attention.py:170-193).
  * Operand planes are written by mvd_gemm(MVD_EPI_QKV):
- *   q/k : [B][heads][Lpad][dq]   16-bit hi/lo planes, dq = roundup(dhead, 32), zero padded, q pre-scaled by
+ *   q/k : [B][heads][Lpad][dq]   16-bit hi/lo planes, dq = roundup(dhead, 16), zero padded (32-channel MFMA steps + one 16-channel tail step), q pre-scaled by
  *                                dhead^-0.5 * log2(e) (mvd_gemm_desc.qscale): the softmax is evaluated with exp2
  *   vt  : [B][heads][dv][Lpad]   16-bit hi/lo planes, dv = roundup(dhead, 16)   (V transposed: keys contiguous)
  * out : (B*L, ldo) split planes, head-major channels ('b n (h d)'): feeds the to_out GEMM. */

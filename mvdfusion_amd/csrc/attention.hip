@@ -27,7 +27,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
   constexpr int NPL = NS >= 3 ? 2 : 1;
   constexpr int KP = DQ + 8;       // LDS pitch of a K row (16-bit elements)
   constexpr int VP = KV_TILE + 8;  // LDS pitch of a V^T row
-  constexpr int QS = DQ / 32;      // MFMA k-steps over the head dim
+  constexpr int QS = DQ / 32;      // full MFMA k-steps (32 channels) over the head dim
+  constexpr bool TAIL = (DQ % 32) != 0;   // + one 16-deep step: head dims 40 -> 48 = 32 + 16, 80 = 64 + 16, 4 -> 16 (no padding to 32 / 64)
+  static_assert(DQ % 16 == 0, "q / k rows are padded to a multiple of 16 channels");
   constexpr int DT = DV / 16;      // output d-tiles
   constexpr int KCH = KV_TILE * DQ / 8;            // 16-byte chunks of a K tile (per plane)
   constexpr int VCH = DV * 8;                      // 16-byte chunks of a V^T tile (per plane)
@@ -55,7 +57,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
   const u16* vp[2] = {vt_hi + bh * DV * Lpad, vt_lo + bh * DV * Lpad};
 
   bool active[QT];
-  op16x8 qh[QT][QS], ql[QT][QS];
+  op16x8 qh[QT][QS > 0 ? QS : 1], ql[QT][QS > 0 ? QS : 1];
+  op4_t qth[QT], qtl[QT];              // the 16-channel tail of the query rows
 #pragma unroll
   for (int t2 = 0; t2 < QT; ++t2) {
     active[t2] = q0 + 16 * t2 < L;
@@ -65,6 +68,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
     for (int ks = 0; ks < QS; ++ks) {
       qh[t2][ks] = inb ? *(const op16x8*)(q_hi + qoff + ks * 32) : (op16x8){0, 0, 0, 0, 0, 0, 0, 0};
       if (NS >= 3) ql[t2][ks] = inb ? *(const op16x8*)(q_lo + qoff + ks * 32) : (op16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    if (TAIL) {      // channels 32 QS + 4g .. + 3 (qoff carries 8g: the tail slice starts at 4g)
+      const size_t toff = (bh * Lpad + q0 + 16 * t2 + c) * DQ + QS * 32 + g * 4;
+      qth[t2] = inb ? *(const op4_t*)(q_hi + toff) : (op4_t){0, 0, 0, 0};
+      if (NS >= 3) qtl[t2] = inb ? *(const op4_t*)(q_lo + toff) : (op4_t){0, 0, 0, 0};
     }
   }
   f32x4 o[QT][DT];
@@ -141,6 +149,29 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
           }
           s[kt] = MVD_MFMA_16x16x32(kh, qh[t2][ks], s[kt], 0, 0, 0);
         }
+      }
+      // the 16-channel tail as its own pass over the four key sub-tiles: consecutive MFMAs hit different accumulators.  (Issued right
+      // behind the last 16x16x32 step of the SAME accumulator, the 16x16x16 MFMA read a stale value in the one-product (NS = 1)
+      // 80-channel instantiation -- tests/test_gpu_ops.py::test_qkv_gemm_and_attention[2-8-256-80-1].)
+      if (TAIL) {
+        op4_t kh4[4], kl4[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          kh4[kt] = *(const op4_t*)&sK[buf][0][kt * 16 + c][QS * 32 + g * 4];
+          if (NS >= 3) kl4[kt] = *(const op4_t*)&sK[buf][NPL - 1][kt * 16 + c][QS * 32 + g * 4];
+        }
+        if (NS == 4) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) s[kt] = MVD_MFMA_16x16x16(kl4[kt], qtl[t2], s[kt]);
+        }
+        if (NS >= 3) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) s[kt] = MVD_MFMA_16x16x16(kl4[kt], qth[t2], s[kt]);
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) s[kt] = MVD_MFMA_16x16x16(kh4[kt], qtl[t2], s[kt]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt] = MVD_MFMA_16x16x16(kh4[kt], qth[t2], s[kt]);
       }
       // ---- online softmax (per query column c; keys are spread over registers and the 4 lane groups)
       // (q carries dhead^-0.5 * log2(e) from the QKV epilogue, so the scores are base-2 logits: exp2 below is a bare v_exp_f32)
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(256) void view_pool_kernel(const float* __restrict_
 template <int NS>
 int launch_attn(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi, const void* vt_lo,
                 void* out_sp, int ldo, int B, int H, int L, int Lk, int Lpad, int dhead, hipStream_t s) {
-  const int dq = (dhead + 31) & ~31, dv = (dhead + 15) & ~15;
+  const int dq = mvd_attn_dpad(dhead), dv = mvd_attn_dpad(dhead);
   // two query tiles per wavefront once that still leaves >= 2 workgroups per CU (long sequences); small heads only
   const long wg2 = (long)((Lpad + 127) / 128) * H * B;
   const bool two = dq <= 96 && wg2 >= 512;
@@ -412,11 +443,11 @@ int launch_attn(const void* q_hi, const void* q_lo, const void* k_hi, const void
                          ldo, H, L, Lk, Lpad, dhead);                                                                    \
     return 0;                                                                                                            \
   }
-  MVD_ATTN_CASE(32, 16)
+  MVD_ATTN_CASE(16, 16)
   MVD_ATTN_CASE(32, 32)
-  MVD_ATTN_CASE(64, 48)
+  MVD_ATTN_CASE(48, 48)
   MVD_ATTN_CASE(64, 64)
-  MVD_ATTN_CASE(96, 80)
+  MVD_ATTN_CASE(80, 80)
   MVD_ATTN_CASE(160, 160)
 #undef MVD_ATTN_CASE
   return -1;
@@ -426,10 +457,10 @@ int launch_attn(const void* q_hi, const void* q_lo, const void* k_hi, const void
 
 extern "C" int mvd_attn_lpad(int L) { return (L + 63) & ~63; }
 extern "C" size_t mvd_attn_qk_plane_elems(int B, int heads, int L, int dhead) {
-  return (size_t)B * heads * mvd_attn_lpad(L) * ((dhead + 31) & ~31);
+  return (size_t)B * heads * mvd_attn_lpad(L) * mvd_attn_dpad(dhead);
 }
 extern "C" size_t mvd_attn_vt_plane_elems(int B, int heads, int L, int dhead) {
-  return (size_t)B * heads * mvd_attn_lpad(L) * ((dhead + 15) & ~15);
+  return (size_t)B * heads * mvd_attn_lpad(L) * mvd_attn_dpad(dhead);
 }
 
 extern "C" int mvd_attention(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,

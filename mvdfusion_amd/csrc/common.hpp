@@ -17,6 +17,17 @@ typedef _Float16 op_t;
 #define MVD_OPERAND_FORMAT 0xf16
 #endif
 typedef __attribute__((ext_vector_type(8))) op_t op16x8;   // 8 MFMA operand elements (fp16 or bf16: MVD_OPERAND_F16)
+// the 16-deep MFMA (k = 16: lane group g = lane >> 4 holds k = 4g .. 4g + 3): attention over short sequences, 16-wide head-dim tails
+#ifdef MVD_OPERAND_BF16
+typedef __attribute__((ext_vector_type(4))) short op4_t;     // mfma_f32_16x16x16bf16_1k takes 4 x i16
+#define MVD_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+#else
+typedef __attribute__((ext_vector_type(4))) _Float16 op4_t;
+#define MVD_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0)
+#endif
+// head-dim padding of the attention operand planes: q / k rows and V^T row counts are rounded up to 16 (one MFMA k-step of 32 per full
+// 32 channels plus a 16-deep tail step)
+__host__ __device__ inline int mvd_attn_dpad(int dhead) { return (dhead + 15) & ~15; }
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short u16;
 

@@ -79,7 +79,7 @@ __device__ __forceinline__ float epi_store_elem(const mvd_gemm_desc& d, int m, i
     const int tok = m - b * d.L;
     if (which == 0) v *= d.qscale;
     if (which < 2) {
-      const int dq = (d.dhead + 31) & ~31;
+      const int dq = mvd_attn_dpad(d.dhead);
       const size_t idx = ((size_t)(b * d.heads + head) * d.Lpad + tok) * dq + dd;
       store_planes1((u16*)(which == 0 ? d.q_hi : d.k_hi), (u16*)(which == 0 ? d.q_lo : d.k_lo), idx, v);
     } else {
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const int C = d.heads * d.dhead;
     const int which = wn0 / C;
     if (which < 2) {
-      const int dq = (d.dhead + 31) & ~31;
+      const int dq = mvd_attn_dpad(d.dhead);
       u16* ph = (u16*)(which == 0 ? d.q_hi : d.k_hi);
       u16* pl = (u16*)(which == 0 ? d.q_lo : d.k_lo);
 #pragma unroll

@@ -31,14 +31,6 @@ constexpr int G4_VEC_MISC = 3 * G4_VEC_BLOCK;          // b_pre 256 | weight_lay
 constexpr int G4_VEC_GRANULES = 44;                    // 44 KiB staged (11264 floats; 11008 used)
 constexpr int G4_SMEM = G4_RING_SLOTS * G4_SLOT_BYTES + G4_VEC_GRANULES * 1024;
 
-#ifdef MVD_OPERAND_BF16
-typedef __attribute__((ext_vector_type(4))) short op4_t;     // mfma_f32_16x16x16bf16_1k takes 4 x i16
-#define MVD_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
-#else
-typedef __attribute__((ext_vector_type(4))) _Float16 op4_t;
-#define MVD_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0)
-#endif
-
 struct G4Params {
   const float *x, *depth_noise, *steps;
   const int* iter;
