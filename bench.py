@@ -240,11 +240,20 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--gn-two-pass", action="store_true", help="A/B: GroupNorm statistics by their own kernels instead of the producers")
+    ap.add_argument("--train-step", action="store_true",
+                    help="instead of the denoising metric: time the TRAINING step (BASELINE configs[4] per GPU: fwd + bwd + AdamW on one "
+                         "scene of --views views, --depth-samples samples; tools/bench_train.py) and print its JSON line")
     ap.add_argument("--tune-cache", default=None, help="JSON file with the GEMM autotuner's choices: loaded if it exists (no "
                     "re-tuning: identical kernels across the bench run and the rocprofv3 passes), written after warm-up otherwise")
     ap.add_argument("--shard-emulate", default=None, metavar="r/N",
                     help="single GPU: also time the work of rank r of an N-way view-parallel job (Vq = V/N query views)")
     a = ap.parse_args()
+    if a.train_step:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_train
+        sys.argv = [sys.argv[0], "--views", str(a.views or 8), "--depth-samples", str(a.depth_samples if a.depth_samples > 1 else 3),
+                    "--steps", str(min(a.steps, 5))]
+        return bench_train.main()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
