@@ -68,7 +68,7 @@ def _planes_padded(x, cols):
     return hip.split_planes(x.contiguous(), ldp=_pad32(cols))
 
 
-def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True, prec=hip.PREC_X4):
+def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True, prec=hip.PREC_X4, need_dw=True):
     """y = x W^T + b  (nn.Linear / 1x1 conv).  x_planes: the forward's A operand, split planes (M, 2*ceil32(K)); weight (N, K) fp32;
     dy (M, N) fp32.  Returns (dx (M, K) | None, dW (N, K), db (N) | None)."""
     M, N = dy.shape
@@ -83,18 +83,20 @@ def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True,
         hip.gemm(_planes_padded(dys, N), wt, dx_full, prec=prec, bias=False, workspace=workspace)
         dx_full *= isc
         dx = dx_full[:, :K]
-    # dW = dY^T X : both operands activations, reduction over the M rows
-    a = transpose_planes(dys, M, N)                                           # (ceil16(N), M) planes
-    b = transpose_planes(x_planes, M, K, src_planes=True)                     # (ceil16(K), M) planes
-    dw_full = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=dev)
-    hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M)), dw_full, prec=prec, bias=False, workspace=workspace)
-    dw_full *= isc
-    dW = dw_full[:N, :K]
+    dW = None
+    if need_dw:                                                               # (frozen parameters: only the dgrad is needed)
+        # dW = dY^T X : both operands activations, reduction over the M rows
+        a = transpose_planes(dys, M, N)                                       # (ceil16(N), M) planes
+        b = transpose_planes(x_planes, M, K, src_planes=True)                 # (ceil16(K), M) planes
+        dw_full = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=dev)
+        hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M)), dw_full, prec=prec, bias=False, workspace=workspace)
+        dw_full *= isc
+        dW = dw_full[:N, :K]
     db = col_sum(dy, M, N) if need_db else None
     return dx, dW, db
 
 
-def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, need_db=True, prec=hip.PREC_X4):
+def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, need_db=True, prec=hip.PREC_X4, need_dw=True):
     """y = conv3x3(x), stride 1, padding 1, channels-last.  x_planes: the forward's A operand (B*H*W, 2*ceil32(Cin)) split planes;
     weight (Cout, Cin, 3, 3) fp32; dy (B*H*W, Cout) fp32.  Returns (dx (M, Cin) | None, dW (Cout, Cin, 3, 3), db | None)."""
     M, Cout = dy.shape
@@ -113,14 +115,16 @@ def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, nee
                  conv=dict(B=B, Hin=H, Win=W, Cin=_pad32(Cout), Hout=H, Wout=W, stride=1, upsample=0))
         dx_full *= isc
         dx = dx_full[:, :Cin]
-    a = transpose_planes(dys, M, Cout)                                        # (ceil16(Cout), M)
-    ldo = _pad32(M)
-    cols_t = torch.zeros(9 * cin_p, 2 * ldo, dtype=torch.int16, device=dev)     # (im2col X)^T, rows ci*9 + tap
-    hip.check(hip.lib().mvd_im2col3x3_t_planes(hip.ptr(x_planes), B, H, W, cin_p, hip.ptr(cols_t), ldo, hip.stream()))
-    dw_full = torch.empty(a.shape[0], 9 * cin_p, dtype=torch.float32, device=dev)
-    hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo), dw_full, prec=prec, bias=False, workspace=workspace)
-    dw_full *= isc
-    dW = dw_full[:Cout, :9 * Cin].reshape(Cout, Cin, 3, 3)
+    dW = None
+    if need_dw:
+        a = transpose_planes(dys, M, Cout)                                    # (ceil16(Cout), M)
+        ldo = _pad32(M)
+        cols_t = torch.zeros(9 * cin_p, 2 * ldo, dtype=torch.int16, device=dev)     # (im2col X)^T, rows ci*9 + tap
+        hip.check(hip.lib().mvd_im2col3x3_t_planes(hip.ptr(x_planes), B, H, W, cin_p, hip.ptr(cols_t), ldo, hip.stream()))
+        dw_full = torch.empty(a.shape[0], 9 * cin_p, dtype=torch.float32, device=dev)
+        hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo), dw_full, prec=prec, bias=False, workspace=workspace)
+        dw_full *= isc
+        dW = dw_full[:Cout, :9 * Cin].reshape(Cout, Cin, 3, 3)
     db = col_sum(dy, M, Cout) if need_db else None
     return dx, dW, db
 

@@ -21,9 +21,10 @@ class Tape:
     """Workspace + thin forward helpers shared by the block backwards (fresh tensors per call: the training path is not the
     allocation-free inference path)."""
 
-    def __init__(self, device, prec=hip.PREC_X4, workspace=None):
+    def __init__(self, device, prec=hip.PREC_X4, workspace=None, only_trainable=False):
         self.device = torch.device(device)
         self.prec = prec
+        self.only_trainable = only_trainable     # skip the weight gradients of frozen parameters (requires_grad False)
         self.ws = workspace if workspace is not None else torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.device)
 
     # ---- forward pieces
@@ -69,11 +70,22 @@ class Tape:
         return q, k, v, o
 
     # ---- backward pieces
-    def linear_bwd(self, a_planes, weight, dy, need_dx=True, need_db=True):
-        return bw.linear_backward(a_planes, weight, dy.contiguous(), self.ws, need_dx=need_dx, need_db=need_db, prec=self.prec)
+    def wants(self, weight):
+        """Whether the weight gradient of this parameter (or view of a parameter) has to be computed."""
+        if not self.only_trainable:
+            return True
+        base = weight._base if weight._base is not None else weight
+        return bool(weight.requires_grad or base.requires_grad)
 
-    def conv_bwd(self, a_planes, weight, dy, B, H, W):
-        return bw.conv3x3_backward(a_planes, weight, dy.contiguous(), B, H, W, self.ws, prec=self.prec)
+    def linear_bwd(self, a_planes, weight, dy, need_dx=True, need_db=True):
+        w = self.wants(weight)
+        return bw.linear_backward(a_planes, weight, dy.contiguous(), self.ws, need_dx=need_dx, need_db=need_db and w, prec=self.prec,
+                                  need_dw=w)
+
+    def conv_bwd(self, a_planes, weight, dy, B, H, W, need_dx=True):
+        w = self.wants(weight)
+        return bw.conv3x3_backward(a_planes, weight, dy.contiguous(), B, H, W, self.ws, need_dx=need_dx, need_db=w, prec=self.prec,
+                                   need_dw=w)
 
 
 def _c(t):
@@ -100,7 +112,8 @@ def resblock_backward(tape, rb, x, emb, dout, B, H, W):
     g = {}
     da2, g["out_layers.3.weight"], g["out_layers.3.bias"] = tape.conv_bwd(a2, conv2.weight, dout, B, H, W)
     dh1, g["out_layers.0.weight"], g["out_layers.0.bias"] = bw.groupnorm_backward(_c(h1), _c(da2), gn2.weight, gn2.bias, B, HW, Co, gn2.eps, True)
-    da1, g["in_layers.2.weight"], db1 = tape.conv_bwd(a1, conv1.weight, dh1, B, H, W)
+    da1, g["in_layers.2.weight"], _ = tape.conv_bwd(a1, conv1.weight, dh1, B, H, W)
+    db1 = bw.col_sum(_c(dh1), B * HW, Co)                                   # also the gradient of the time-embedding vector: always needed
     g["in_layers.2.bias"] = db1
     # the time-embedding vector is added per channel to every row: its gradient is the same column sum
     g["emb_layers.1.bias"] = db1.clone()
@@ -110,7 +123,7 @@ def resblock_backward(tape, rb, x, emb, dout, B, H, W):
     if has_skip:
         sk = rb.skip_connection
         dxs, dWs, g["skip_connection.bias"] = tape.linear_bwd(xp, sk.weight.reshape(Co, Ci), dout)
-        g["skip_connection.weight"] = dWs.reshape(sk.weight.shape)
+        g["skip_connection.weight"] = None if dWs is None else dWs.reshape(sk.weight.shape)
         dx = dx + dxs
     else:
         dx = dx + dout
@@ -176,7 +189,7 @@ def spatial_transformer_backward(tape, st, x, context, dout, B, H, W):
     # ---- backward
     g = {}
     dt3, dWo, g["proj_out.bias"] = tape.linear_bwd(t3p, w_out, dout)
-    g["proj_out.weight"] = dWo.reshape(st.proj_out.weight.shape)
+    g["proj_out.weight"] = None if dWo is None else dWo.reshape(st.proj_out.weight.shape)
     dt2 = _feed_forward_backward(tape, tb, t2, ln3, hff, gp, dt3, g, pre)
     # attn2 with one key: only to_v / to_out see a gradient; to_q, to_k and norm2 get exact zeros
     dvec = dt2.view(B, L, C).sum(1)                                            # (B, C)
@@ -190,7 +203,7 @@ def spatial_transformer_backward(tape, st, x, context, dout, B, H, W):
         g[pre + name] = torch.zeros_like(p)
     dt = _self_attention_backward(tape, tb, t, ln1, q, k, v, o, dt2, B, L, g, pre)
     dn, dWi, g["proj_in.bias"] = tape.linear_bwd(n, w_in, dt)
-    g["proj_in.weight"] = dWi.reshape(st.proj_in.weight.shape)
+    g["proj_in.weight"] = None if dWi is None else dWi.reshape(st.proj_in.weight.shape)
     dx, g["norm.weight"], g["norm.bias"] = bw.groupnorm_backward(_c(x), _c(dn), st.norm.weight, st.norm.bias, B, L, C, st.norm.eps, False)
     return dx + dout, g, dcontext
 

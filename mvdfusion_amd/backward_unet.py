@@ -11,8 +11,8 @@ block on the inference path, and chains the block backwards of backward_blocks.p
 Strided and upsampling convolutions reuse the stride-1 backward: a stride-2 conv's dgrad / wgrad equal the stride-1 ones on the
 zero-stuffed output gradient (Z[2i, 2j] = dY[i, j]); nearest-2x upsampling + conv is the stride-1 backward on the explicitly
 upsampled input followed by a 2x2 block sum.  The per-step vectors (time embedding MLP, cc_projection) are a few (1 x 128) / (V x 768)
-products: host glue in torch.  The gradient w.r.t. the volume features (the output of GridAttn) is returned -- GridAttn's own
-backward is not built yet.
+products: host glue in torch.  The gradient w.r.t. the volume features (the output of GridAttn) is returned: GridAttn's own
+backward continues from it (backward_gridattn.py).
 """
 import torch
 import torch.nn.functional as F
@@ -81,7 +81,7 @@ def unet_backward(unet, ctx, tape, record, dh, B, S, D, emb, t_sin, context, vol
         pre = names[id(blk)]
         if isinstance(blk[0], _StemConv):
             d = d + skip_grad.pop(0)
-            _, dW, db = bw.conv3x3_backward(x_in, blk[0].weight, d.contiguous(), B, H, W, tape.ws, need_dx=False, prec=tape.prec)
+            _, dW, db = tape.conv_bwd(x_in, blk[0].weight, d, B, H, W, need_dx=False)
             grads[pre + "0.weight"], grads[pre + "0.bias"] = dW, db
             continue
         is_input = pre.startswith("input_blocks.")

@@ -185,7 +185,7 @@ class _HipTrainingLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, batch, trainer_config, names, *params):
-        loss, grads = model.gradients(batch, trainer_config, noise_source=getattr(model, "_noise_source", None))
+        loss, grads = model.gradients(batch, trainer_config, noise_source=getattr(model, "_noise_source", None), only_trainable=True)
         ctx.grads = [grads.get(n) for n in names]
         ctx.shapes = [p.shape for p in params]
         return loss.clone()
@@ -440,11 +440,11 @@ class ViewFusion(nn.Module):
         return loss
 
     @torch.no_grad()
-    def unet_gradients(self, batch, trainer_config, noise_source=None):
+    def unet_gradients(self, batch, trainer_config, noise_source=None, only_trainable=False):
         """`loss.backward()` (train.py:90-95) through the WHOLE UNet and the per-step vector paths on the HIP backward kernels
         (mvdfusion_amd/backward_unet.py): gradients of every `unet_model.unet_model.*` and `cc_projection.*` parameter, plus the
-        gradient w.r.t. the volume features that GridAttn produced (GridAttn's own backward -- `view_attn.*`, `time_embed.*` -- is
-        not built yet).  Returns (loss, {state_dict key: gradient}, dvol (V, S, S, D, 768))."""
+        gradient w.r.t. the volume features that GridAttn produced (its own backward -- `view_attn.*`, `time_embed.*` -- continues
+        from there in `gradients`).  Returns (loss, {state_dict key: gradient}, dvol (V, S, S, D, 768))."""
         from . import backward_blocks as bb
         from . import backward_unet as bu
         unet = self.unet_model.unet_model
@@ -461,7 +461,7 @@ class ViewFusion(nn.Module):
         M = V * S * S
         emb = ctx.ws.get("temb.emb", (1, unet.model_channels * 4))
         t_sin = ctx.ws.get("vf.tsin_unet", (1, unet.model_channels))
-        tape = bb.Tape(dh.device, prec=ctx.prec, workspace=ctx.gemm_ws)
+        tape = bb.Tape(dh.device, prec=ctx.prec, workspace=ctx.gemm_ws, only_trainable=only_trainable)
         dh_rows = dh.permute(0, 2, 3, 1).reshape(M, mc).contiguous()
         context = eng.context[:V].clone()
         g, dcontext, dvol = bu.unet_backward(unet, ctx, tape, record, dh_rows, V, S, D, emb, t_sin, context, eng.vol.view(V, S, S, D, -1))
@@ -474,18 +474,18 @@ class ViewFusion(nn.Module):
         return loss, grads, dvol
 
     @torch.no_grad()
-    def gradients(self, batch, trainer_config, noise_source=None):
+    def gradients(self, batch, trainer_config, noise_source=None, only_trainable=False):
         """The complete `loss.backward()` of train.py:90-95 on the HIP path: unet_gradients continued through GridAttn
         (mvdfusion_amd/backward_gridattn.py: final layer, softmax-over-V pooling, 3 DiT blocks, pre layer, grid_sample backward,
-        z-embedding) and ViewFusion.time_embed.  Returns (loss, {state_dict key: gradient}) for every trainable parameter the loss
-        depends on."""
+        z-embedding) and ViewFusion.time_embed.  Returns (loss, {state_dict key: gradient}) for every parameter the loss depends on;
+        with only_trainable the weight gradients of frozen parameters (requires_grad False) are skipped (None) -- their dgrad still runs."""
         from . import backward_blocks as bb
         from . import backward_gridattn as bg
-        loss, grads, dvol = self.unet_gradients(batch, trainer_config, noise_source=noise_source)
+        loss, grads, dvol = self.unet_gradients(batch, trainer_config, noise_source=noise_source, only_trainable=only_trainable)
         V, S, _, D, _ = dvol.shape
         eng = self.engine(V, S, D, False)
         ctx = eng.ctx
-        tape = bb.Tape(dvol.device, prec=ctx.prec, workspace=ctx.gemm_ws)
+        tape = bb.Tape(dvol.device, prec=ctx.prec, workspace=ctx.gemm_ws, only_trainable=only_trainable)
         c = ctx.ws.get("vf.c", (1, 256))
         g, dc = bg.gridattn_backward(self.view_attn, tape, eng, c, dvol.reshape(V * S * S * D, -1).contiguous(), V, S, D)
         grads.update({"view_attn." + k: v for k, v in g.items()})
