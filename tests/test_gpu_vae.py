@@ -352,6 +352,20 @@ def test_training_all_gradients_vs_reference_golden():
     assert not bad, bad[:10]
 
 
+def test_training_backward_is_bit_reproducible():
+    """Two evaluations of the whole backward on the same batch and draws give bit-identical gradients: every reduction runs in a
+    fixed order (split-K slices, fp64 column sums, LDS-tiled attention backward) or through integer atomics (GroupNorm statistics,
+    grid_sample backward)."""
+    gd = load_golden("train_grads_mc32_v4_d3")
+    m, batch, tc, draws = _training_setup(gd)
+    l1, g1 = m.gradients(batch, tc, noise_source=draws)
+    g1 = {k: v.clone() for k, v in g1.items()}
+    l2, g2 = m.gradients(batch, tc, noise_source=draws)
+    assert torch.equal(l1, l2) and set(g1) == set(g2)
+    diff = [k for k in g1 if not torch.equal(g1[k], g2[k])]
+    assert not diff, diff[:10]
+
+
 def test_training_loop_drop_in_loss_backward_optimizer_step():
     """The reference's training loop verbatim (train.py:86-95): ``loss = model(batch, cfg); optimizer.zero_grad(); loss.backward();
     optimizer.step()`` with the optimizer of configure_optimizers (AdamW).  `.grad` of every parameter after loss.backward() equals
