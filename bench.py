@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_16BIT_DENSE_PEAK = 2.5e15  # FLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (dense; not the 2:1-sparse figure)
 HBM_PEAK = 8.0e12               # B/s (spec; ~6.3 TB/s achievable), same guide
-ROUND = "r02"
+ROUND = "r03"
 
 
 def log(*a):
@@ -226,6 +226,25 @@ def workload_label(V, S, D, N, cfg_scale):
             "SD1.x UNet 320ch + 10 view-aligned transformers + GridAttn, random-init (deterministic fill) weights")
 
 
+def spawn_ranks(n):
+    """Re-launch this command as n ranks under torch.distributed.run (one process per GPU, RCCL over xGMI)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs on this node, found {ndev}; refusing to measure fewer devices than requested",
+              file=sys.stderr, flush=True)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,6 +258,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (0 = all host cores)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the V=8 x 256^2 single-GPU workload (north-star 1-GPU target) "
+                    "that the default N=1 run times in the same process")
     ap.add_argument("--gn-two-pass", action="store_true", help="A/B: GroupNorm statistics by their own kernels instead of the producers")
     ap.add_argument("--train-step", action="store_true",
                     help="instead of the denoising metric: time the TRAINING step (BASELINE configs[4] per GPU: fwd + bwd + AdamW on one "
@@ -255,11 +276,21 @@ def main():
                     "--steps", str(min(a.steps, 5))]
         return bench_train.main()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU, RCCL) -- never measure one GPU and call it N
+        return spawn_ranks(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % torch.cuda.device_count()       # (functional testing of the N>1 path on one GPU)
+    ndev = torch.cuda.device_count()
+    if world > 1 and a.gpus > 1 and a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if world > ndev and not os.environ.get("MVD_DIST_SHARE_GPU"):
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node has {ndev} "
+                         "(MVD_DIST_SHARE_GPU=1 lets ranks share devices for functional tests only)")
+    local = local % ndev
     torch.cuda.set_device(local)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MVD_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
@@ -319,6 +350,7 @@ def main():
         out = {
             "metric": "denoising-steps/sec", "value": a.steps / dt, "unit": "steps/s", "n_gpus": N, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "rccl_ranks": world if backend == "nccl" else 0,
             "scaling": "strong" if N > 1 else "weak", "vs_baseline": None,
             "dtype": {"f16x4": "f16x4 (fp16 MFMA operands split hi+lo, all 4 partial products, fp32 accumulate)",
                       "f16x3": "f16x3 (fp16 MFMA operands split hi+lo, 3 products, fp32 accumulate)",
@@ -417,6 +449,22 @@ def main():
             cb, _ = cpu_baseline(sd, V, S, D, cfg_scale, n_timed=a.cpu_steps, threads=a.cpu_threads)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        if not a.no_secondary and (V, S, D) == (4, 32, 1):
+            # BASELINE.json north_star's 1-GPU target workload (8 views x 256^2 x 50 DDIM steps), timed in this same process
+            V2 = 8
+            eng2, *_ = prepare(m, V2, S, D, cfg_scale)
+            dt2, gms2 = timed_run(eng2, None)
+            T2 = V2 * V2 * S * S * D
+            fl2 = 2 * V2 * f_unet + T2 * (3516416 + 3072 * V2) + V2 * S * S * D * 393216 + (V2 + 1) * S * S * 2560
+            sec = {"workload": workload_label(V2, S, D, 1, cfg_scale), "value": a.steps / dt2, "unit": "steps/s", "steps": a.steps,
+                   "warmup": a.warmup, "ms_per_step": dt2 * 1e3 / a.steps, "gpu_ms_per_step_hip_events": gms2,
+                   "algorithmic_tflops": fl2 / (dt2 / a.steps) / 1e12, "frac_of_dense_16bit_peak": fl2 / (dt2 / a.steps) / MFMA_16BIT_DENSE_PEAK}
+            del eng2
+            if not a.no_cpu_baseline:
+                cb2, _ = cpu_baseline(sd, V2, S, D, cfg_scale, n_timed=2, threads=a.cpu_threads)
+                sec["cpu_baseline"] = cb2
+                sec["speedup_vs_cpu_baseline"] = sec["value"] / cb2["value"]
+            out["secondary"] = sec
     else:
         # view-parallel speed-up reference: the same V-view workload on ONE GPU (rank 0), unsharded
         if rank == 0:
@@ -441,4 +489,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

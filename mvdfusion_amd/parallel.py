@@ -35,14 +35,18 @@ class ViewExchange:
                              "would own no view")
         self.uniform = len({n for _, n in self.ranges}) == 1
 
-    def gather(self, x_full):
-        """x_full (V, ...) holds this rank's fresh rows at [q0, q0+Vq); on return every rank holds all rows."""
-        if self.world == 1:
+    def gather(self, x_full, force=False):
+        """x_full (V, ...) holds this rank's fresh rows at [q0, q0+Vq); on return every rank holds all rows.
+
+        Uniform shards: ONE in-place all-gather -- the send buffer is this rank's own slice of the receive buffer (RCCL's
+        in-place form: sendbuff == recvbuff + rank * count), enqueued behind the step's kernels on the compute stream's
+        dependency chain; no staging copy, nothing on the host's critical path.  `force` runs the collective even in a
+        one-rank group (exercises the RCCL code path on a single GPU)."""
+        if self.world == 1 and not (force and dist.is_initialized()):
             return x_full
-        mine = x_full[self.q0:self.q0 + self.Vq].clone()
+        assert x_full.is_contiguous()
         if self.uniform:
-            outs = [x_full[a:a + n] for a, n in self.ranges]      # views: the collective writes in place
-            dist.all_gather(outs, mine, group=self.group)
+            dist.all_gather_into_tensor(x_full, x_full[self.q0:self.q0 + self.Vq], group=self.group)
         else:                                                      # ragged: broadcast each block from its owner
             for r, (a, n) in enumerate(self.ranges):
                 if n:
@@ -51,18 +55,18 @@ class ViewExchange:
         return x_full
 
 
-def run_view_parallel(x_T, n_steps, local_step, exchange):
+def run_view_parallel(x_T, n_steps, local_step, exchange, force_collective=False):
     """Generic loop: `local_step(i, x_full) -> None` must update rows [q0, q0+Vq) of x_full in place."""
     x = x_T
     for i in range(n_steps):
         local_step(i, x)
-        exchange.gather(x)
+        exchange.gather(x, force=force_collective)
     return x
 
 
 @torch.no_grad()
 def sample_view_parallel(model, batch_cameras, input_latents, input_cameras, clip_embed, cfg_scale, x_T, depth_noise,
-                         ddim_noise, num_steps=None, use_graph=True, group=None):
+                         ddim_noise, num_steps=None, use_graph=True, group=None, force_collective=False):
     """DDIMSampler.sample with the views sharded over the ranks of `group` (one process per GPU, RCCL)."""
     from .engine import ddim_step_table
     samp = model.ddim
@@ -80,5 +84,5 @@ def sample_view_parallel(model, batch_cameras, input_latents, input_cameras, cli
     def local_step(i, x):
         eng.step(cfg_scale, do_update=True, use_graph=use_graph)
 
-    run_view_parallel(eng.x, n_run, local_step, ex)
+    run_view_parallel(eng.x, n_run, local_step, ex, force_collective=force_collective)
     return eng.x.clone()

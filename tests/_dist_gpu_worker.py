@@ -30,7 +30,8 @@ def main():
     inp = syn.make_inputs(V, S, seed=4)
     dn, sn = syn.step_noise(V, S, D, 50, seed=4)              # every rank draws the FULL noise from the same seed
     x = sample_view_parallel(m, inp["batch_cameras"], inp["input_latents"], inp["input_cameras"], inp["clip_v_embed"], 2.5,
-                             inp["x_T"].cuda(), dn, sn, num_steps=steps, use_graph=True)
+                             inp["x_T"].cuda(), dn, sn, num_steps=steps, use_graph=True,
+                             force_collective=world == 1)      # one-rank RCCL job: still run the all-gather
     torch.cuda.synchronize()
     # every rank must hold the same full latent tensor after the last exchange
     ref = x.clone()

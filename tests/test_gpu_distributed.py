@@ -22,9 +22,9 @@ def _free_port():
     return p
 
 
-def _run(backend, V, steps, worker="_dist_gpu_worker.py"):
+def _run(backend, V, steps, worker="_dist_gpu_worker.py", nproc=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", worker), backend, str(V), str(steps)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     recs, dec, pos = [], json.JSONDecoder(), 0          # (the two ranks' lines may interleave on one line)
@@ -78,3 +78,29 @@ def test_two_rank_ddp_training_step():
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         json.dump({"backend": used, "records": recs}, open(os.path.join(out, "dist_ddp_2rank_one_gpu.json"), "w"))
+
+
+def test_rccl_one_rank_view_parallel():
+    """RCCL itself (backend "nccl", device_id bound) carries the view-parallel job: a ONE-rank process group on this box's GPU runs
+    sample_view_parallel with the in-place all-gather of ViewExchange forced on after every captured step -- no gloo fallback here."""
+    r, recs = _run("nccl", 4, 3, nproc=1)
+    assert r.returncode == 0 and len(recs) == 1, (r.stderr[-3000:], r.stdout[-1500:])
+    rec = recs[0]
+    assert rec["backend"] == "nccl" and rec["replicas_identical"] and rec["finite"]
+    assert rec["rmse"] < 1e-5 and rec["max_abs_diff"] < 1e-4, rec
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"backend": "nccl", "world": 1, "records": recs}, open(os.path.join(out, "dist_rccl_1rank.json"), "w"))
+
+
+def test_rccl_one_rank_ddp_training_step():
+    """The DDP-wrapped training step (train.py:38, 86-95) over RCCL with a one-rank group: DDP's bucketed all-reduce runs through RCCL
+    and leaves the gradients equal to the local ones."""
+    r, recs = _run("nccl", 0, 0, worker="_dist_ddp_worker.py", nproc=1)
+    assert r.returncode == 0 and len(recs) == 1, (r.stderr[-3000:], r.stdout[-1500:])
+    x = recs[0]
+    assert x["backend"] == "nccl" and x["max_rel_err_vs_mean_of_local_grads"] < 1e-5 and x["n_grads"] >= 300, x
+    assert abs(x["loss_local"] - x["loss_ddp"]) < 1e-6
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"backend": "nccl", "world": 1, "records": recs}, open(os.path.join(out, "dist_ddp_rccl_1rank.json"), "w"))
