@@ -231,16 +231,13 @@ _CACHE_ATTRS = ("_p", "_pg", "_temb", "_xattn", "_head", "_pq", "_q", "_fused")
 
 
 def params_signature(module):
-    """Cheap fingerprint of a module's parameters: changes when any parameter is updated in place (load_state_dict,
-    optimizer step, fill) or re-allocated (.cuda() / .to()).  The packed MFMA operand images are derived from the
-    fp32 parameters; the owners compare this before (re)using them."""
-    ver, ptr_ = 0, 0
-    for p in module.parameters():
-        ver += p._version
-        ptr_ ^= p.data_ptr()
-    for b in module.buffers():
-        ptr_ ^= b.data_ptr()
-    return ver, ptr_
+    """Fingerprint of a module's parameters: one (storage pointer, autograd version) pair PER tensor, hashed as a tuple -- no
+    sum / xor that two changes could cancel.  It changes when any parameter is updated in place through autograd-visible ops
+    (load_state_dict, optimizer steps, fill_) or re-allocated (.cuda() / .to()).  Writes through ``p.data`` (``p.data.copy_``,
+    EMA swaps via ``.data``, ``torch._foreach_*`` on ``.data``) bump no version and keep the pointer: they are invisible here by
+    construction, and ``ViewFusion.invalidate_packed()`` is MANDATORY after them (ViewFusion.load_state_dict / _apply call it
+    themselves).  The packed MFMA operand images are derived from the fp32 parameters; their owners compare this before reuse."""
+    return hash(tuple((p.data_ptr(), p._version) for p in module.parameters()) + tuple(b.data_ptr() for b in module.buffers()))
 
 
 def drop_packed_caches(module):

@@ -3,7 +3,7 @@
 
 Drop-in surface kept: constructor kwargs (unknown keys ignored, :41), ``apply_model`` (:282), ``sample`` (:348),
 ``embed_time`` (:276), ``prepare_batch`` (:165), ``encode``/``decode`` (:157-163), ``forward``/``p_losses`` (:362-397
--- inference-side forward only in this round), ``configure_optimizers`` (:399), ``_print_parameter_count`` (:134),
+-- the training loss with a hand-written HIP backward behind torch autograd), ``configure_optimizers`` (:399), ``_print_parameter_count`` (:134),
 ``.ddim`` (DDIMSampler), ``.scheduler``; state_dict keys ``view_attn.*``, ``unet_model.unet_model.*``,
 ``cc_projection.{0,2,4}``, ``time_embed.{0,2}``, ``scheduler.*`` (+ ``vae.*`` / ``clip_image_encoder.*`` when those
 host-side PyTorch modules are plugged in -- they are outside the hot path).
@@ -269,6 +269,21 @@ class ViewFusion(nn.Module):
         """Drop every packed weight image, captured graph and engine: they are rebuilt from the live fp32 parameters."""
         hip.drop_packed_caches(self)
         self._engines.clear()
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """nn.Module.load_state_dict, then drop every derived packed weight / engine / graph (demo.py:165, train.py:144-153)."""
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.invalidate_packed()
+        self._packed_sig = None
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        """.cuda() / .to() / .float(): parameters move, so every derived packed image is stale."""
+        r = super()._apply(fn, *a, **kw)
+        if "_engines" in self.__dict__:
+            self.invalidate_packed()
+            self._packed_sig = None
+        return r
 
     def engine(self, V, S, D, cfg, q0=0, Vq=None):
         sig = hip.params_signature(self)

@@ -458,3 +458,34 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert hip.lib().mvd_packed_weight_bytes(320, 2880) == 320 * 2880 * 4
     assert hip.lib().mvd_attn_lpad(1000) == 1024
     assert ctypes.sizeof(hip.GemmDesc) > 0
+
+
+def test_params_signature_tracks_updates_and_does_not_cancel():
+    """hip.params_signature (the guard of every packed-weight / engine / graph cache): per-tensor (pointer, version) pairs, so
+    in-place updates, re-allocation and a storage SWAP between two parameters (which a xor / sum fingerprint cancels) all change it;
+    `.data` writes are documented as invisible and ViewFusion.load_state_dict / _apply invalidate explicitly."""
+    import torch.nn as nn
+    from mvdfusion_amd import hip
+    m = nn.Sequential(nn.Linear(4, 4), nn.Linear(4, 4))
+    s0 = hip.params_signature(m)
+    assert hip.params_signature(m) == s0
+    with torch.no_grad():
+        m[0].weight.add_(1.0)
+    s1 = hip.params_signature(m)
+    assert s1 != s0
+    a, b = m[0].weight, m[1].weight
+    m[0].weight, m[1].weight = b, a                       # swap: the multiset of pointers and the version sum are unchanged
+    assert hip.params_signature(m) != s1
+    m[0].weight, m[1].weight = a, b
+    assert hip.params_signature(m) == s1
+    m[1].bias = nn.Parameter(m[1].bias.detach().clone())  # re-allocation
+    assert hip.params_signature(m) != s1
+    from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
+    from conftest import model_config
+    vf = ViewFusion(**model_config(32))
+    vf._engines["stale"] = object()
+    vf.load_state_dict(vf.state_dict(), strict=False)
+    assert not vf._engines and vf._packed_sig is None
+    vf._engines["stale"] = object()
+    vf.float()
+    assert not vf._engines

@@ -411,6 +411,50 @@ def test_training_loop_drop_in_loss_backward_optimizer_step():
     assert losses[1] < losses[0] and losses[-1] < losses[1]
 
 
+def test_checkpoint_save_resume_round_trip(tmp_path):
+    """train.py:166-181 (save_model: {local_step, global_step, epoch, model_state_dict, optimizer_state_dict}) and :144-153 (resume:
+    torch.load -> model.load_state_dict(strict=False) -> optimizer.load_state_dict): two AdamW steps, save, rebuild model + optimizer
+    from scratch, resume, and the third step reproduces the uninterrupted run's loss and updated weights BIT FOR BIT (the backward is
+    bit-reproducible, the packed MFMA operand images are rebuilt from the loaded fp32 parameters)."""
+    gd = load_golden("train_grads_mc32_v4_d3")
+
+    def fresh():
+        m, batch, tc, draws = _training_setup(gd)
+        m._noise_source = draws
+        for p in list(m.vae.parameters()) + list(m.clip_image_encoder.parameters()):
+            p.requires_grad_(False)
+        return m, batch, tc, m.configure_optimizers(lr=2e-4)
+
+    def one_step(m, opt, batch, tc):
+        loss = m(batch, tc)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss.detach().clone()
+
+    m, batch, tc, opt = fresh()
+    losses = [one_step(m, opt, batch, tc) for _ in range(2)]
+    path = str(tmp_path / "latest.pt")
+    torch.save({"local_step": 2, "global_step": 2, "epoch": 0, "model_state_dict": m.state_dict(),
+                "optimizer_state_dict": opt.state_dict()}, path)
+    l3 = one_step(m, opt, batch, tc)                             # the uninterrupted run's third step
+    w3 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    assert float(l3) < float(losses[0])
+    del m, opt
+    m2, batch2, tc2, opt2 = fresh()
+    w_init = m2.view_attn.final_layer_b.weight.detach().clone()
+    ckpt = torch.load(path, map_location="cpu")
+    assert set(ckpt) == {"local_step", "global_step", "epoch", "model_state_dict", "optimizer_state_dict"}
+    missing, unexpected = m2.load_state_dict(ckpt["model_state_dict"], strict=False)
+    assert not missing and not unexpected
+    opt2.load_state_dict(ckpt["optimizer_state_dict"])
+    assert ckpt["global_step"] == 2 and not torch.equal(w_init, m2.view_attn.final_layer_b.weight.detach())
+    l3r = one_step(m2, opt2, batch2, tc2)
+    assert torch.equal(l3r, l3), (float(l3r), float(l3))
+    bad = [k for k, v in m2.state_dict().items() if not torch.equal(v, w3[k])]
+    assert not bad, bad[:5]
+
+
 @pytest.mark.parametrize("name,model", [("clip_tiny", "tiny-test"), ("clip_vit_l14", "ViT-L/14")])
 def test_clip_image_encoder_vs_reference_golden(name, model):
     """FrozenCLIPImageEmbedder.encode on the HIP path (patch-embedding GEMM, 24 x [LN, QKV GEMM + bias, flash attention over 257
