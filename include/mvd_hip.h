@@ -86,6 +86,7 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, floa
 #define MVD_ACT_QUICKGELU 3 /* x * sigmoid(1.702 x): the MLP activation of OpenAI CLIP's vision transformer */
 
 #define MVD_GEMM_TILES 5 /* tile shapes of mvd_gemm_desc.cfg */
+#define MVD_GEMM_LOOPS 7 /* k-loop variants of mvd_gemm_desc.cfg */
 #define MVD_B_PACKED 0   /* B: weight image of mvd_pack_linear_weight / mvd_pack_conv3x3_weight */
 #define MVD_B_PLANES 1   /* B: (N, ldb) row-major split planes (an activation), N % 16 == 0 */
 
@@ -136,14 +137,19 @@ typedef struct mvd_gemm_desc {
   int splitk;
   float* workspace;
   size_t workspace_elems;
-  /* kernel configuration: 0 = built-in heuristic; otherwise cfg = 1 + 8 * tile + 2 * loop + order with
+  /* kernel configuration: 0 = built-in heuristic; otherwise cfg = 1 + 16 * tile + 2 * loop + order with
    *   tile : 0 = 64x64 (4 waves)  1 = 128x128 (8 waves)  2 = 128x80 (4 waves)  3 = 64x80 (4 waves)  4 = 128x160 (8 waves);
    *          tiles >= 2 (the 80-column family for N = 320 * k: no N padding, 256 workgroups at M = 8192, N = 320) serve
    *          MVD_EPI_STORE only
    *   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop (two k-tiles in LDS, MFMA fragments double-buffered in
    *          registers), 2 = staggered (8-wave tiles only: three k-tiles in LDS, the two wavefronts of a SIMD half an
    *          iteration apart, so one issues LDS-DMA / fragment reads while the other runs MFMAs), 3 = staggered with four
-   *          k-tiles in LDS (128x128 only)
+   *          k-tiles in LDS (128x128 only), 4 = the register-pipelined loop over a ring of up to 4 k-tiles in LDS, 5 = over a
+   *          ring of up to 8 (4-wave tiles): one workgroup per CU keeps 3 / 7 k-tiles of operands in flight, for the small grids
+   *          of the low-resolution levels whose k-loop is otherwise one DMA round trip per k-tile, 6 = the input-patch kernel for
+   *          stride-1 padded 3x3 convolutions (tiles 1, 2, 4): the tile's pixels + halo are staged once per 32-channel block and the
+   *          nine taps read shifted slots of that patch (4-6x less A traffic into LDS); mvd_gemm_cfg_supported() tells whether a
+   *          cfg serves a problem
    *   order: 0 = n-fastest, 1 = m-fastest order of the output tiles over the 8 XCDs.
    * The host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
    * winner from then on (mvdfusion_amd/hip.py: autotune). */
@@ -157,6 +163,9 @@ typedef struct mvd_gemm_desc {
 } mvd_gemm_desc;
 
 int mvd_gemm(const mvd_gemm_desc* d, mvd_stream_t stream);
+/* 1 if kernel configuration `cfg` (see mvd_gemm_desc.cfg) serves the problem `d` describes (tile family vs epilogue, loop variant vs
+ * tile, the input-patch kernel vs the convolution's geometry), else 0.  The host autotuner enumerates with it. */
+int mvd_gemm_cfg_supported(const mvd_gemm_desc* d, int cfg);
 
 /* fp32 (rows, cols) matrix with leading dim ldx -> split planes (rows, ldp), ldp % 32 == 0; columns [cols, ldp) are 0.
  * Used where a GEMM consumes a tensor that only exists in fp32 (residual stream into the 1x1 skip / up / down convs). */

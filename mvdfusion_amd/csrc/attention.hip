@@ -130,63 +130,75 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * KV_TILE, buf = NBUF == 2 ? (t & 1) : 0;
     if (t + 1 < ntiles) load_tile(kv0 + KV_TILE);      // in flight under the MFMAs below
+    // ---- S^T = K Q^T for every query tile of the wave: s[t2][kt][r] = S[q = c of tile t2][key = kv0 + kt*16 + g*4 + r].  The K
+    //      fragments are read from LDS ONCE per key sub-tile and feed all QT query tiles (tiles past L compute on zero / padding rows
+    //      and are never stored: no branches in the loop body, one basic block to schedule).
+    f32x4 s[QT][4];
 #pragma unroll
-    for (int t2 = 0; t2 < QT; ++t2) {
-      if (!active[t2]) continue;
-      // ---- S^T = K Q^T : s[kt][r] = S[q = c][key = kv0 + kt*16 + g*4 + r]
-      f32x4 s[4];
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int t2 = 0; t2 < QT; ++t2) s[t2][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < QS; ++ks) {
+        const op16x8 kh = *(const op16x8*)&sK[buf][0][kt * 16 + c][ks * 32 + g * 8];
+        if (NS >= 3) {
+          const op16x8 kl = *(const op16x8*)&sK[buf][NPL - 1][kt * 16 + c][ks * 32 + g * 8];
+          if (NS == 4) {
+#pragma unroll
+            for (int t2 = 0; t2 < QT; ++t2) s[t2][kt] = MVD_MFMA_16x16x32(kl, ql[t2][ks], s[t2][kt], 0, 0, 0);
+          }
+#pragma unroll
+          for (int t2 = 0; t2 < QT; ++t2) s[t2][kt] = MVD_MFMA_16x16x32(kl, qh[t2][ks], s[t2][kt], 0, 0, 0);
+#pragma unroll
+          for (int t2 = 0; t2 < QT; ++t2) s[t2][kt] = MVD_MFMA_16x16x32(kh, ql[t2][ks], s[t2][kt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < QT; ++t2) s[t2][kt] = MVD_MFMA_16x16x32(kh, qh[t2][ks], s[t2][kt], 0, 0, 0);
+      }
+    }
+    // the 16-channel tail as its own pass over the four key sub-tiles: consecutive MFMAs hit different accumulators.  (Issued right
+    // behind the last 16x16x32 step of the SAME accumulator, the 16x16x16 MFMA read a stale value in the one-product (NS = 1)
+    // 80-channel instantiation -- tests/test_gpu_ops.py::test_qkv_gemm_and_attention[2-8-256-80-1].)
+    if (TAIL) {
+      op4_t kh4[4], kl4[4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < QS; ++ks) {
-          const op16x8 kh = *(const op16x8*)&sK[buf][0][kt * 16 + c][ks * 32 + g * 8];
-          if (NS >= 3) {
-            const op16x8 kl = *(const op16x8*)&sK[buf][NPL - 1][kt * 16 + c][ks * 32 + g * 8];
-            if (NS == 4) s[kt] = MVD_MFMA_16x16x32(kl, ql[t2][ks], s[kt], 0, 0, 0);
-            s[kt] = MVD_MFMA_16x16x32(kl, qh[t2][ks], s[kt], 0, 0, 0);
-            s[kt] = MVD_MFMA_16x16x32(kh, ql[t2][ks], s[kt], 0, 0, 0);
-          }
-          s[kt] = MVD_MFMA_16x16x32(kh, qh[t2][ks], s[kt], 0, 0, 0);
-        }
+        kh4[kt] = *(const op4_t*)&sK[buf][0][kt * 16 + c][QS * 32 + g * 4];
+        if (NS >= 3) kl4[kt] = *(const op4_t*)&sK[buf][NPL - 1][kt * 16 + c][QS * 32 + g * 4];
       }
-      // the 16-channel tail as its own pass over the four key sub-tiles: consecutive MFMAs hit different accumulators.  (Issued right
-      // behind the last 16x16x32 step of the SAME accumulator, the 16x16x16 MFMA read a stale value in the one-product (NS = 1)
-      // 80-channel instantiation -- tests/test_gpu_ops.py::test_qkv_gemm_and_attention[2-8-256-80-1].)
-      if (TAIL) {
-        op4_t kh4[4], kl4[4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          kh4[kt] = *(const op4_t*)&sK[buf][0][kt * 16 + c][QS * 32 + g * 4];
-          if (NS >= 3) kl4[kt] = *(const op4_t*)&sK[buf][NPL - 1][kt * 16 + c][QS * 32 + g * 4];
-        }
+      for (int t2 = 0; t2 < QT; ++t2) {
         if (NS == 4) {
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt) s[kt] = MVD_MFMA_16x16x16(kl4[kt], qtl[t2], s[kt]);
+          for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kl4[kt], qtl[t2], s[t2][kt]);
         }
         if (NS >= 3) {
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt) s[kt] = MVD_MFMA_16x16x16(kl4[kt], qth[t2], s[kt]);
+          for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kl4[kt], qth[t2], s[t2][kt]);
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt) s[kt] = MVD_MFMA_16x16x16(kh4[kt], qtl[t2], s[kt]);
+          for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kh4[kt], qtl[t2], s[t2][kt]);
         }
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) s[kt] = MVD_MFMA_16x16x16(kh4[kt], qth[t2], s[kt]);
+        for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kh4[kt], qth[t2], s[t2][kt]);
       }
-      // ---- online softmax (per query column c; keys are spread over registers and the 4 lane groups)
-      // (q carries dhead^-0.5 * log2(e) from the QKV epilogue, so the scores are base-2 logits: exp2 below is a bare v_exp_f32)
+    }
+    // ---- online softmax (per query column c; keys are spread over registers and the 4 lane groups)
+    // (q carries dhead^-0.5 * log2(e) from the QKV epilogue, so the scores are base-2 logits: exp2 below is a bare v_exp_f32)
+    op16x8 ph[QT][2], pl2[QT][2];
+#pragma unroll
+    for (int t2 = 0; t2 < QT; ++t2) {
       if (kv0 + KV_TILE > Lk) {     // ragged last tile only (uniform branch): keys past Lk do not take part
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kv0 + kt * 16 + g * 4 + r >= Lk) s[kt][r] = -INFINITY;
+            if (kv0 + kt * 16 + g * 4 + r >= Lk) s[t2][kt][r] = -INFINITY;
       }
       float mt = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kt][r]);
+        for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[t2][kt][r]);
       mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       const float m_new = fmaxf(m_run[t2], mt);
@@ -197,46 +209,51 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
-          psum += s[kt][r];
+          s[t2][kt][r] = __builtin_amdgcn_exp2f(s[t2][kt][r] - m_new);
+          psum += s[t2][kt][r];
         }
       l_run[t2] = l_run[t2] * alpha + psum;
 #pragma unroll
       for (int i = 0; i < DT; ++i) o[t2][i] *= alpha;
       // ---- P^T as MFMA B operand: k-slot (g, j): j<4 -> key 32u + 4g + j ; j>=4 -> key 32u + 16 + 4g + (j-4)
-      op16x8 ph[2], pl2[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         union { op16x8 v; u16 e[8]; } H8, L8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float pv = j < 4 ? s[2 * u][j] : s[2 * u + 1][j - 4];
+          const float pv = j < 4 ? s[t2][2 * u][j] : s[t2][2 * u + 1][j - 4];
           if (NS >= 3) {
             split_op16(pv, H8.e[j], L8.e[j]);
           } else {
             H8.e[j] = to_op_bits(pv);
           }
         }
-        ph[u] = H8.v;
-        if (NS >= 3) pl2[u] = L8.v;
+        ph[t2][u] = H8.v;
+        if (NS >= 3) pl2[t2][u] = L8.v;
       }
-      // ---- O^T += V^T P^T
+    }
+    // ---- O^T += V^T P^T: every V^T fragment is read once and multiplies the P^T of all QT query tiles
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
+    for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          union { op16x8 v; uint2 h2[2]; } VH, VL;
-          VH.h2[0] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 4 * g];
-          VH.h2[1] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 16 + 4 * g];
-          if (NS >= 3) {
-            VL.h2[0] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 4 * g];
-            VL.h2[1] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 16 + 4 * g];
-            if (NS == 4) o[t2][dt] = MVD_MFMA_16x16x32(VL.v, pl2[u], o[t2][dt], 0, 0, 0);
-            o[t2][dt] = MVD_MFMA_16x16x32(VL.v, ph[u], o[t2][dt], 0, 0, 0);
-            o[t2][dt] = MVD_MFMA_16x16x32(VH.v, pl2[u], o[t2][dt], 0, 0, 0);
+      for (int u = 0; u < 2; ++u) {
+        union { op16x8 v; uint2 h2[2]; } VH, VL;
+        VH.h2[0] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 4 * g];
+        VH.h2[1] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 16 + 4 * g];
+        if (NS >= 3) {
+          VL.h2[0] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 4 * g];
+          VL.h2[1] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 16 + 4 * g];
+          if (NS == 4) {
+#pragma unroll
+            for (int t2 = 0; t2 < QT; ++t2) o[t2][dt] = MVD_MFMA_16x16x32(VL.v, pl2[t2][u], o[t2][dt], 0, 0, 0);
           }
-          o[t2][dt] = MVD_MFMA_16x16x32(VH.v, ph[u], o[t2][dt], 0, 0, 0);
+#pragma unroll
+          for (int t2 = 0; t2 < QT; ++t2) o[t2][dt] = MVD_MFMA_16x16x32(VL.v, ph[t2][u], o[t2][dt], 0, 0, 0);
+#pragma unroll
+          for (int t2 = 0; t2 < QT; ++t2) o[t2][dt] = MVD_MFMA_16x16x32(VH.v, pl2[t2][u], o[t2][dt], 0, 0, 0);
         }
+#pragma unroll
+        for (int t2 = 0; t2 < QT; ++t2) o[t2][dt] = MVD_MFMA_16x16x32(VH.v, ph[t2][u], o[t2][dt], 0, 0, 0);
       }
     }
     if (NBUF == 2) {

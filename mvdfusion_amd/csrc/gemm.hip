@@ -136,6 +136,195 @@ __device__ __forceinline__ float4 epi_store4(const mvd_gemm_desc& d, int m, int 
   return v;
 }
 
+// conv_patch_kernel: slots of the input patch (128 B each) a workgroup may hold (BM = 128: 288 = 8 images of 4x4 with halo)
+#define MVD_PATCH_SLOTS_MAX 288
+// ... and the depth of its ring of weight stages, by tile width (two patch buffers of 37 KiB + the ring fit the CU's 160 KiB)
+__host__ __device__ constexpr int conv_patch_ring(int bn, int waves) {
+  const int bstage = ((bn / 8 + waves - 1) / waves) * waves;       // KiB
+  const int fit = (160 - 2 * (MVD_PATCH_SLOTS_MAX / 8 + 1) - 2) / bstage;
+  return fit > 4 ? 4 : fit;
+}
+
+// ------------------------------------------------------------------------------------------------ tile epilogue
+// Shared by gemm_kernel and conv_patch_kernel: the wave's accumulator tile is transposed through LDS (the stage buffers are free: the
+// caller has passed a workgroup barrier after its last fragment read) so that global traffic is row-contiguous 16-byte accesses.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], unsigned char* smem, int m0,
+                                              int n0, int lane, int wave) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int LDW = WTN + 4;                        // fp32 pitch of the epilogue staging tile
+  constexpr int C4 = WTN / 4;                         // float4 columns of a wave tile row
+  const mvd_gemm_desc& d = p.d;
+  const int wm = wave / WN, wn = wave % WN;
+  //      (the final barrier above guarantees nobody still reads the stage buffers; each wave owns a private region)
+  float* sC = (float*)smem + wave * (WTM * LDW);
+  {
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;   // C layout: row = (lane>>4)*4 + r, col = lane&15
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sC[(i * 16 + crow + r) * LDW + j * 16 + ccol] = acc[i][j][r];
+  }
+  const int wm0 = m0 + wm * WTM, wn0 = n0 + wn * WTN;
+  if (wn0 >= d.N) return;
+
+  if (p.splits > 1) {   // raw partial sums -> workspace slab; splitk_reduce_kernel sums the slabs and applies the epilogue.
+    // (Reducing inside this kernel -- last-arriving workgroup per tile behind an agent-scope release/acquire -- was
+    //  built and measured: bit-identical, but 15 % slower per step.  A 128x128 tile has 64 KB slabs, far above the
+    //  few tens of KB where that hand-off pays, and its cache-wide write-back / invalidate disturbs the operand
+    //  streams of the other workgroups.)
+    float* ws = d.workspace + (size_t)blockIdx.z * d.M * d.N;
+#pragma unroll
+    for (int ps = 0; ps < (WTM * C4 + 63) / 64; ++ps) {
+      const int idx = ps * 64 + lane;
+      const int row = idx / C4, col = (idx - row * C4) * 4;
+      const int m = wm0 + row, n = wn0 + col;
+      if (idx < WTM * C4 && m < d.M && n < d.N) *(float4*)(ws + (size_t)m * d.N + n) = *(const float4*)(sC + row * LDW + col);
+    }
+    return;
+  }
+  if constexpr (WTN == 32) {      // GEGLU / QKV epilogues address 32-column blocks (one value|gate block, head-aligned q/k/v)
+  if (d.epi == MVD_EPI_GEGLU) {   // wave tile = 16 value columns | 16 gate columns
+    const int ocol0 = (wn0 >> 5) * 16;
+    const int half = d.N >> 1;
+#pragma unroll
+    for (int ps = 0; ps < WTM / 16; ++ps) {
+      const int row = ps * 16 + (lane >> 2), q = (lane & 3) * 4;
+      const int m = wm0 + row;
+      if (m >= d.M) continue;
+      float4 v = *(const float4*)(sC + row * LDW + q);
+      float4 g = *(const float4*)(sC + row * LDW + 16 + q);
+      const int col = ocol0 + q;
+      v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
+      g.x *= d.acc_scale; g.y *= d.acc_scale; g.z *= d.acc_scale; g.w *= d.acc_scale;
+      if (d.bias) {
+        const float4 bv = *(const float4*)(d.bias + col), bg = *(const float4*)(d.bias + half + col);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
+      }
+      v.x *= gelu_erf(g.x); v.y *= gelu_erf(g.y); v.z *= gelu_erf(g.z); v.w *= gelu_erf(g.w);
+      if (d.out) *(float4*)(d.out + (size_t)m * d.ldo + col) = v;
+      if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, col, v.x, v.y, v.z, v.w);
+    }
+    return;
+  }
+  if (d.epi == MVD_EPI_QKV) {     // a 32-column aligned wave tile lies inside one of q / k / v
+    const int C = d.heads * d.dhead;
+    const int which = wn0 / C;
+    if (which < 2) {
+      const int dq = mvd_attn_dpad(d.dhead);
+      u16* ph = (u16*)(which == 0 ? d.q_hi : d.k_hi);
+      u16* pl = (u16*)(which == 0 ? d.q_lo : d.k_lo);
+#pragma unroll
+      for (int ps = 0; ps < WTM / 8; ++ps) {
+        const int row = ps * 8 + (lane >> 3), col = (lane & 7) * 4;
+        const int m = wm0 + row, n = wn0 + col;
+        if (m >= d.M) continue;
+        float4 v = *(const float4*)(sC + row * LDW + col);
+        const int cc = n - which * C;
+        const int head = cc / d.dhead, dd = cc - head * d.dhead;
+        const int b = m / d.L, tok = m - b * d.L;
+        const size_t idx = ((size_t)(b * d.heads + head) * d.Lpad + tok) * dq + dd;
+        const float qs = which == 0 ? d.qscale : 1.0f;
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias) bb = *(const float4*)(d.bias + n);        // in_proj bias (nn.MultiheadAttention, timm qkv_bias); SD attention has none
+        store_planes4(ph, pl, idx, (v.x * d.acc_scale + bb.x) * qs, (v.y * d.acc_scale + bb.y) * qs, (v.z * d.acc_scale + bb.z) * qs,
+                      (v.w * d.acc_scale + bb.w) * qs);
+      }
+    } else {                      // V^T: each lane takes 4 consecutive tokens of one channel (8-byte stores, keys contiguous)
+      const int dv = (d.dhead + 15) & ~15;
+      const int col = lane & 31, rsel = lane >> 5;
+      const int cc = wn0 + col - 2 * C;
+      const int head = cc / d.dhead, dd = cc - head * d.dhead;
+#pragma unroll
+      for (int ps = 0; ps < WTM / 8; ++ps) {
+        const int row = (ps * 2 + rsel) * 4;
+        const int m = wm0 + row;
+        if (m >= d.M) continue;
+        const int b = m / d.L, tok = m - b * d.L;
+        const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
+        const float bv = d.bias ? d.bias[wn0 + col] : 0.f;
+        store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, sC[row * LDW + col] * d.acc_scale + bv, sC[(row + 1) * LDW + col] * d.acc_scale + bv,
+                      sC[(row + 2) * LDW + col] * d.acc_scale + bv, sC[(row + 3) * LDW + col] * d.acc_scale + bv);
+      }
+    }
+    return;
+  }
+  }
+  // MVD_EPI_STORE
+#pragma unroll
+  for (int ps = 0; ps < (WTM * C4 + 63) / 64; ++ps) {
+    const int idx = ps * 64 + lane;
+    const int row = idx / C4, col = (idx - row * C4) * 4;
+    const int m = wm0 + row, n = wn0 + col;
+    if (idx >= WTM * C4 || m >= d.M || n >= d.N) continue;
+    const float4 v = *(const float4*)(sC + row * LDW + col);
+    if (n + 3 < d.n_store) {
+      const float4 f = epi_store4(d, m, n, v);
+      if (d.gn_stats) *(float4*)(sC + row * LDW + col) = f;      // final values back into the staging tile for the statistics pass
+    } else {
+      epi_store_elem(d, m, n, v.x);
+      epi_store_elem(d, m, n + 1, v.y);
+      epi_store_elem(d, m, n + 2, v.z);
+      epi_store_elem(d, m, n + 3, v.w);
+    }
+  }
+  if (d.gn_stats) {
+    // GroupNorm statistics of the tensor just produced, for the GroupNorm that consumes it (mvd_groupnorm_from_stats): one lane
+    // per column sums its 16-row slabs in row order, the first lane of every (group, slab) fragment adds up its columns in
+    // column order and hands the pair to the integer atomics.  (The wave owns its staging tile: LDS ops of one wave are ordered.)
+    const int cg = d.n_store / d.gn_groups;
+    const int jmax = cg < 64 ? cg : 64;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c0 = 0; c0 < WTN; c0 += 64) {
+      const int col = c0 + lane, n = wn0 + col;
+      const bool okc = col < WTN && n < d.n_store;
+      const int gidx = okc ? n / cg : 0, pos = okc ? n - gidx * cg : 0;
+      const bool leader = okc && (pos == 0 || lane == 0);
+      int len = 0;
+      if (leader) {
+        len = cg - pos;
+        if (len > 64 - lane) len = 64 - lane;
+        if (len > WTN - col) len = WTN - col;
+        if (len > d.n_store - n) len = d.n_store - n;
+      }
+      // images at least as tall as the wave tile (gn_hw % WTM == 0): one pair of atomics per wave tile and group fragment -- the
+      // 16-row slabs are summed in row order first; shorter images: one pair per slab
+      const bool whole = d.gn_hw % WTM == 0;
+      float s1 = 0.f, q1 = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < WTM / 16; ++sl) {
+        const int ms = wm0 + sl * 16;
+        if (ms >= d.M) break;
+        if (!whole) s1 = q1 = 0.f;
+        if (okc) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = sC[(sl * 16 + r) * LDW + col];
+            s1 += v;
+            q1 += v * v;
+          }
+        }
+        if (whole && sl + 1 < WTM / 16 && ms + 16 < d.M) continue;
+        float ss = s1, qq = q1;
+        for (int j = 1; j < jmax; ++j) {
+          const float ts = __shfl_down(s1, j, 64), tq = __shfl_down(q1, j, 64);
+          if (j < len) {
+            ss += ts;
+            qq += tq;
+          }
+        }
+        if (leader) gn_stats_add(d.gn_stats, ms / d.gn_hw, gidx, d.gn_groups, ss, qq);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ main kernel
 template <int N>
 __device__ __forceinline__ void wait_vm_and_barrier() {
@@ -162,6 +351,14 @@ __device__ __forceinline__ void sched_pattern() {
   }
 }
 
+template <int J, int N, class F>
+__device__ __forceinline__ void unroll_steps(F&& f) {
+  if constexpr (J < N) {
+    f(std::integral_constant<int, J>{});
+    unroll_steps<J + 1, N>(f);
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int NS, int AMODE, int STAGES>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
@@ -176,16 +373,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   constexpr int LDW = WTN + 4;                        // fp32 pitch of the epilogue staging tile
   constexpr int C4 = WTN / 4;                         // float4 columns of a wave tile row
   constexpr int EPI_BYTES = NW * WTM * LDW * 4;
-  constexpr bool PIPE = STAGES == 3;                   // 3 = register-pipelined loop (still two LDS buffers)
-  constexpr bool STAG = STAGES >= 4;                   // 4 / 5 = staggered wave groups with three / four LDS buffers
-  constexpr int NBUF = STAG ? STAGES - 1 : 2;
+  constexpr bool RING = STAGES >= 6;                   // 6 / 7 = register-pipelined loop over a DEEP ring of LDS buffers (<= 4 / <= 8)
+  constexpr bool PIPE = STAGES == 3 || RING;           // 3 = register-pipelined loop (two LDS buffers)
+  constexpr bool STAG = STAGES == 4 || STAGES == 5;    // 4 / 5 = staggered wave groups with three / four LDS buffers
+  constexpr int TAB_BYTES = AMODE != MVD_A_DENSE ? BM * 9 * 4 : 0;
+  constexpr int RING_FIT = (160 * 1024 - TAB_BYTES) / STAGE;   // a workgroup may own the whole 160 KiB of its CU
+  constexpr int RING_WANT = STAGES == 6 ? 4 : 8;
+  constexpr int NBUF = STAG ? STAGES - 1 : (RING ? (RING_WANT < RING_FIT ? RING_WANT : RING_FIT) : 2);
   constexpr int LEAD = NBUF - 1;                       // staggered loop: k-tiles staged ahead of the one being read
   constexpr int SMEM = NBUF * STAGE > EPI_BYTES ? NBUF * STAGE : EPI_BYTES;
+  static_assert(NBUF >= 2 && SMEM + TAB_BYTES <= 160 * 1024, "LDS budget");
   static_assert(!STAG || NW == 8, "the staggered loop pairs the two wavefronts of each SIMD: 8-wave tiles only");
   static_assert(A_GRAN % NW == 0, "A granules must divide evenly over the waves");
   static_assert(WTM % 16 == 0 && WTN % 16 == 0 && B_GRAN % 2 == 0, "wave tiles are made of 16x16 MFMA tiles");
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + (AMODE != MVD_A_DENSE ? BM * 9 * 4 : 0)];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + TAB_BYTES];
 
   const mvd_gemm_desc& d = p.d;
   const int tid = threadIdx.x;
@@ -440,48 +642,56 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     }
     __syncthreads();   // the epilogue reuses the stage buffers
   } else if (PIPE) {
-    // ---- register-pipelined loop, two LDS buffers.  While the MFMAs of k-tile t run out of one fragment register set,
-    //      the wave reads k-tile t+1 from LDS into the other set and issues the DMA of k-tile t+2 into the buffer that
-    //      tile t occupied (its fragments are already in registers).  One barrier per k-tile; the DMA it waits for was
-    //      issued a whole iteration earlier, so neither LDS nor L2 latency sits between two MFMA bursts.
+    // ---- register-pipelined loop over a ring of NBUF LDS buffers (NBUF = 2: STAGES 3; up to 4 / 8: the RING variants).  While the
+    //      MFMAs of k-tile t run out of one fragment register set, the wave reads k-tile t+1 from LDS into the other set and issues
+    //      the DMA of k-tile t+NBUF into the buffer that tile t occupied (its fragments are already in registers).  One barrier per
+    //      k-tile; NBUF - 1 k-tiles of operands are in flight per workgroup, so a small grid (one workgroup per CU, as the low-resolution
+    //      levels of the UNet give) is not bound by one DMA round trip per k-tile: Little's law with 16 KiB in flight per CU and
+    //      ~1.5 us from a cold weight to LDS is ~10 GB/s per CU; a ring of 8 lifts that bound 7x.
     op16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
-    stage(0);
-    advance_tap();
-    if (nkt > 1) {
-      stage(1);
-      advance_tap();
-      wait_vm_and_barrier<LPS>();
-    } else {
-      wait_vm_and_barrier<0>();
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) {
+      if (q < nkt) {
+        stage(q);
+        advance_tap();
+      }
     }
+    if (nkt >= NBUF) wait_vm_and_barrier<(NBUF - 1) * LPS>();   // k-tile 0 landed, the newer ones stay in flight
+    else wait_vm_and_barrier<0>();
     read_frags(0, fah[0], fal[0], fbh[0], fbl[0]);
+    int bs = 0, br = NBUF > 1 ? 1 : 0;              // buffer staged next (= it % NBUF), buffer read next (= (it + 1) % NBUF)
     auto step = [&](auto parity, auto steady, int it) {
       constexpr int P = decltype(parity)::value;
       constexpr bool FULL = decltype(steady)::value;   // steady state: no conditions -> one basic block to schedule
-      // k-tile it+1 has landed for every wave, and every wave's fragment reads of buffer P have returned
-      wait_vm_and_barrier<0>();
-      if (FULL || it + 2 < nkt) stage(P);
-      if (FULL || it + 1 < nkt) read_frags(P ^ 1, fah[P ^ 1], fal[P ^ 1], fbh[P ^ 1], fbl[P ^ 1]);
+      // k-tile it+1 has landed for every wave (the NBUF - 2 newer stages may still fly), and every wave's fragment reads of the
+      // buffer of k-tile it have returned
+      if (FULL) wait_vm_and_barrier<(NBUF - 2) * LPS>();
+      else wait_vm_and_barrier<0>();
+      if (FULL || it + NBUF < nkt) stage(bs);
+      if (FULL || it + 1 < nkt) read_frags(br, fah[P ^ 1], fal[P ^ 1], fbh[P ^ 1], fbl[P ^ 1]);
       mfma_tile(fah[P], fal[P], fbh[P], fbl[P]);
       if (FULL) {
         constexpr int NM = TM * TN * NS, NR = (TM + TN) * (NS >= 3 ? 2 : 1);
         sched_pattern<0, LPS + NR, NM, LPS>();     // (the conv table reads of advance_tap() follow the pattern)
       }
-      if (FULL || it + 2 < nkt) advance_tap();
+      if (FULL || it + NBUF < nkt) advance_tap();
+      bs = bs + 1 == NBUF ? 0 : bs + 1;
+      br = br + 1 == NBUF ? 0 : br + 1;
     };
     using std::integral_constant;
     int it = 0;
-    for (; it + 3 < nkt; it += 2) {
+    for (; it + NBUF + 1 < nkt; it += 2) {
       step(integral_constant<int, 0>{}, integral_constant<bool, true>{}, it);
       step(integral_constant<int, 1>{}, integral_constant<bool, true>{}, it + 1);
     }
-    // at most three k-tiles remain (`it` is even).  Straight-line on purpose: as a loop with a run-time parity switch
+    // at most NBUF + 1 k-tiles remain (`it` is even).  Straight-line on purpose: as a loop with a run-time parity switch
     // the compiler carried the accumulators through AGPR copies on the back edge, and one of them (v_accvgpr_mov of the
     // register the last MFMA had just written) read a stale value in the 64x64 conv instantiation -- every
     // configuration is now cross-checked in tests/test_gpu_ops.py::test_gemm_configurations_agree.
-    if (it < nkt) step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, it);
-    if (it + 1 < nkt) step(integral_constant<int, 1>{}, integral_constant<bool, false>{}, it + 1);
-    if (it + 2 < nkt) step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, it + 2);
+    unroll_steps<0, NBUF + 1>([&](auto j) {
+      constexpr int J = decltype(j)::value;
+      if (it + J < nkt) step(integral_constant<int, J & 1>{}, integral_constant<bool, false>{}, it + J);
+    });
     __syncthreads();   // the epilogue reuses the stage buffers
   } else {
     // ---- plain two-buffer loop: DMA of k-tile t+1 in flight while tile t is read and multiplied
@@ -502,173 +712,236 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     }
   }
 
-  // ---- epilogue: transpose the wave tile through LDS so that global traffic is row-contiguous 16-byte accesses.
-  //      (the final barrier above guarantees nobody still reads the stage buffers; each wave owns a private region)
-  float* sC = (float*)smem + wave * (WTM * LDW);
+  // ---- epilogue (the final barrier above guarantees nobody still reads the stage buffers; each wave owns a private region)
+  tile_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, lane, wave);
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 convolution, input patch in LDS
+// conv_patch_kernel: stride-1 3x3 convolution whose A operand is staged ONCE per 32-channel block as the tile's input PATCH (the
+// tile's pixels plus a one-pixel halo: (rows + 2) x (W + 2) pixel lines of 128 bytes) instead of nine shifted copies of the tile -- the
+// nine taps of a channel block read their A fragments from the same patch at shifted pixel slots.  gemm_kernel's implicit GEMM moves
+// 9 x BM pixel lines per channel block through the LDS-DMA path (all L2 hits, but the kernel is bound by what one CU can pull from
+// L2 into LDS); the patch is (BM / W + 2)(W + 2) lines, 1.4 - 2.3 x BM: the A side of the operand delivery shrinks 4 - 6 x, so a
+// narrow tile (128 x 80: 256 workgroups at M = 8192, N = 320 -- the whole chip) no longer pays for its low A reuse.
+//   * slot p of the patch = padded pixel (segment s, patch row pr, patch column pc), p = (s (Rb + 2) + pr)(W + 2) + pc; a tile is
+//     either Rb = BM / W whole rows of one image (H W >= BM) or BM / (H W) whole images (segments).  Slot p lives at byte
+//     128 p of the patch buffer, its 16-byte chunk cc at position cc ^ ((p >> 1) & 7) (the DMA is lane-linear in LDS, so the
+//     swizzle is applied to the per-lane SOURCE address; zero padding and rows past M source the zero page).
+//   * tile row r -> centre slot c(r); tap (ky, kx) reads slot c(r) + (ky - 1)(W + 2) + (kx - 1).
+//   * B: the packed weights, k order (channel block, tap) like gemm_kernel, through a ring of NB stages; two patch buffers: the
+//     patch of block cb + 1 arrives in NSHARE = 11 - NB shares of PI granules per wave, issued next to the B stages of the k-tiles
+//     (cb - 1, tap 8), (cb, tap 0 .. 9 - NB): after the last readers of the buffer (block cb - 1) passed their barrier, and early
+//     enough that the counted vmcnt of the k-loop has retired them when (cb + 1, tap 0) is read.  Every k-tile issues the same
+//     number of DMAs per wave (dummies copy the zero page into a dump granule) so the counted waits stay compile-time constants.
+//   * loop: the register-pipelined ring of gemm_kernel (fragments of k-tile t + 1 read under the MFMAs of k-tile t).  Same MFMA order
+//     and k order as gemm_kernel => bit-identical results.
+template <int BM, int BN, int WM, int WN, int NS, int PI>
+__global__ __launch_bounds__(WM * WN * 64) void conv_patch_kernel(GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int B_GRAN = BN / 8, BI = (B_GRAN + NW - 1) / NW, B_GRAN_P = BI * NW;
+  constexpr int BSTAGE = B_GRAN_P * 1024;
+  constexpr int PSLOTS = MVD_PATCH_SLOTS_MAX, PG_MAX = PSLOTS / 8;
+  constexpr int PATCH = (PG_MAX + 1) * 1024;          // + one dump granule for the dummy DMAs
+  constexpr int NB = conv_patch_ring(BN, NW);
+  constexpr int NSHARE = 11 - NB;
+  constexpr int LPS = BI + PI;
+  constexpr int PP = (PG_MAX + NW - 1) / NW;          // prologue: the whole patch of the first channel block
+  constexpr int LDW = WTN + 4;
+  constexpr int EPI_BYTES = NW * WTM * LDW * 4;
+  constexpr int MAIN = 2 * PATCH + NB * BSTAGE;
+  constexpr int SMEM = MAIN > EPI_BYTES ? MAIN : EPI_BYTES;
+  static_assert(SMEM + PSLOTS * 4 <= 160 * 1024 && NB >= 2 && NSHARE >= 1, "LDS budget");
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && B_GRAN % 2 == 0, "wave tiles are made of 16x16 MFMA tiles");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + PSLOTS * 4];
+
+  const mvd_gemm_desc& d = p.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int tile;
   {
-    const int crow = (lane >> 4) * 4, ccol = lane & 15;   // C layout: row = (lane>>4)*4 + r, col = lane&15
+    const int nb = p.tiles_n * p.tiles_m, bid = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (p.m_fastest ? tile % p.tiles_m : tile / p.tiles_n) * BM;
+  const int n0 = (p.m_fastest ? tile / p.tiles_m : tile % p.tiles_n) * BN;
+  const int cb0 = blockIdx.z * (p.kt_per_split / 9);                 // kt_per_split is a multiple of 9 here (whole channel blocks)
+  const int nblk = min(p.nk / 9, cb0 + p.kt_per_split / 9) - cb0;
+  const int nkt = nblk * 9;
+
+  // ---- patch geometry (uniform)
+  const int W = d.Wout, H = d.Hout, HW = H * W, PW = W + 2;
+  const int nseg = HW >= BM ? 1 : BM / HW, Rb = HW >= BM ? BM / W : H;
+  const int seg_slots = (Rb + 2) * PW, P = nseg * seg_slots, PG = (P + 7) >> 3;
+  int* s_src = (int*)(smem + SMEM);
+  {
+    const int b0 = m0 / HW, y0 = HW >= BM ? (m0 - b0 * HW) / W : 0;
+    for (int e = tid; e < PSLOTS; e += NW * 64) {
+      int off = -1;
+      if (e < P) {
+        const int sg = e / seg_slots, rem = e - sg * seg_slots;
+        const int pr = rem / PW, pc = rem - pr * PW;
+        const int b = b0 + sg, y = y0 + pr - 1, x = pc - 1;
+        if (b < d.B && y >= 0 && y < H && x >= 0 && x < W) off = ((b * H + y) * W + x) * 2 * d.Cin;
+      }
+      s_src[e] = off;
+    }
+  }
+  __syncthreads();
+  const u16* zero = (const u16*)g_zero_page;
+  unsigned char* const sB = smem + 2 * PATCH;
+
+  int centre[TM];                      // patch slot of this lane's row of every 16-row MFMA block of the wave tile
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = (wm * TM + i) * 16 + (lane & 15);
+    const int sg = r / (Rb * W), rr = r - sg * Rb * W;
+    const int yy = rr / W, xx = rr - yy * W;
+    centre[i] = sg * seg_slots + (yy + 1) * PW + xx + 1;
+  }
+
+  const u16* b_cur[BI];
+  size_t b_step[BI];
+  {
+    const size_t b_kstride = (size_t)p.nt16 * 1024;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int gi = wave + i * NW;
+      const int nt = (n0 >> 4) + (gi >> 1);
+      const bool ok = gi < B_GRAN && nt < p.nt16;
+      b_cur[i] = ok ? (const u16*)d.Wp + (size_t)nt * 1024 + (gi & 1) * 512 + lane * 8 + (size_t)cb0 * 9 * b_kstride : zero;
+      b_step[i] = ok ? b_kstride : 0;
+    }
+  }
+  auto stage_b = [&](int buf) {
+    unsigned char* sbase = sB + buf * BSTAGE;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_cur[i],
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave + i * NW) * 1024), 16, 0, 0);
+      b_cur[i] += b_step[i];
+    }
+  };
+  // granule g of the patch of channel block `blk` (relative to cb0); not `real`: a dummy copy of the zero page into the dump granule
+  auto patch_granule = [&](int g, int blk, bool real) {
+    const int slot = g * 8 + (lane >> 3);
+    const int off = real ? s_src[slot < PSLOTS ? slot : 0] : -1;
+    const int cc = (lane & 7) ^ ((slot >> 1) & 7);
+    const u16* src = off >= 0 ? (const u16*)d.A + (unsigned)(off + (cb0 + blk) * 64 + cc * 8) : zero;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smem + (blk & 1) * PATCH + (real ? g : PG_MAX) * 1024), 16, 0, 0);
+  };
+  auto patch_share = [&](int j, int blk) {
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+      const int g = (j * PI + i) * NW + wave;
+      patch_granule(g, blk, j < NSHARE && blk < nblk && g < PG);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto mfma_tile = [&](const op16x8 (&ah)[TM], const op16x8 (&al)[TM], const op16x8 (&bh)[TN], const op16x8 (&bl)[TN]) {
+    // (same term-major order as gemm_kernel: lo*lo, lo*hi, hi*lo, hi*hi per accumulator and k-tile)
+    if (NS == 4) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(al[i], bl[j], acc[i][j], 0, 0, 0);
+    }
+    if (NS >= 3) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(ah[i], bl[j], acc[i][j], 0, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  };
+  const int fg = lane >> 4;
+  auto read_frags = [&](int bbuf, int pbuf, int tap, op16x8 (&ah)[TM], op16x8 (&al)[TM], op16x8 (&bh)[TN], op16x8 (&bl)[TN]) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int tapoff = (ky - 1) * PW + kx - 1;
+    const unsigned char* sP = smem + pbuf * PATCH;
+    const unsigned char* sBb = sB + bbuf * BSTAGE;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sC[(i * 16 + crow + r) * LDW + j * 16 + ccol] = acc[i][j][r];
-  }
-  const int wm0 = m0 + wm * WTM, wn0 = n0 + wn * WTN;
-  if (wn0 >= d.N) return;
+    for (int i = 0; i < TM; ++i) {
+      const int slot = centre[i] + tapoff;
+      const int sw = (slot >> 1) & 7;
+      ah[i] = *(const op16x8*)(sP + slot * 128 + ((fg ^ sw) << 4));
+      if (NS >= 3) al[i] = *(const op16x8*)(sP + slot * 128 + (((4 + fg) ^ sw) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[j] = *(const op16x8*)(sBb + (wn * TN + j) * 2048 + lane * 16);
+      if (NS >= 3) bl[j] = *(const op16x8*)(sBb + (wn * TN + j) * 2048 + 1024 + lane * 16);
+    }
+  };
 
-  if (p.splits > 1) {   // raw partial sums -> workspace slab; splitk_reduce_kernel sums the slabs and applies the epilogue.
-    // (Reducing inside this kernel -- last-arriving workgroup per tile behind an agent-scope release/acquire -- was
-    //  built and measured: bit-identical, but 15 % slower per step.  A 128x128 tile has 64 KB slabs, far above the
-    //  few tens of KB where that hand-off pays, and its cache-wide write-back / invalidate disturbs the operand
-    //  streams of the other workgroups.)
-    float* ws = d.workspace + (size_t)blockIdx.z * d.M * d.N;
+  // ---- prologue: the whole patch of block 0, then B of k-tiles 0 .. NB-1 (each with its PI patch DMAs: the last one carries share 0
+  //      of block 1, i.e. plays iteration -1; the others are dummies so that every stage is LPS DMAs)
 #pragma unroll
-    for (int ps = 0; ps < (WTM * C4 + 63) / 64; ++ps) {
-      const int idx = ps * 64 + lane;
-      const int row = idx / C4, col = (idx - row * C4) * 4;
-      const int m = wm0 + row, n = wn0 + col;
-      if (idx < WTM * C4 && m < d.M && n < d.N) *(float4*)(ws + (size_t)m * d.N + n) = *(const float4*)(sC + row * LDW + col);
+  for (int i = 0; i < PP; ++i) {
+    const int g = i * NW + wave;
+    patch_granule(g, 0, g < PG);
+  }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    stage_b(q);
+    patch_share(q == NB - 1 ? 0 : NSHARE, 1);
+  }
+  wait_vm_and_barrier<(NB - 1) * LPS>();
+  op16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+  read_frags(0, 0, 0, fah[0], fal[0], fbh[0], fbl[0]);
+  int bs = 0, br = 1 % NB, tap = 0, blk = 0;        // (tap, blk): the k-tile whose MFMAs run in the current iteration
+  auto step = [&](auto parity, auto steady, int it) {
+    constexpr int Pq = decltype(parity)::value;
+    constexpr bool FULL = decltype(steady)::value;
+    if (FULL) wait_vm_and_barrier<(NB - 2) * LPS>();
+    else wait_vm_and_barrier<0>();
+    const bool last_tap = tap == 8;
+    if (FULL || it + NB < nkt) {
+      stage_b(bs);
+      patch_share(last_tap ? 0 : tap + 1, blk + (last_tap ? 2 : 1));
     }
-    return;
-  }
-  if constexpr (WTN == 32) {      // GEGLU / QKV epilogues address 32-column blocks (one value|gate block, head-aligned q/k/v)
-  if (d.epi == MVD_EPI_GEGLU) {   // wave tile = 16 value columns | 16 gate columns
-    const int ocol0 = (wn0 >> 5) * 16;
-    const int half = d.N >> 1;
-#pragma unroll
-    for (int ps = 0; ps < WTM / 16; ++ps) {
-      const int row = ps * 16 + (lane >> 2), q = (lane & 3) * 4;
-      const int m = wm0 + row;
-      if (m >= d.M) continue;
-      float4 v = *(const float4*)(sC + row * LDW + q);
-      float4 g = *(const float4*)(sC + row * LDW + 16 + q);
-      const int col = ocol0 + q;
-      v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
-      g.x *= d.acc_scale; g.y *= d.acc_scale; g.z *= d.acc_scale; g.w *= d.acc_scale;
-      if (d.bias) {
-        const float4 bv = *(const float4*)(d.bias + col), bg = *(const float4*)(d.bias + half + col);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
-      }
-      v.x *= gelu_erf(g.x); v.y *= gelu_erf(g.y); v.z *= gelu_erf(g.z); v.w *= gelu_erf(g.w);
-      if (d.out) *(float4*)(d.out + (size_t)m * d.ldo + col) = v;
-      if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, col, v.x, v.y, v.z, v.w);
+    if (FULL || it + 1 < nkt)
+      read_frags(br, (blk + (last_tap ? 1 : 0)) & 1, last_tap ? 0 : tap + 1, fah[Pq ^ 1], fal[Pq ^ 1], fbh[Pq ^ 1], fbl[Pq ^ 1]);
+    mfma_tile(fah[Pq], fal[Pq], fbh[Pq], fbl[Pq]);
+    if (FULL) {
+      constexpr int NM = TM * TN * NS, NR = (TM + TN) * (NS >= 3 ? 2 : 1);
+      sched_pattern<0, LPS + NR, NM, LPS>();
     }
-    return;
+    bs = bs + 1 == NB ? 0 : bs + 1;
+    br = br + 1 == NB ? 0 : br + 1;
+    tap = last_tap ? 0 : tap + 1;
+    blk += last_tap ? 1 : 0;
+  };
+  using std::integral_constant;
+  int it = 0;
+  for (; it + NB + 1 < nkt; it += 2) {
+    step(integral_constant<int, 0>{}, integral_constant<bool, true>{}, it);
+    step(integral_constant<int, 1>{}, integral_constant<bool, true>{}, it + 1);
   }
-  if (d.epi == MVD_EPI_QKV) {     // a 32-column aligned wave tile lies inside one of q / k / v
-    const int C = d.heads * d.dhead;
-    const int which = wn0 / C;
-    if (which < 2) {
-      const int dq = mvd_attn_dpad(d.dhead);
-      u16* ph = (u16*)(which == 0 ? d.q_hi : d.k_hi);
-      u16* pl = (u16*)(which == 0 ? d.q_lo : d.k_lo);
-#pragma unroll
-      for (int ps = 0; ps < WTM / 8; ++ps) {
-        const int row = ps * 8 + (lane >> 3), col = (lane & 7) * 4;
-        const int m = wm0 + row, n = wn0 + col;
-        if (m >= d.M) continue;
-        float4 v = *(const float4*)(sC + row * LDW + col);
-        const int cc = n - which * C;
-        const int head = cc / d.dhead, dd = cc - head * d.dhead;
-        const int b = m / d.L, tok = m - b * d.L;
-        const size_t idx = ((size_t)(b * d.heads + head) * d.Lpad + tok) * dq + dd;
-        const float qs = which == 0 ? d.qscale : 1.0f;
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.bias) bb = *(const float4*)(d.bias + n);        // in_proj bias (nn.MultiheadAttention, timm qkv_bias); SD attention has none
-        store_planes4(ph, pl, idx, (v.x * d.acc_scale + bb.x) * qs, (v.y * d.acc_scale + bb.y) * qs, (v.z * d.acc_scale + bb.z) * qs,
-                      (v.w * d.acc_scale + bb.w) * qs);
-      }
-    } else {                      // V^T: each lane takes 4 consecutive tokens of one channel (8-byte stores, keys contiguous)
-      const int dv = (d.dhead + 15) & ~15;
-      const int col = lane & 31, rsel = lane >> 5;
-      const int cc = wn0 + col - 2 * C;
-      const int head = cc / d.dhead, dd = cc - head * d.dhead;
-#pragma unroll
-      for (int ps = 0; ps < WTM / 8; ++ps) {
-        const int row = (ps * 2 + rsel) * 4;
-        const int m = wm0 + row;
-        if (m >= d.M) continue;
-        const int b = m / d.L, tok = m - b * d.L;
-        const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
-        const float bv = d.bias ? d.bias[wn0 + col] : 0.f;
-        store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, sC[row * LDW + col] * d.acc_scale + bv, sC[(row + 1) * LDW + col] * d.acc_scale + bv,
-                      sC[(row + 2) * LDW + col] * d.acc_scale + bv, sC[(row + 3) * LDW + col] * d.acc_scale + bv);
-      }
-    }
-    return;
-  }
-  }
-  // MVD_EPI_STORE
-#pragma unroll
-  for (int ps = 0; ps < (WTM * C4 + 63) / 64; ++ps) {
-    const int idx = ps * 64 + lane;
-    const int row = idx / C4, col = (idx - row * C4) * 4;
-    const int m = wm0 + row, n = wn0 + col;
-    if (idx >= WTM * C4 || m >= d.M || n >= d.N) continue;
-    const float4 v = *(const float4*)(sC + row * LDW + col);
-    if (n + 3 < d.n_store) {
-      const float4 f = epi_store4(d, m, n, v);
-      if (d.gn_stats) *(float4*)(sC + row * LDW + col) = f;      // final values back into the staging tile for the statistics pass
-    } else {
-      epi_store_elem(d, m, n, v.x);
-      epi_store_elem(d, m, n + 1, v.y);
-      epi_store_elem(d, m, n + 2, v.z);
-      epi_store_elem(d, m, n + 3, v.w);
-    }
-  }
-  if (d.gn_stats) {
-    // GroupNorm statistics of the tensor just produced, for the GroupNorm that consumes it (mvd_groupnorm_from_stats): one lane
-    // per column sums its 16-row slabs in row order, the first lane of every (group, slab) fragment adds up its columns in
-    // column order and hands the pair to the integer atomics.  (The wave owns its staging tile: LDS ops of one wave are ordered.)
-    const int cg = d.n_store / d.gn_groups;
-    const int jmax = cg < 64 ? cg : 64;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c0 = 0; c0 < WTN; c0 += 64) {
-      const int col = c0 + lane, n = wn0 + col;
-      const bool okc = col < WTN && n < d.n_store;
-      const int gidx = okc ? n / cg : 0, pos = okc ? n - gidx * cg : 0;
-      const bool leader = okc && (pos == 0 || lane == 0);
-      int len = 0;
-      if (leader) {
-        len = cg - pos;
-        if (len > 64 - lane) len = 64 - lane;
-        if (len > WTN - col) len = WTN - col;
-        if (len > d.n_store - n) len = d.n_store - n;
-      }
-      // images at least as tall as the wave tile (gn_hw % WTM == 0): one pair of atomics per wave tile and group fragment -- the
-      // 16-row slabs are summed in row order first; shorter images: one pair per slab
-      const bool whole = d.gn_hw % WTM == 0;
-      float s1 = 0.f, q1 = 0.f;
-#pragma unroll
-      for (int sl = 0; sl < WTM / 16; ++sl) {
-        const int ms = wm0 + sl * 16;
-        if (ms >= d.M) break;
-        if (!whole) s1 = q1 = 0.f;
-        if (okc) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = sC[(sl * 16 + r) * LDW + col];
-            s1 += v;
-            q1 += v * v;
-          }
-        }
-        if (whole && sl + 1 < WTM / 16 && ms + 16 < d.M) continue;
-        float ss = s1, qq = q1;
-        for (int j = 1; j < jmax; ++j) {
-          const float ts = __shfl_down(s1, j, 64), tq = __shfl_down(q1, j, 64);
-          if (j < len) {
-            ss += ts;
-            qq += tq;
-          }
-        }
-        if (leader) gn_stats_add(d.gn_stats, ms / d.gn_hw, gidx, d.gn_groups, ss, qq);
-      }
-    }
-  }
+  unroll_steps<0, NB + 1>([&](auto j) {
+    constexpr int J = decltype(j)::value;
+    if (it + J < nkt) step(integral_constant<int, J & 1>{}, integral_constant<bool, false>{}, it + J);
+  });
+  __syncthreads();   // the epilogue reuses the patch / stage buffers
+  tile_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------------------ split-K reduce
@@ -780,10 +1053,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmParams p) 
   gn_stats_add(d.gn_stats, m0 / d.gn_hw, g, d.gn_groups, ss, qq);
 }
 
-// Tile configurations (mvd_gemm_desc.cfg = 1 + 6 * tile + 2 * loop + order; 0 = built-in heuristic).
+// Tile configurations (mvd_gemm_desc.cfg = 1 + 16 * tile + 2 * loop + order; 0 = built-in heuristic).
 //   tile : 0 = 64x64 (2x2 waves)  1 = 128x128 (2x4)  2 = 128x80 (4x1)  3 = 64x80 (4x1)  4 = 128x160 (4x2)
 //   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop, 2 = staggered wave groups, 3 LDS buffers (8-wave tiles 1 and
-//          4 only), 3 = staggered, 4 LDS buffers (tile 1 only: 128 KiB)
+//          4 only), 3 = staggered, 4 LDS buffers (tile 1 only: 128 KiB), 4 = register-pipelined loop over a ring of <= 4 LDS buffers,
+//          5 = over a ring of <= 8 (4-wave tiles 0, 2, 3 only: the 8-wave tiles fit 4), 6 = conv_patch_kernel (stride-1 3x3 convolutions, tiles 1, 2, 4)
 //   order : 0 = n-fastest tile order, 1 = m-fastest
 // The 80-column family serves MVD_EPI_STORE only (GEGLU / QKV epilogues address 32-column wave tiles).
 struct TileInfo {
@@ -800,9 +1074,9 @@ static const TileInfo kTiles[MVD_GEMM_TILES] = {{64, 64, 4, 5, 3}, {128, 128, 8,
 static int choose_splits(long tiles, int nk, const TileInfo& ti, int loop, size_t mn) {
   const double area = (double)ti.bm * ti.bn / (128.0 * 128.0);
   const double t_mfma = 0.75 * area;                 // MFMA-pipe time of one k-tile of one workgroup
-  const double t_lat = loop == 0 ? 1.0 : (loop == 1 ? 0.4 : (loop == 2 ? 0.2 : 0.1));   // exposed DMA latency per k-tile, workgroup alone
+  const double t_lat = loop == 0 ? 1.0 : (loop == 1 ? 0.4 : (loop == 2 ? 0.2 : (loop == 5 ? 0.05 : 0.1)));      // (loops 3, 4, 6: 0.1)   // exposed DMA latency per k-tile, workgroup alone
   const double t_epi = 0.27 + 1.73 * area;
-  const int coresident = loop == 0 ? ti.cores_plain : (loop == 1 ? ti.cores_pipe : 1);
+  const int coresident = loop == 0 ? ti.cores_plain : (loop == 1 ? ti.cores_pipe : (loop == 4 && ti.waves == 4 ? 2 : 1));
   const double red_fixed = 6.0, red_per_split = (double)mn * 8.0 / 3.0e12 / 0.7e-6;
   int best = 1;
   double best_t = 1e30;
@@ -837,7 +1111,47 @@ void launch_cfg(GemmParams& p, hipStream_t s) {
   if (conv && ns == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_CONV3X3, STAGES>), grid, block, 0, s, p);
 }
 
+template <int BM, int BN, int WM, int WN>
+void launch_patch(GemmParams& p, hipStream_t s, int pi) {
+  dim3 grid(p.tiles_n * p.tiles_m, 1, p.splits), block(WM * WN * 64);
+  const int ns = p.d.prec;
+#define MVD_PATCH_CASE(NS_, PI_) \
+  if (ns == NS_ && pi == PI_) hipLaunchKernelGGL((conv_patch_kernel<BM, BN, WM, WN, NS_, PI_>), grid, block, 0, s, p);
+  MVD_PATCH_CASE(4, 1) MVD_PATCH_CASE(4, 2) MVD_PATCH_CASE(3, 1) MVD_PATCH_CASE(3, 2) MVD_PATCH_CASE(1, 1) MVD_PATCH_CASE(1, 2)
+#undef MVD_PATCH_CASE
+}
+
+// conv_patch_kernel serves stride-1, padded 3x3 convolutions whose BM-row tiles are whole image rows of one image or whole images;
+// returns the patch DMAs per wave and k-tile (1 or 2), 0 when the problem does not fit.
+static int patch_shares(const mvd_gemm_desc& d, const TileInfo& ti) {
+  if (d.a_mode != MVD_A_CONV3X3 || d.b_mode != MVD_B_PACKED || d.stride != 1 || d.upsample || d.no_pad_tl) return 0;
+  if (d.Hin != d.Hout || d.Win != d.Wout || ti.bm != 128) return 0;
+  const int W = d.Wout, HW = d.Hout * d.Wout;
+  if (ti.bm % W != 0 || (HW >= ti.bm ? HW % ti.bm != 0 : ti.bm % HW != 0)) return 0;
+  const int nseg = HW >= ti.bm ? 1 : ti.bm / HW, Rb = HW >= ti.bm ? ti.bm / W : d.Hout;
+  const int P = nseg * (Rb + 2) * (W + 2);
+  if (P > MVD_PATCH_SLOTS_MAX) return 0;
+  const int PG = (P + 7) / 8, cap = (11 - conv_patch_ring(ti.bn, ti.waves)) * ti.waves;
+  return PG <= cap ? 1 : (PG <= 2 * cap ? 2 : 0);
+}
+
+static bool cfg_supported(const mvd_gemm_desc& d, int cfg) {
+  if (cfg == 0) return true;
+  if (cfg < 0 || cfg > 16 * MVD_GEMM_TILES) return false;
+  const int tile = (cfg - 1) / 16, loop = ((cfg - 1) % 16) >> 1;
+  if (loop >= MVD_GEMM_LOOPS) return false;
+  if (tile >= 2 && d.epi != MVD_EPI_STORE) return false;
+  const int waves = kTiles[tile].waves;
+  if ((loop == 2 || loop == 3) && waves != 8) return false;
+  if (loop == 3 && tile != 1) return false;
+  if (loop == 5 && waves != 4) return false;
+  if (loop == 6) return (tile == 1 || tile == 2 || tile == 4) && patch_shares(d, kTiles[tile]) > 0;
+  return true;
+}
+
 }  // namespace
+
+extern "C" int mvd_gemm_cfg_supported(const mvd_gemm_desc* dp, int cfg) { return dp && cfg_supported(*dp, cfg) ? 1 : 0; }
 
 extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   MVD_CHECK_ARG(dp != nullptr, "mvd_gemm: null descriptor");
@@ -898,14 +1212,13 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   p.nt16 = d.N / 16;
   // ---- kernel configuration: explicit (cfg >= 1) or the built-in heuristic (128x128 once the grid fills the chip, else 64x64)
   int tile, loop = 0, order = -1;
-  MVD_CHECK_ARG(d.cfg >= 0 && d.cfg <= 8 * MVD_GEMM_TILES, "mvd_gemm: bad cfg %d", d.cfg);
+  MVD_CHECK_ARG(d.cfg >= 0 && d.cfg <= 16 * MVD_GEMM_TILES, "mvd_gemm: bad cfg %d", d.cfg);
   if (d.cfg >= 1) {
-    tile = (d.cfg - 1) / 8;
-    loop = ((d.cfg - 1) % 8) >> 1;
+    tile = (d.cfg - 1) / 16;
+    loop = ((d.cfg - 1) % 16) >> 1;
     order = (d.cfg - 1) & 1;
-    MVD_CHECK_ARG(tile < 2 || d.epi == MVD_EPI_STORE, "mvd_gemm: cfg %d (80-column tile) serves MVD_EPI_STORE only", d.cfg);
-    MVD_CHECK_ARG(loop < 2 || kTiles[tile].waves == 8, "mvd_gemm: cfg %d: the staggered loop needs an 8-wave tile", d.cfg);
-    MVD_CHECK_ARG(loop < 3 || tile == 1, "mvd_gemm: cfg %d: four LDS buffers fit the 128x128 tile only", d.cfg);
+    MVD_CHECK_ARG(cfg_supported(d, d.cfg), "mvd_gemm: cfg %d (tile %d, loop %d) does not serve this problem (include/mvd_hip.h: cfg)", d.cfg, tile,
+                  loop);
   } else {
     const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
     tile = (tiles128 >= 128 && (d.N >= 512 || d.K >= 2048)) ? 1 : 0;
@@ -934,22 +1247,34 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     }
   }
   p.kt_per_split = cdiv(p.nk, splits);
+  if (loop == 6) p.kt_per_split = 9 * cdiv(p.nk / 9, splits);       // conv_patch_kernel: a split is a run of whole channel blocks
   p.splits = cdiv(p.nk, p.kt_per_split);
   hipStream_t s = (hipStream_t)stream;
-  switch (tile * 4 + loop) {
+  switch (tile * 8 + loop) {
     case 0: launch_cfg<64, 64, 2, 2, 2>(p, s); break;
     case 1: launch_cfg<64, 64, 2, 2, 3>(p, s); break;
-    case 4: launch_cfg<128, 128, 2, 4, 2>(p, s); break;
-    case 5: launch_cfg<128, 128, 2, 4, 3>(p, s); break;
-    case 6: launch_cfg<128, 128, 2, 4, 4>(p, s); break;
-    case 7: launch_cfg<128, 128, 2, 4, 5>(p, s); break;
-    case 8: launch_cfg<128, 80, 4, 1, 2>(p, s); break;
-    case 9: launch_cfg<128, 80, 4, 1, 3>(p, s); break;
-    case 12: launch_cfg<64, 80, 4, 1, 2>(p, s); break;
-    case 13: launch_cfg<64, 80, 4, 1, 3>(p, s); break;
-    case 16: launch_cfg<128, 160, 4, 2, 2>(p, s); break;
-    case 17: launch_cfg<128, 160, 4, 2, 3>(p, s); break;
-    case 18: launch_cfg<128, 160, 4, 2, 4>(p, s); break;
+    case 4: launch_cfg<64, 64, 2, 2, 6>(p, s); break;
+    case 5: launch_cfg<64, 64, 2, 2, 7>(p, s); break;
+    case 8: launch_cfg<128, 128, 2, 4, 2>(p, s); break;
+    case 9: launch_cfg<128, 128, 2, 4, 3>(p, s); break;
+    case 10: launch_cfg<128, 128, 2, 4, 4>(p, s); break;
+    case 11: launch_cfg<128, 128, 2, 4, 5>(p, s); break;
+    case 12: launch_cfg<128, 128, 2, 4, 6>(p, s); break;
+    case 16: launch_cfg<128, 80, 4, 1, 2>(p, s); break;
+    case 17: launch_cfg<128, 80, 4, 1, 3>(p, s); break;
+    case 20: launch_cfg<128, 80, 4, 1, 6>(p, s); break;
+    case 21: launch_cfg<128, 80, 4, 1, 7>(p, s); break;
+    case 24: launch_cfg<64, 80, 4, 1, 2>(p, s); break;
+    case 25: launch_cfg<64, 80, 4, 1, 3>(p, s); break;
+    case 28: launch_cfg<64, 80, 4, 1, 6>(p, s); break;
+    case 29: launch_cfg<64, 80, 4, 1, 7>(p, s); break;
+    case 32: launch_cfg<128, 160, 4, 2, 2>(p, s); break;
+    case 33: launch_cfg<128, 160, 4, 2, 3>(p, s); break;
+    case 34: launch_cfg<128, 160, 4, 2, 4>(p, s); break;
+    case 36: launch_cfg<128, 160, 4, 2, 6>(p, s); break;
+    case 14: launch_patch<128, 128, 2, 4>(p, s, patch_shares(d, ti)); break;
+    case 22: launch_patch<128, 80, 4, 1>(p, s, patch_shares(d, ti)); break;
+    case 38: launch_patch<128, 160, 4, 2>(p, s, patch_shares(d, ti)); break;
     default: MVD_CHECK_ARG(false, "mvd_gemm: no kernel for tile %d loop %d", tile, loop);
   }
   MVD_CHECK_LAUNCH("mvd_gemm");

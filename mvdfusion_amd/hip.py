@@ -52,6 +52,7 @@ SIGNATURES = {
     "mvd_pack_linear_weight": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "mvd_pack_conv3x3_weight": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "mvd_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "mvd_gemm_cfg_supported": (_i, [C.POINTER(GemmDesc), _i]),
     "mvd_split_planes": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp]),
     "mvd_gemv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_groupnorm_chunks": (_i, [_i]),
@@ -355,7 +356,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     if cfg is None:
         tuned = _TUNED.get(key)
         if tuned is None and AUTOTUNE:
-            tuned = _autotune(d, A if A.is_contiguous() else None)
+            tuned = _autotune(d, A if A.is_contiguous() else None, W_data=W.data if not isinstance(W, PlanesOperand) else None)
             _TUNED[key] = tuned
         if tuned is not None:
             cfg, d.splitk = tuned
@@ -366,28 +367,49 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     return out
 
 
-# mvd_gemm_desc.cfg = 1 + 8 * tile + 2 * loop + order (include/mvd_hip.h)
+# mvd_gemm_desc.cfg = 1 + 16 * tile + 2 * loop + order (include/mvd_hip.h)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
-GEMM_LOOPS = (2, 3, 4, 5)       # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups (3 / 4 LDS buffers)
+GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
+                                 # (3 / 4 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
+                                 # (stride-1 3x3 convolutions: the input patch is staged once per channel block)
+PATCH_LOOP = 6
 
 
 def _cfg_parts(cfg):
-    return (cfg - 1) // 8, ((cfg - 1) % 8) >> 1, (cfg - 1) & 1          # tile, loop, order
+    return (cfg - 1) // 16, ((cfg - 1) % 16) >> 1, (cfg - 1) & 1          # tile, loop, order
+
+
+def make_cfg(tile, loop, order=0):
+    return 1 + 16 * tile + 2 * loop + order
 
 
 def _cfg_valid(cfg, epi, b_mode=0):
     tile, loop, _ = _cfg_parts(cfg)
+    if loop >= len(GEMM_LOOPS):
+        return False
     bm, bn, wm, wn = GEMM_TILES[tile]
-    return (loop < 2 or wm * wn == 8) and (loop < 3 or tile == 1) and (tile < 2 or epi == EPI_STORE)
+    waves = wm * wn
+    return (loop not in (2, 3) or waves == 8) and (loop != 3 or tile == 1) and (loop != 5 or waves == 4) and \
+        (loop != PATCH_LOOP or tile in (1, 2, 4)) and (tile < 2 or epi == EPI_STORE)
 
 
-GEMM_CONFIGS = tuple(c for c in range(1, 8 * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
+_ALL_CONFIGS = tuple(c for c in range(1, 16 * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
+GEMM_CONFIGS = tuple(c for c in _ALL_CONFIGS if _cfg_parts(c)[1] != PATCH_LOOP)       # serve every problem kind (dense and conv)
+PATCH_CONFIGS = tuple(c for c in _ALL_CONFIGS if _cfg_parts(c)[1] == PATCH_LOOP)      # stride-1 padded 3x3 convolutions only
+GEMM_CONFIGS_CONV = GEMM_CONFIGS + PATCH_CONFIGS
 
 
-def gemm_configs(epi=EPI_STORE, b_mode=0):
+def gemm_configs(epi=EPI_STORE, b_mode=0, conv=False):
     """Kernel configurations valid for an epilogue / B operand kind (the 80-column tiles serve EPI_STORE only; the staggered loop
-    needs an 8-wave tile; every configuration serves both B operand kinds)."""
-    return tuple(c for c in GEMM_CONFIGS if _cfg_valid(c, epi, b_mode))
+    needs an 8-wave tile; every configuration serves both B operand kinds); conv: + the input-patch kernel (whether it takes a
+    given convolution: cfg_supported)."""
+    return tuple(c for c in (GEMM_CONFIGS_CONV if conv else GEMM_CONFIGS) if _cfg_valid(c, epi, b_mode))
+
+
+def cfg_supported(d, cfg):
+    """Whether kernel configuration `cfg` serves the problem of the GemmDesc `d` (mvd_gemm_cfg_supported: e.g. the input-patch loop
+    only takes stride-1 padded 3x3 convolutions whose tiles are whole image rows / whole images)."""
+    return bool(lib().mvd_gemm_cfg_supported(C.byref(d), cfg))
 
 
 def kernel_symbol(cfg, prec, conv):
@@ -396,6 +418,8 @@ def kernel_symbol(cfg, prec, conv):
         return f"gemm_kernel<auto, {prec}, {1 if conv else 0}>"
     tile, loop, _ = _cfg_parts(cfg)
     bm, bn, wm, wn = GEMM_TILES[tile]
+    if loop == PATCH_LOOP:
+        return f"conv_patch_kernel<{bm}, {bn}, {wm}, {wn}, {prec}>"
     return f"gemm_kernel<{bm}, {bn}, {wm}, {wn}, {prec}, {1 if conv else 0}, {GEMM_LOOPS[loop]}>"
 
 
@@ -431,7 +455,7 @@ def _flush_caches():
     _TRASH.add_(1.0)
 
 
-def _autotune(d, A=None, reps=4, trials=3):
+def _autotune(d, A=None, reps=4, trials=3, W_data=None):
     """Time the kernel configurations (tile x loop variant x tile order; split-K follows from the library's model)
     on the actual operands -- the op is idempotent -- and return the fastest.
 
@@ -443,19 +467,31 @@ def _autotune(d, A=None, reps=4, trials=3):
     e0, e1 = Event(), Event()
     stats_ptr, d.gn_stats = d.gn_stats, None          # the statistics atomics must run exactly once: only in the real launch
     # split-K: the library's model (0 = auto) or none (1); the timed region includes the reduce kernel of a split GEMM
-    cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode) for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]
+    cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode, conv=d.a_mode == A_CONV3X3) if cfg_supported(d, c)
+             for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]
+    # three cold copies of the packed weight, launched back to back between one pair of events: the eager launch latency (a few us
+    # of jitter, the size of the differences being ranked) is paid once per three kernels and hides behind the first one
+    wp0 = d.Wp
+    rot = [wp0]
+    if TUNE_COLD and A is not None and d.b_mode == 0:
+        if W_data is not None and W_data.data_ptr() == wp0:
+            rot += [W_data.clone(), W_data.clone()]
+    ptrs = [wp0] + [t.data_ptr() for t in rot[1:]]
     for cfg, sk in cands:
         d.cfg, d.splitk = cfg, sk
         check(lib().mvd_gemm(C.byref(d), stream()))
         ms = float("inf")
         if TUNE_COLD and A is not None:
-            for _ in range(trials + 2):
+            for _ in range(trials + 1):
                 _flush_caches()
                 A.view(-1)[:A.numel() // 2 * 2].view(torch.int32).sum()        # the producer of A just ran: A is cache-warm
                 e0.record()
-                check(lib().mvd_gemm(C.byref(d), stream()))
+                for wp in ptrs:
+                    d.Wp = wp
+                    check(lib().mvd_gemm(C.byref(d), stream()))
                 e1.record()
-                ms = min(ms, e0.elapsed_ms(e1))
+                ms = min(ms, e0.elapsed_ms(e1) / len(ptrs))
+            d.Wp = wp0
         else:
             for _ in range(trials):
                 e0.record()

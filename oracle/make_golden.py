@@ -132,7 +132,7 @@ def gold_cameras():
     print("  cameras: rig / re-basing / project / unproject agree with the reference call sites")
 
 
-def _gridattn_case(V, D, S, seed, t_val):
+def _gridattn_case(V, D, S, seed, t_val, tokens=True, tol=2e-5):
     from mvdfusion.view_attn_efficient2 import GridAttn
     from mvdfusion.scheduler import DDPMScheduler
     ga = GridAttn(in_channels=5, input_size=S, output_dim=768, num_layers=3, z_near_far_scale=0.8, n_pts_per_ray=D)
@@ -157,10 +157,10 @@ def _gridattn_case(V, D, S, seed, t_val):
                                   inp["input_latents"], cam_dict(inp["input_cameras"]), n_pts_per_ray=D)
         tokens = O.gridattn_forward(sd, "view_attn.", x, cam_dict(inp["batch_cameras"]), t_embed, t, tab, depth_noise,
                                     inp["input_latents"], cam_dict(inp["input_cameras"]), n_pts_per_ray=D,
-                                    return_tokens=True)
+                                    return_tokens=True) if tokens else torch.zeros(97, 1, 1)
     e = rel_err(mine, ref)
     print(f"  gridattn V={V} D={D} S={S} t={t_val}: oracle vs reference rel-max err {e:.2e}")
-    assert e < 2e-5, e
+    assert e < tol, e
     return dict(x=x, t_embed=t_embed, t=t, depth_noise=depth_noise, out=ref, seed=np.int64(seed),
                 tokens_sample=tokens[::97][:, :, :].contiguous(), tokens_stride=np.int64(97))
 
@@ -308,6 +308,15 @@ def gold_gridattn_v15():
     c.pop("tokens_sample")
     save("gridattn_v15_d1", out_strided=out[:, ::5, ::7, :, ::3], out_mean=out.mean(), out_std=out.std(),
          out_l2=out.norm(), **c)
+
+
+def gold_gridattn_v8_s64():
+    """BASELINE configs[3]'s cross-view problem: V = 8 views x 64x64 latents (T = 262 144 tokens, 0.94 TFLOP): strided lattice +
+    norms of the (8, 64, 64, 1, 768) feature frustum."""
+    c = _gridattn_case(8, 1, 64, 5, 401, tokens=False, tol=5e-5)      # (fp32 restatement vs reference at 262 144 tokens: 3.3e-5)
+    out = c.pop("out")
+    c.pop("tokens_sample")
+    save("gridattn_v8_d1_s64", out_strided=out[:, ::5, ::7, :, ::3], out_mean=out.mean(), out_std=out.std(), out_l2=out.norm(), **c)
 
 
 def gold_trajectory(model_channels, V, D, tag, steps=5, S=32):
@@ -699,6 +708,8 @@ ALL = {
     "step320": lambda: gold_step(320, 4, 1, "step_mc320_v4_d1", indices=(49, 0)),
     "step32_s64": lambda: gold_step(32, 4, 1, "step_mc32_v4_d1_s64", indices=(49, 0), S=64, lean=True),
     "step320_v8": lambda: gold_step(320, 8, 1, "step_mc320_v8_d1", indices=(49,), lean=True),
+    "step320_v8_s64": lambda: gold_step(320, 8, 1, "step_mc320_v8_d1_s64", indices=(49,), S=64, lean=True),      # BASELINE configs[3]
+    "gridattn_v8_s64": gold_gridattn_v8_s64,
     "unet320_s64": lambda: gold_unet(320, 2, 1, "unet_mc320_v2_d1_s64", S=64, full=False),
     "unet320_d3": lambda: gold_unet(320, 2, 3, "unet_mc320_v2_d3", t_val=501),
     "gridattn_v15": gold_gridattn_v15,

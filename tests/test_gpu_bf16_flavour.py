@@ -1,0 +1,35 @@
+"""The bf16 flavour of the library (libmvd_hip_bf16.so: the same sources with -DMVD_OPERAND_BF16, bf16 MFMA operands hi + lo, three
+partial products) -- BASELINE.json configs[3] names bf16.  The operand type is fixed per process (MVD_OPERAND_FORMAT is read at
+import), so the op-level tests and one denoising-step golden are re-run in a SUBPROCESS with MVD_OPERAND_FORMAT=bf16: every kernel of
+that .so executes and is checked against the same references with the bf16x3 tolerances the tests carry."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=1500):
+    env = dict(os.environ, MVD_OPERAND_FORMAT="bf16")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    tail = (r.stdout[-2500:] + "\n" + r.stderr[-1500:])
+    assert r.returncode == 0, tail
+    return r.stdout
+
+
+def test_bf16_flavour_op_tests():
+    out = _run([os.path.join("tests", "test_gpu_ops.py")])
+    assert " passed" in out and "failed" not in out, out[-800:]
+
+
+def test_bf16_flavour_denoise_step_and_gridattn_goldens():
+    out = _run([os.path.join("tests", "test_gpu_model.py"), "-k",
+                "test_denoise_step_vs_reference_golden or test_gridattn_vs_reference_golden or test_graph_replay_equals_eager"])
+    assert " passed" in out and "failed" not in out, out[-800:]
+    import ctypes
+    from mvdfusion_amd import hip
+    assert ctypes.CDLL(hip.LIB_PATHS["bf16"]).mvd_operand_format() == 0xbf16

@@ -191,16 +191,34 @@ def test_conv3x3(hip, prec, case):
              conv=dict(B=B, Hin=H, Win=H, Cin=cin_pad, Hout=Ho, Wout=Ho, stride=stride, upsample=up))
     got = out[:, :Cout].view(B, Ho, Ho, Cout).permute(0, 3, 1, 2)
     assert rel_err(got, ref) < TOL[prec]
+    # the input-patch kernel (stride-1 convolutions): every precision, bias, ragged N; bit-equal to the implicit-GEMM kernel
+    served = 0
+    for cfg in hip.PATCH_CONFIGS[::2]:
+        out2 = torch.zeros_like(out)
+        try:
+            hip.gemm(xp, Wp, out2, prec=prec, workspace=ws, ldo=ldo, cfg=cfg, splitk=1,
+                     conv=dict(B=B, Hin=H, Win=H, Cin=cin_pad, Hout=Ho, Wout=Ho, stride=stride, upsample=up))
+        except RuntimeError as e:
+            assert "does not serve" in str(e)
+            continue
+        served += 1
+        base = torch.zeros_like(out)
+        hip.gemm(xp, Wp, base, prec=prec, workspace=ws, ldo=ldo, cfg=1, splitk=1,
+                 conv=dict(B=B, Hin=H, Win=H, Cin=cin_pad, Hout=Ho, Wout=Ho, stride=stride, upsample=up))
+        assert torch.equal(out2, base), (case, cfg)
+    assert served == (0 if case in ("s2", "up") else len(hip.PATCH_CONFIGS[::2])), (case, served)
 
 
-@pytest.mark.parametrize("cfg", list(_hip.GEMM_CONFIGS))
+@pytest.mark.parametrize("cfg", list(_hip.GEMM_CONFIGS_CONV))
 @pytest.mark.parametrize("splitk", [0, 1, 3])
 def test_gemm_configurations_agree(hip, cfg, splitk):
     """Every kernel configuration the autotuner may pick (tile x loop variant x tile order, include/mvd_hip.h `cfg`), with and
     without split-K, on conv and dense problems with even and odd k-tile counts: all must match the fp32 reference AND be
     repeatable bit for bit (a stale-accumulator miscompile of one instantiation showed up exactly here)."""
     ws = torch.empty(16 * 1024 * 1024, device="cuda")
-    for B, H, Cin, Cout in [(2, 32, 64, 64), (2, 16, 96, 320), (1, 8, 320, 48)]:       # nk = 18, 27, 90
+    # nk = 18, 27, 90, 18, 9; the input-patch kernel (hip.PATCH_CONFIGS) meets tiles of 4 rows of one image, half an image, 2 images (one
+    # past M), 8 whole 4x4 images and 2 rows of a 64-wide image (the last two need two patch DMAs per wave and k-tile at 128x80)
+    for B, H, Cin, Cout in [(2, 32, 64, 64), (2, 16, 96, 320), (1, 8, 320, 48), (11, 4, 64, 80), (1, 64, 32, 80)]:
         x = torch.randn(B, Cin, H, H, generator=g(40))
         w = torch.randn(Cout, Cin, 3, 3, generator=g(41)) / math.sqrt(9 * Cin)
         ref = F.conv2d(x, w, None, padding=1).permute(0, 2, 3, 1).reshape(B * H * H, Cout)
@@ -214,7 +232,14 @@ def test_gemm_configurations_agree(hip, cfg, splitk):
             outs.append(out.cpu())
         assert rel_err(outs[0], ref) < TOL[4], (B, H, Cin, Cout)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        if splitk == 1:      # without split-K every tile / loop variant sums each output's k-tiles in the same order: bit-equal to cfg 1
+            base = torch.empty(B * H * H, Cout, device="cuda")
+            hip.gemm(xp, Wp, base, prec=4, workspace=ws, cfg=1, splitk=1,
+                     conv=dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, upsample=0))
+            assert torch.equal(base.cpu(), outs[0]), (B, H, Cin, Cout)
     for M, N, K in [(2048, 320, 320), (512, 640, 2592), (100, 48, 96)]:                   # nk = 10, 81, 3
+        if cfg in hip.PATCH_CONFIGS:
+            break                                                                          # (convolutions only)
         a = torch.randn(M, K, generator=g(42))
         w = torch.randn(N, K, generator=g(43)) / math.sqrt(K)
         ref = a @ w.t()
@@ -227,6 +252,10 @@ def test_gemm_configurations_agree(hip, cfg, splitk):
             outs.append(out.cpu())
         assert rel_err(outs[0], ref) < TOL[4], (M, N, K)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        if splitk == 1:
+            base = torch.empty(M, N, device="cuda")
+            hip.gemm(ap, Wp, base, prec=4, workspace=ws, cfg=1, splitk=1)
+            assert torch.equal(base.cpu(), outs[0]), (M, N, K)
 
 
 @pytest.mark.parametrize("cfg", [0] + list(_hip.gemm_configs(_hip.EPI_STORE)))
