@@ -160,6 +160,23 @@ typedef struct mvd_gemm_desc {
    * rows per image (multiple of 16).  NULL = off. */
   long long* gn_stats;
   int gn_hw, gn_groups;
+  /* Row statistics of the OUTPUT for a LayerNorm that is folded into the CONSUMER GEMM (MVD_EPI_STORE, n_store == N): rs_out =
+   * [M][rs_ld] pairs of floats {sum, sum of squares} of the stored values of row m over one column slot (a wave tile of the kernel
+   * that ran, or a 256-column span of the split-K reduce); the number of slots written per row goes to rs_count[0] (device int).
+   * rs_ld >= N / 32 (the narrowest wave tile).  No atomics: the consumer adds the slots in order.  NULL = off. */
+  float* rs_out;
+  int* rs_count;
+  int rs_ld;
+  /* LayerNorm folded into THIS GEMM (MVD_EPI_QKV / MVD_EPI_GEGLU): A holds the raw rows x (the producer's split planes), the packed
+   * weight is W' = W * diag(gamma), and the epilogue forms  rstd_m (x_m . W'_n - mean_m ln_colsum[n]) + bias[n]  with
+   * ln_colsum[n] = sum_k W'[n][k] (logical column order, like bias), bias[n] = sum_k beta[k] W[n][k] (+ the layer's own bias),
+   * mean / rstd of row m over its ln_dim real columns from the producer's ln_stats = rs_out, ln_count = rs_count, ln_ld = rs_ld,
+   * eps = ln_eps.  Exact algebra: LayerNorm is affine per row.  Runs without split-K.  NULL = off. */
+  const float* ln_stats;
+  const int* ln_count;
+  const float* ln_colsum;
+  int ln_ld, ln_dim;
+  float ln_eps;
 } mvd_gemm_desc;
 
 int mvd_gemm(const mvd_gemm_desc* d, mvd_stream_t stream);

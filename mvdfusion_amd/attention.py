@@ -56,6 +56,12 @@ class CrossAttention(nn.Module):
                 self._p[key] = hip.pack_linear(getattr(self, "to_" + key).weight)
         return self._p[key]
 
+    def packed_qkv_ln(self, norm):
+        """The fused QKV weight with the LayerNorm in front of it folded in (hip.LnFold)."""
+        if getattr(self, "_lnf", None) is None:
+            self._lnf = hip.LnFold(torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach(), self.to_v.weight.detach()], 0), None, norm)
+        return self._lnf
+
 
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
@@ -76,6 +82,12 @@ class FeedForward(nn.Module):
             self._p = (hip.pack_linear(self.net[0].proj.weight, self.net[0].proj.bias, geglu=True),
                        hip.pack_linear(self.net[2].weight, self.net[2].bias))
         return self._p
+
+    def packed_geglu_ln(self, norm):
+        """The GEGLU projection with the LayerNorm in front of it folded in (hip.LnFold)."""
+        if getattr(self, "_lnf", None) is None:
+            self._lnf = hip.LnFold(self.net[0].proj.weight, self.net[0].proj.bias, norm, geglu=True)
+        return self._lnf
 
     def packed_geglu(self):
         if self._p is not None:
@@ -109,15 +121,20 @@ class _TransformerCore(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.dim, self.n_heads, self.d_head = dim, n_heads, d_head
 
-    def self_attn(self, ctx, t, B, L, tag, o=None):
+    def self_attn(self, ctx, t, B, L, tag, o=None, t_planes=None, t_stats=None):
         """returns t + attn1(norm1(t)) pieces: the attention output `o` (pre to_out); `o` may be a wider planes buffer whose
-        first C columns receive it."""
+        first C columns receive it.  t_planes / t_stats: the producer of t wrote its split planes and row statistics -- norm1 is then
+        folded into the QKV GEMM (no LayerNorm kernel)."""
         C, M = self.dim, B * L
-        ln = ctx.ws.planes(tag + ".ln", M, C)
-        ctx.layernorm(t, ln, self.norm1, M, C)
         planes = ctx.ws.attn_planes(B, self.n_heads, L, self.d_head)
-        ctx.gemm(ln, self.attn1.packed("qkv"), None, epi=hip.EPI_QKV,
-                 qkv=dict(planes=planes, heads=self.n_heads, dhead=self.d_head, L=L))
+        qkv = dict(planes=planes, heads=self.n_heads, dhead=self.d_head, L=L)
+        if t_planes is not None:
+            fold = self.attn1.packed_qkv_ln(self.norm1)
+            ctx.gemm(t_planes, fold.w, None, epi=hip.EPI_QKV, qkv=qkv, ln=(t_stats, fold))
+        else:
+            ln = ctx.ws.planes(tag + ".ln", M, C)
+            ctx.layernorm(t, ln, self.norm1, M, C)
+            ctx.gemm(ln, self.attn1.packed("qkv"), None, epi=hip.EPI_QKV, qkv=qkv)
         if o is None:
             o = ctx.ws.planes(tag + ".o", M, C)
         hip.attention(planes, o, B, self.n_heads, L, self.d_head, prec=ctx.prec)
@@ -127,12 +144,17 @@ class _TransformerCore(nn.Module):
         """The (M, 5C) operand [g | t] of the merged ff-out / proj_out GEMM: the producer of t fills columns [4C, 5C)."""
         return ctx.ws.planes(tag + ".cat5", M, 5 * self.dim)
 
-    def feed_forward_proj(self, ctx, t2, cat5, w_merged, x, out, M, tag, gn=None):
-        """out = proj_out(t2 + ff(norm3(t2))) + x with t2's planes already in cat5[:, 4C:] (see module docstring)."""
+    def feed_forward_proj(self, ctx, t2, cat5, w_merged, x, out, M, tag, gn=None, t2_stats=None):
+        """out = proj_out(t2 + ff(norm3(t2))) + x with t2's planes already in cat5[:, 4C:] (see module docstring).  t2_stats: the row
+        statistics its producer emitted -- norm3 is then folded into the GEGLU GEMM, which reads t2's planes where they already are."""
         C = self.dim
-        ln = ctx.ws.planes(tag + ".ln", M, C)
-        ctx.layernorm(t2, ln, self.norm3, M, C)
-        ctx.gemm(ln, self.ff.packed_geglu(), None, epi=hip.EPI_GEGLU, out_planes=cat5)      # columns [0, 4C)
+        if t2_stats is not None:
+            fold = self.ff.packed_geglu_ln(self.norm3)
+            ctx.gemm(cat5[:, 2 * 4 * C:], fold.w, None, M=M, lda=5 * C, epi=hip.EPI_GEGLU, out_planes=cat5, ln=(t2_stats, fold))
+        else:
+            ln = ctx.ws.planes(tag + ".ln", M, C)
+            ctx.layernorm(t2, ln, self.norm3, M, C)
+            ctx.gemm(ln, self.ff.packed_geglu(), None, epi=hip.EPI_GEGLU, out_planes=cat5)      # columns [0, 4C)
         ctx.gemm(cat5, w_merged, out, res=x, gn=gn)
         return out
 
@@ -173,8 +195,10 @@ class SpatialTransformer(nn.Module):
         n = ctx.ws.planes("tf.n", M, C)
         ctx.groupnorm(x, n, self.norm, B, L, C, silu=False)
         t = ctx.ws.get("tf.t", (M, C))
-        ctx.gemm(n, w_in, t)
-        o = tb.self_attn(ctx, t, B, L, "tf")
+        fold = ctx.ln_fold
+        tp, rs1, rs2 = (ctx.ws.planes("tf.tp", M, C), ctx.row_stats("tf.rs1", M, C), ctx.row_stats("tf.rs2", M, C)) if fold else (None,) * 3
+        ctx.gemm(n, w_in, t, out_planes=tp, row_stats=rs1)
+        o = tb.self_attn(ctx, t, B, L, "tf", t_planes=tp, t_stats=rs1)
         # attn2 on the length-1 CLIP context: per-view vector to_out(to_v(ctx_b)), broadcast over the pixels
         a2 = tb.attn2
         xvec = getattr(ctx, "xattn_vec", None)
@@ -187,10 +211,10 @@ class SpatialTransformer(nn.Module):
             ctx.gemv_rows(a2.to_out[0].weight, a2.to_out[0].bias, v1, vec)
         t2 = ctx.ws.get("tf.t2", (M, C))
         cat5 = tb.cat5(ctx, M, "tf")
-        ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L, out_planes=cat5, out_planes_col=4 * C)
+        ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2)
         if out is None:
             out = ctx.act((M, C))
-        return tb.feed_forward_proj(ctx, t2, cat5, w_ffproj, x, out, M, "tf", gn=(B, L))
+        return tb.feed_forward_proj(ctx, t2, cat5, w_ffproj, x, out, M, "tf", gn=(B, L), t2_stats=rs2)
 
 
 class ViewAlignedFeatureTransformer(nn.Module):
@@ -237,15 +261,17 @@ class ViewAlignedFeatureTransformer(nn.Module):
         n = ctx.ws.planes("tf.n", M, C)
         ctx.groupnorm(x, n, self.aligned_attn_norm, B, L, C, silu=False)
         t = ctx.ws.get("tf.t", (M, C))
-        ctx.gemm(n, w_in, t)
+        fold = ctx.ln_fold
+        tp, rs1, rs2 = (ctx.ws.planes("tf.tp", M, C), ctx.row_stats("tf.rs1", M, C), ctx.row_stats("tf.rs2", M, C)) if fold else (None,) * 3
+        ctx.gemm(n, w_in, t, out_planes=tp, row_stats=rs1)
         t2b = ctx.ws.get("tf.t2b", (M, C))
         cat5 = tb.cat5(ctx, M, "tf")
         if D == 1:
             assert vol_col == C and vol.shape[-1] == 2 * (C + 768), (vol_col, C, vol.shape)
-            tb.self_attn(ctx, t, B, L, "tf", o=vol)            # o -> columns [0, C) of the [o | vol] operand
-            ctx.gemm(vol, self.packed_ovol(), t2b, res=t, out_planes=cat5, out_planes_col=4 * C)
+            tb.self_attn(ctx, t, B, L, "tf", o=vol, t_planes=tp, t_stats=rs1)            # o -> columns [0, C) of the [o | vol] operand
+            ctx.gemm(vol, self.packed_ovol(), t2b, res=t, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2)
         else:
-            o = tb.self_attn(ctx, t, B, L, "tf")
+            o = tb.self_attn(ctx, t, B, L, "tf", t_planes=tp, t_stats=rs1)
             t2 = ctx.ws.get("tf.t2", (M, C))
             ctx.gemm(o, tb.attn1.packed("out"), t2, res=t)
             a2 = tb.attn2.packed
@@ -259,7 +285,7 @@ class ViewAlignedFeatureTransformer(nn.Module):
             ctx.gemm(vol, a2("v"), v)
             o2 = ctx.ws.planes("tf.o2", M, C)
             hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o2), M, D, tb.n_heads, tb.d_head, hip.stream()))
-            ctx.gemm(o2, a2("out"), t2b, res=t2, out_planes=cat5, out_planes_col=4 * C)
+            ctx.gemm(o2, a2("out"), t2b, res=t2, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2)
         if out is None:
             out = ctx.act((M, C))
-        return tb.feed_forward_proj(ctx, t2b, cat5, w_ffproj, x, out, M, "tf", gn=(B, L))
+        return tb.feed_forward_proj(ctx, t2b, cat5, w_ffproj, x, out, M, "tf", gn=(B, L), t2_stats=rs2)

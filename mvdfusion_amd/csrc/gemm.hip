@@ -145,12 +145,36 @@ __host__ __device__ constexpr int conv_patch_ring(int bn, int waves) {
   return fit > 4 ? 4 : fit;
 }
 
+// LayerNorm folded into a GEMM (mvd_gemm_desc.ln_stats): mean and 1/std of row m of the A operand from the producer's per-slot
+// {sum, sum of squares} partials -- summed in slot order in double (deterministic; var = E[x^2] - mean^2 needs the headroom).
+__device__ __forceinline__ float2 ln_row_stats(const mvd_gemm_desc& d, int m) {
+  const int cnt = d.ln_count[0];
+  const float2* p = (const float2*)d.ln_stats + (size_t)m * d.ln_ld;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < cnt; i += 4) {          // four independent loads in flight per round trip; added in slot order
+    float2 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = p[min(i + j, cnt - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i + j < cnt) {
+        s += (double)v[j].x;
+        q += (double)v[j].y;
+      }
+    }
+  }
+  const double mean = s / (double)d.ln_dim;
+  double var = q / (double)d.ln_dim - mean * mean;
+  if (var < 0.0) var = 0.0;
+  return make_float2((float)mean, (float)(1.0 / sqrt(var + (double)d.ln_eps)));
+}
+
 // ------------------------------------------------------------------------------------------------ tile epilogue
 // Shared by gemm_kernel and conv_patch_kernel: the wave's accumulator tile is transposed through LDS (the stage buffers are free: the
 // caller has passed a workgroup barrier after its last fragment read) so that global traffic is row-contiguous 16-byte accesses.
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], unsigned char* smem, int m0,
-                                              int n0, int lane, int wave) {
+                                              int n0, int lane, int wave, const float* s_rows = nullptr) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int LDW = WTN + 4;                        // fp32 pitch of the epilogue staging tile
@@ -170,7 +194,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
   const int wm0 = m0 + wm * WTM, wn0 = n0 + wn * WTN;
   if (wn0 >= d.N) return;
-
+  // LayerNorm of the A rows folded in: y = rstd (acc - mean colsum) + bias; {mean, rstd} of the block tile's rows were gathered into LDS
+  // by the kernel's prologue (gemm_kernel: ln_gather_rows)
+  const bool lnf = s_rows != nullptr;
+  const float* sR = s_rows + (wave / WN) * WTM * 2;
   if (p.splits > 1) {   // raw partial sums -> workspace slab; splitk_reduce_kernel sums the slabs and applies the epilogue.
     // (Reducing inside this kernel -- last-arriving workgroup per tile behind an agent-scope release/acquire -- was
     //  built and measured: bit-identical, but 15 % slower per step.  A 128x128 tile has 64 KB slabs, far above the
@@ -200,6 +227,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       const int col = ocol0 + q;
       v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
       g.x *= d.acc_scale; g.y *= d.acc_scale; g.z *= d.acc_scale; g.w *= d.acc_scale;
+      if (lnf) {
+        const float mean = sR[row * 2], rstd = sR[row * 2 + 1];
+        const float4 sv = *(const float4*)(d.ln_colsum + col), sg = *(const float4*)(d.ln_colsum + half + col);
+        v.x = (v.x - mean * sv.x) * rstd; v.y = (v.y - mean * sv.y) * rstd; v.z = (v.z - mean * sv.z) * rstd; v.w = (v.w - mean * sv.w) * rstd;
+        g.x = (g.x - mean * sg.x) * rstd; g.y = (g.y - mean * sg.y) * rstd; g.z = (g.z - mean * sg.z) * rstd; g.w = (g.w - mean * sg.w) * rstd;
+      }
       if (d.bias) {
         const float4 bv = *(const float4*)(d.bias + col), bg = *(const float4*)(d.bias + half + col);
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
@@ -231,8 +264,13 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         const float qs = which == 0 ? d.qscale : 1.0f;
         float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
         if (d.bias) bb = *(const float4*)(d.bias + n);        // in_proj bias (nn.MultiheadAttention, timm qkv_bias); SD attention has none
-        store_planes4(ph, pl, idx, (v.x * d.acc_scale + bb.x) * qs, (v.y * d.acc_scale + bb.y) * qs, (v.z * d.acc_scale + bb.z) * qs,
-                      (v.w * d.acc_scale + bb.w) * qs);
+        v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
+        if (lnf) {
+          const float mean = sR[row * 2], rstd = sR[row * 2 + 1];
+          const float4 cs = *(const float4*)(d.ln_colsum + n);
+          v.x = (v.x - mean * cs.x) * rstd; v.y = (v.y - mean * cs.y) * rstd; v.z = (v.z - mean * cs.z) * rstd; v.w = (v.w - mean * cs.w) * rstd;
+        }
+        store_planes4(ph, pl, idx, (v.x + bb.x) * qs, (v.y + bb.y) * qs, (v.z + bb.z) * qs, (v.w + bb.w) * qs);
       }
     } else {                      // V^T: each lane takes 4 consecutive tokens of one channel (8-byte stores, keys contiguous)
       const int dv = (d.dhead + 15) & ~15;
@@ -247,8 +285,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         const int b = m / d.L, tok = m - b * d.L;
         const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
         const float bv = d.bias ? d.bias[wn0 + col] : 0.f;
-        store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, sC[row * LDW + col] * d.acc_scale + bv, sC[(row + 1) * LDW + col] * d.acc_scale + bv,
-                      sC[(row + 2) * LDW + col] * d.acc_scale + bv, sC[(row + 3) * LDW + col] * d.acc_scale + bv);
+        float t4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          t4[i] = sC[(row + i) * LDW + col] * d.acc_scale;
+          if (lnf) t4[i] = (t4[i] - sR[(row + i) * 2] * d.ln_colsum[wn0 + col]) * sR[(row + i) * 2 + 1];
+          t4[i] += bv;
+        }
+        store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, t4[0], t4[1], t4[2], t4[3]);
       }
     }
     return;
@@ -264,13 +308,30 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     const float4 v = *(const float4*)(sC + row * LDW + col);
     if (n + 3 < d.n_store) {
       const float4 f = epi_store4(d, m, n, v);
-      if (d.gn_stats) *(float4*)(sC + row * LDW + col) = f;      // final values back into the staging tile for the statistics pass
+      if (d.gn_stats || d.rs_out) *(float4*)(sC + row * LDW + col) = f;      // final values back into the staging tile for the statistics passes
     } else {
       epi_store_elem(d, m, n, v.x);
       epi_store_elem(d, m, n + 1, v.y);
       epi_store_elem(d, m, n + 2, v.z);
       epi_store_elem(d, m, n + 3, v.w);
     }
+  }
+  if (d.rs_out) {
+    // per-row {sum, sum of squares} of the stored values over this wave tile's columns -> slot wn0 / WTN of the row (a LayerNorm folded
+    // into the consumer GEMM sums the slots in order: deterministic, no atomics).  One lane per row, 16-byte LDS reads.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int ncol = min(WTN, d.n_store - wn0);
+    for (int r = lane; r < WTM && wm0 + r < d.M; r += 64) {
+      float s1 = 0.f, q1 = 0.f;
+      for (int c = 0; c + 3 < ncol; c += 4) {
+        const float4 v = *(const float4*)(sC + r * LDW + c);
+        s1 += (v.x + v.y) + (v.z + v.w);
+        q1 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      *((float2*)d.rs_out + (size_t)(wm0 + r) * d.rs_ld + wn0 / WTN) = make_float2(s1, q1);
+    }
+    if (m0 == 0 && n0 == 0 && wave == 0 && lane == 0) d.rs_count[0] = (d.n_store + WTN - 1) / WTN;
   }
   if (d.gn_stats) {
     // GroupNorm statistics of the tensor just produced, for the GroupNorm that consumes it (mvd_groupnorm_from_stats): one lane
@@ -377,17 +438,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   constexpr bool PIPE = STAGES == 3 || RING;           // 3 = register-pipelined loop (two LDS buffers)
   constexpr bool STAG = STAGES == 4 || STAGES == 5;    // 4 / 5 = staggered wave groups with three / four LDS buffers
   constexpr int TAB_BYTES = AMODE != MVD_A_DENSE ? BM * 9 * 4 : 0;
-  constexpr int RING_FIT = (160 * 1024 - TAB_BYTES) / STAGE;   // a workgroup may own the whole 160 KiB of its CU
+  constexpr int LNR_BYTES = AMODE == MVD_A_DENSE ? BM * 8 : 0;      // {mean, rstd} of the tile's rows (LayerNorm fold: dense problems)
+  constexpr int RING_FIT = (160 * 1024 - TAB_BYTES - LNR_BYTES) / STAGE;   // a workgroup may own the whole 160 KiB of its CU
   constexpr int RING_WANT = STAGES == 6 ? 4 : 8;
   constexpr int NBUF = STAG ? STAGES - 1 : (RING ? (RING_WANT < RING_FIT ? RING_WANT : RING_FIT) : 2);
   constexpr int LEAD = NBUF - 1;                       // staggered loop: k-tiles staged ahead of the one being read
   constexpr int SMEM = NBUF * STAGE > EPI_BYTES ? NBUF * STAGE : EPI_BYTES;
-  static_assert(NBUF >= 2 && SMEM + TAB_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(NBUF >= 2 && SMEM + TAB_BYTES + LNR_BYTES <= 160 * 1024, "LDS budget");
   static_assert(!STAG || NW == 8, "the staggered loop pairs the two wavefronts of each SIMD: 8-wave tiles only");
   static_assert(A_GRAN % NW == 0, "A granules must divide evenly over the waves");
   static_assert(WTM % 16 == 0 && WTN % 16 == 0 && B_GRAN % 2 == 0, "wave tiles are made of 16x16 MFMA tiles");
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + TAB_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + TAB_BYTES + LNR_BYTES];
 
   const mvd_gemm_desc& d = p.d;
   const int tid = threadIdx.x;
@@ -410,6 +472,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   const int kt0 = blockIdx.z * p.kt_per_split;
   const int kt1 = min(p.nk, kt0 + p.kt_per_split);
   const int nkt = kt1 - kt0;
+  // LayerNorm fold (mvd_gemm_desc.ln_stats): mean / rstd of the tile's rows from the producer's slots, one thread per row, called right
+  // after the prologue's DMAs are in flight (the loads' round trips hide behind the first k-tile's) and read by the epilogue -- the
+  // k-loop's barriers order the two.
+  float* s_rows = (float*)(smem + SMEM + TAB_BYTES);
+  auto ln_gather_rows = [&]() {
+    if (AMODE == MVD_A_DENSE && d.ln_stats != nullptr && tid < BM) {
+      const float2 st = m0 + tid < d.M ? ln_row_stats(d, m0 + tid) : make_float2(0.f, 0.f);
+      s_rows[tid * 2] = st.x;
+      s_rows[tid * 2 + 1] = st.y;
+    }
+  };
 
   // ---- per-lane staging roles.  Lane l of a granule fills slot l: row r = l>>3 (of 8), stored chunk l&7 holds source
   //      chunk cc = (l&7) ^ f(R), f(R) = (R>>1) & 7 with R the row inside its 16-row MFMA block.
@@ -617,6 +690,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         advance_tap();
       }
     }
+    ln_gather_rows();
     if (nkt >= LEAD) wait_vm_and_barrier<(LEAD - 1) * LPS>();
     else wait_vm_and_barrier<0>();
     for (int ph = 0; ph <= 2 * nkt; ++ph) {
@@ -656,6 +730,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         advance_tap();
       }
     }
+    ln_gather_rows();
     if (nkt >= NBUF) wait_vm_and_barrier<(NBUF - 1) * LPS>();   // k-tile 0 landed, the newer ones stay in flight
     else wait_vm_and_barrier<0>();
     read_frags(0, fah[0], fal[0], fbh[0], fbl[0]);
@@ -697,6 +772,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     // ---- plain two-buffer loop: DMA of k-tile t+1 in flight while tile t is read and multiplied
     stage(0);
     advance_tap();
+    ln_gather_rows();
     wait_vm_and_barrier<0>();
     int buf = 0;
     for (int it = 0; it < nkt; ++it) {
@@ -713,7 +789,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   }
 
   // ---- epilogue (the final barrier above guarantees nobody still reads the stage buffers; each wave owns a private region)
-  tile_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, lane, wave);
+  tile_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, lane, wave, AMODE == MVD_A_DENSE && d.ln_stats != nullptr ? s_rows : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 convolution, input patch in LDS
@@ -995,6 +1071,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
+// Split-K reduce for a GEMM whose output feeds a LayerNorm folded into its consumer (mvd_gemm_desc.rs_out): one wavefront per row and
+// 256-column span; same sums and epilogue as splitk_reduce_kernel, then the row's {sum, sum of squares} over the span go to slot
+// blockIdx.y of the row (wave reduction in a fixed order).  MVD_EPI_STORE, n_store == N.
+__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(GemmParams p) {
+  const mvd_gemm_desc& d = p.d;
+  const size_t MN = (size_t)d.M * d.N;
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.y * 256 + lane * 4;
+  if (m >= d.M) return;
+  float s1 = 0.f, q1 = 0.f;
+  if (n < d.N) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* w = d.workspace + (size_t)m * d.N + n;
+    for (int z = 0; z < p.splits; ++z) {
+      const float4 t = *(const float4*)(w + z * MN);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float4 f = epi_store4(d, m, n, v);
+    s1 = (f.x + f.y) + (f.z + f.w);
+    q1 = (f.x * f.x + f.y * f.y) + (f.z * f.z + f.w * f.w);
+  }
+  s1 = wave_sum(s1);
+  q1 = wave_sum(q1);
+  if (lane == 0) *((float2*)d.rs_out + (size_t)m * d.rs_ld + blockIdx.y) = make_float2(s1, q1);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) d.rs_count[0] = gridDim.y;
+}
+
 // Split-K reduce for a GEMM whose output feeds a GroupNorm: one workgroup per (16-row slab, 256-column span); thread = (4 rows,
 // one float4 column), same sums and epilogue as splitk_reduce_kernel.  The per-column {sum, sum of squares} of the slab are
 // combined over the rows, then per group in column order (a group cut by the span boundary contributes from both workgroups),
@@ -1055,6 +1159,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmParams p) 
 
 // Tile configurations (mvd_gemm_desc.cfg = 1 + 16 * tile + 2 * loop + order; 0 = built-in heuristic).
 //   tile : 0 = 64x64 (2x2 waves)  1 = 128x128 (2x4)  2 = 128x80 (4x1)  3 = 64x80 (4x1)  4 = 128x160 (4x2)
+//          (a 256x128 tile -- 128x32 wave tiles, 64 MFMAs per k-tile and wave against 20 fragment reads and 6 DMAs -- was built and
+//          measured in round 3: equal or slower on every shape of the step, profiles/r03_gemm_tile256_probe.log; dropped)
 //   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop, 2 = staggered wave groups, 3 LDS buffers (8-wave tiles 1 and
 //          4 only), 3 = staggered, 4 LDS buffers (tile 1 only: 128 KiB), 4 = register-pipelined loop over a ring of <= 4 LDS buffers,
 //          5 = over a ring of <= 8 (4-wave tiles 0, 2, 3 only: the 8-wave tiles fit 4), 6 = conv_patch_kernel (stride-1 3x3 convolutions, tiles 1, 2, 4)
@@ -1198,6 +1304,15 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   } else {
     MVD_CHECK_ARG(false, "mvd_gemm: bad epilogue %d", d.epi);
   }
+  if (d.rs_out)
+    MVD_CHECK_ARG(d.epi == MVD_EPI_STORE && d.n_store == d.N && !d.gn_stats && d.rs_count && d.rs_ld >= cdiv(d.N, 32) && ((uintptr_t)d.rs_out & 7) == 0,
+                  "mvd_gemm: rs_out needs MVD_EPI_STORE, n_store == N, no gn_stats, rs_count and rs_ld >= N / 32 (N=%d rs_ld=%d)", d.N, d.rs_ld);
+  if (d.ln_stats) {
+    MVD_CHECK_ARG((d.epi == MVD_EPI_QKV || d.epi == MVD_EPI_GEGLU) && d.ln_count && d.ln_colsum && d.ln_dim > 0 && d.ln_ld > 0 &&
+                      ((uintptr_t)d.ln_stats & 7) == 0 && ((uintptr_t)d.ln_colsum & 15) == 0,
+                  "mvd_gemm: ln_stats (LayerNorm fold) serves the QKV / GEGLU epilogues and needs ln_count, ln_colsum, ln_dim, ln_ld");
+    d.splitk = 1;      // the fold lives in the tile epilogue (the row statistics are per tile row)
+  }
   if (d.gn_stats)
     MVD_CHECK_ARG(d.epi == MVD_EPI_STORE && d.n_store == d.N && d.M % 16 == 0 && d.gn_hw > 0 && d.gn_hw % 16 == 0 && d.gn_groups > 0 &&
                       d.N % d.gn_groups == 0,
@@ -1279,7 +1394,9 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   }
   MVD_CHECK_LAUNCH("mvd_gemm");
   if (p.splits > 1) {
-    if (d.gn_stats) {
+    if (d.rs_out) {
+      hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(cdiv(d.M, 4), cdiv(d.N, 256)), dim3(256), 0, s, p);
+    } else if (d.gn_stats) {
       const int spans = (d.N + 255) / 256;
       if ((d.M / 16) * spans >= 1024)
         hipLaunchKernelGGL(splitk_reduce_stats_kernel<4>, dim3(d.M / 16, spans), dim3(256), 0, s, p);

@@ -59,6 +59,7 @@ class Workspace:
 class Ctx:
     """Per-model execution context handed down the module tree."""
     gn_from_producer = True         # False: every GroupNorm runs its own statistics kernel (A/B measurement, bench.py --gn-two-pass)
+    ln_fold = True                  # False: LayerNorm kernels instead of the fold into the QKV / GEGLU GEMMs (A/B: bench.py --ln-kernels)
 
     def __init__(self, device, prec=hip.PREC_X4):
         self.device = torch.device(device)
@@ -77,6 +78,7 @@ class Ctx:
         self.gn_arena = torch.zeros(GN_SLOTS * GN_SLOT_ELEMS, dtype=torch.int64, device=self.device)
         self._gn_next = 0
         self._gn = {}               # data_ptr of a produced tensor -> (stats slot, B, HW, C)
+        self._rs = {}               # (tag, rows, width) -> hip.RowStats (static: part of the captured graph)
 
     def begin_step(self):
         """Reset the rotation of the layer-output buffers: the eager warm-up step and the captured step then walk the
@@ -95,6 +97,16 @@ class Ctx:
         self._gn_next += 1
         self._gn[out.data_ptr()] = (st, B, HW, C)
         return st
+
+    def row_stats(self, tag, rows, width):
+        """Static per-row statistics slots for a (rows, width) tensor whose LayerNorm is folded into the consumer GEMM."""
+        key = (tag, int(rows), int(width))
+        rs = self._rs.get(key)
+        if rs is None:
+            assert not self.ws.frozen, f"row statistics {key} requested during graph capture"
+            rs = hip.RowStats(rows, width, self.device)
+            self._rs[key] = rs
+        return rs
 
     def act(self, shape):
         """Rotating layer-output buffers (3 per shape): a layer's input stays valid while it writes its output."""

@@ -40,6 +40,8 @@ class GemmDesc(C.Structure):
         ("heads", _i), ("dhead", _i), ("L", _i), ("Lpad", _i), ("qscale", _f),
         ("splitk", _i), ("workspace", _vp), ("workspace_elems", _sz), ("cfg", _i),
         ("gn_stats", _vp), ("gn_hw", _i), ("gn_groups", _i),
+        ("rs_out", _vp), ("rs_count", _vp), ("rs_ld", _i),
+        ("ln_stats", _vp), ("ln_count", _vp), ("ln_colsum", _vp), ("ln_ld", _i), ("ln_dim", _i), ("ln_eps", _f),
     ]
 
 
@@ -163,6 +165,35 @@ class PackedWeight:
         self.acc_scale = acc_scale
 
 
+class RowStats:
+    """Per-row {sum, sum of squares} slots a GEMM emits for the LayerNorm folded into its consumer (mvd_gemm_desc.rs_out)."""
+
+    __slots__ = ("slots", "count", "ld")
+
+    def __init__(self, rows, n_max, device):
+        self.ld = (n_max + 31) // 32
+        self.slots = torch.zeros(rows, self.ld, 2, dtype=torch.float32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+class LnFold:
+    """A Linear behind a LayerNorm as ONE packed weight: W' = W diag(gamma) (PackedWeight .w, bias = W beta + b), the column sums of
+    W' and the LayerNorm's width / eps (mvd_gemm_desc.ln_*; exact algebra, the composition is formed in fp64)."""
+
+    __slots__ = ("w", "colsum", "dim", "eps")
+
+    def __init__(self, weight, bias, norm, geglu=False):
+        Wd = weight.detach().double()
+        g, b = norm.weight.detach().double(), norm.bias.detach().double()
+        Wf = Wd * g[None, :]
+        bf = Wd @ b + (bias.detach().double() if bias is not None else 0.0)
+        self.w = pack_linear(Wf.float().contiguous(), bf.float().contiguous(), geglu=geglu)
+        Np = self.w.N if not geglu else Wd.shape[0]
+        cs = torch.zeros(max(Np, Wd.shape[0]), dtype=torch.float32, device=weight.device)
+        cs[:Wd.shape[0]] = Wf.sum(dim=1).float()
+        self.colsum, self.dim, self.eps = cs, int(Wd.shape[1]), float(norm.eps)
+
+
 class PlanesOperand:
     """An activation matrix (N rows, K columns, split planes with `ld` elements per row) in the B-operand role of mvd_gemm:
     out = A @ B^T between two activations (MVD_B_PLANES).  Duck-types PackedWeight for hip.gemm."""
@@ -228,7 +259,7 @@ def pack_conv3x3(weight, bias=None):
 # ---------------------------------------------------------------------------------------------
 # packed-weight cache invalidation
 # ---------------------------------------------------------------------------------------------
-_CACHE_ATTRS = ("_p", "_pg", "_temb", "_xattn", "_head", "_pq", "_q", "_fused")
+_CACHE_ATTRS = ("_p", "_pg", "_temb", "_xattn", "_head", "_pq", "_q", "_fused", "_lnf")
 
 
 def params_signature(module):
@@ -289,7 +320,7 @@ def split_planes(x, out=None, ldp=None):
 
 def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
          bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
-         out_planes=None, out_planes_col=0, cfg=None, gn_stats=None, gn_hw=0, gn_groups=32):
+         out_planes=None, out_planes_col=0, cfg=None, gn_stats=None, gn_hw=0, gn_groups=32, row_stats=None, ln=None):
     """out = epilogue(A @ W^T).  A: split planes (M, 2*K) int16 (dense) or the NHWC image rows (B*H*W, 2*C) with
     conv=dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
     out: fp32 tensor or None; out_planes: split-planes tensor or None (feeds the next GEMM); out_planes_col: first column
@@ -297,6 +328,8 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     [out_planes_col, out_planes_col + N) of every row and leaves the others alone (operand concatenation along K).
     gn_stats: zeroed int64 (M / gn_hw, gn_groups, 2) tensor that receives the GroupNorm statistics of the output (consumed by
     groupnorm_from_stats instead of a statistics kernel).
+    row_stats = RowStats: the GEMM also emits per-row {sum, sum of squares} slots of its output (for a LayerNorm folded into the
+    consumer); ln = (RowStats of the producer of A, LnFold of this weight): LayerNorm(A rows) folded into this QKV / GEGLU GEMM.
     """
     assert A.dtype == torch.int16, "A must be in split-planes format (see hip.split_planes)"
     d = GemmDesc()
@@ -347,12 +380,20 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.qscale = float(qkv["dhead"]) ** -0.5 * 1.4426950408889634      # * log2(e): mvd_attention works in base 2
     if gn_stats is not None:
         d.gn_stats, d.gn_hw, d.gn_groups = gn_stats.data_ptr(), int(gn_hw), int(gn_groups)
+    if row_stats is not None:
+        assert row_stats.slots.shape[0] >= d.M and row_stats.ld >= (d.N + 31) // 32
+        d.rs_out, d.rs_count, d.rs_ld = row_stats.slots.data_ptr(), row_stats.count.data_ptr(), row_stats.ld
+    if ln is not None:
+        rs, fold = ln
+        d.ln_stats, d.ln_count, d.ln_ld = rs.slots.data_ptr(), rs.count.data_ptr(), rs.ld
+        d.ln_colsum, d.ln_dim, d.ln_eps = fold.colsum.data_ptr(), fold.dim, fold.eps
+        splitk = 1
     d.splitk = splitk
     if workspace is not None:
         d.workspace = workspace.data_ptr()
         d.workspace_elems = workspace.numel()
     key = (d.M, d.N, d.K, d.a_mode, d.Cin, d.stride, d.upsample, d.no_pad_tl, d.epi, d.prec, res is not None, out is not None,
-           out_planes is not None, splitk, d.b_mode)
+           out_planes is not None, splitk, d.b_mode, row_stats is not None, ln is not None)
     if cfg is None:
         tuned = _TUNED.get(key)
         if tuned is None and AUTOTUNE:

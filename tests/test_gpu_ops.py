@@ -394,6 +394,63 @@ def test_qkv_gemm_and_attention(hip, prec, B, H, L, d):
     assert rel_err(planes_to_float(out), ref) < 2 * TOL[prec] + PL
 
 
+@pytest.mark.parametrize("pcfg,psplit", [(0, 1), (_hip.make_cfg(2, 1), 1), (_hip.make_cfg(1, 0), 1), (_hip.make_cfg(3, 4), 1), (0, 3)])
+@pytest.mark.parametrize("B,L,H,d,offs", [(2, 256, 8, 40, 0.0), (1, 64, 8, 160, 3.0), (3, 32, 4, 24, -1.5)])
+def test_gemm_layernorm_fold(hip, pcfg, psplit, B, L, H, d, offs):
+    """LayerNorm folded into the consumer GEMM (mvd_gemm_desc.rs_out / ln_stats): the producer GEMM (tile epilogues with 32- and
+    80-column wave tiles, and the split-K reduce) emits per-row {sum, sum of squares} slots and the row's split planes; the QKV and
+    GEGLU consumers run on the RAW rows with W' = W diag(gamma) and finish  rstd (acc - mean colsum) + W beta  in their epilogues.
+    Rows with a large mean (offs) exercise the cancellation in  x.W' - mean sum(W')."""
+    import torch.nn as nn
+    M, C = B * L, H * d
+    x = torch.randn(M, C, generator=g(80))
+    Win = torch.randn(C, C, generator=g(81)) / math.sqrt(C)
+    bin_ = torch.randn(C, generator=g(82)) + offs
+    res = torch.randn(M, C, generator=g(83))
+    t = F.linear(x, Win, bin_) + res
+    norm = nn.LayerNorm(C)
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.3 * torch.randn(C, generator=g(84)))
+        norm.bias.copy_(0.2 * torch.randn(C, generator=g(85)))
+    ln = F.layer_norm(t, (C,), norm.weight, norm.bias, norm.eps)
+    ws = torch.empty(16 * 1024 * 1024, device="cuda")
+    normc = norm.cuda()
+    # producer: t (fp32), its planes and the row statistics
+    tp = hip.planes_like(M, C, "cuda")
+    tt = torch.empty(M, C, device="cuda")
+    rs = hip.RowStats(M, C, "cuda")
+    hip.gemm(hip.split_planes(x.cuda()), hip.pack_linear(Win.cuda(), bin_.cuda()), tt, res=res.cuda(), out_planes=tp, row_stats=rs,
+             workspace=ws, cfg=pcfg or None, splitk=psplit)
+    assert rel_err(tt, t) < TOL[4]
+    cnt = int(rs.count.item())
+    got = rs.slots[:, :cnt].sum(1).cpu().double()
+    assert 1 <= cnt <= rs.ld
+    assert float((got[:, 0] - t.double().sum(1)).abs().max()) < 1e-3 and rel_err(got[:, 1], (t.double() ** 2).sum(1)) < 1e-5
+    # consumer 1: QKV -> attention
+    wq, wk, wv = (torch.randn(C, C, generator=g(86 + i)) / math.sqrt(C) * 1.5 for i in range(3))
+    q, k, v = (F.linear(ln, w).view(B, L, H, d).permute(0, 2, 1, 3) for w in (wq, wk, wv))
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).permute(0, 2, 1, 3).reshape(M, C)
+    fold = hip.LnFold(torch.cat([wq, wk, wv], 0).cuda(), None, normc)
+    planes = hip.alloc_attn_planes(B, H, L, d, "cuda")
+    hip.gemm(tp, fold.w, None, epi=hip.EPI_QKV, qkv=dict(planes=planes, heads=H, dhead=d, L=L), workspace=ws, ln=(rs, fold))
+    out = hip.planes_like(M, C, "cuda")
+    hip.attention(planes, out, B, H, L, d)
+    assert rel_err(planes_to_float(out), ref) < 4 * TOL[4] + PL
+    # consumer 2: GEGLU, reading the rows as a column block of a wider operand buffer and writing its first columns
+    Wg = torch.randn(8 * C, C, generator=g(90)) / math.sqrt(C)
+    bg = torch.randn(8 * C, generator=g(91))
+    a, gt = F.linear(ln, Wg, bg).chunk(2, dim=-1)
+    refg = a * F.gelu(gt)
+    foldg = hip.LnFold(Wg.cuda(), bg.cuda(), normc, geglu=True)
+    cat5 = hip.planes_like(M, 5 * C, "cuda")
+    cat5[:, 2 * 4 * C:] = tp
+    hip.gemm(cat5[:, 2 * 4 * C:], foldg.w, None, M=M, lda=5 * C, epi=hip.EPI_GEGLU, out_planes=cat5, workspace=ws, ln=(rs, foldg))
+    gotg = planes_to_float(cat5)
+    assert rel_err(gotg[:, :4 * C], refg) < 4 * TOL[4] + PL
+    assert torch.equal(cat5[:, 2 * 4 * C:].cpu(), tp.cpu())
+
+
 def test_attention_forced_rescale(hip):
     """A key whose score dominates late in the sequence forces the online-softmax rescale path."""
     B, H, L, d = 1, 8, 256, 40
