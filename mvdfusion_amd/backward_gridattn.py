@@ -93,7 +93,8 @@ def gridattn_backward(ga, tape, eng, c, dvol, V, S, D):
     half = 1.0 / float(S)
     grid_lin = torch.linspace(1.0 - half, -1.0 + half, S, dtype=torch.float32).to(dev)
     tokens = hip.planes_like(T, hip.TOKEN_LD, dev)
-    geo = (hip.ptr(eng.x), hip.ptr(eng.depth_noise), hip.ptr(eng.steps), hip.ptr(eng.iter), hip.ptr(grid_lin))
+    dsrc, dsteps = eng.depth_geo()          # (the depth source the forward used: x itself, or an overwrite_attn_depth map)
+    geo = (hip.ptr(dsrc), hip.ptr(eng.depth_noise), hip.ptr(dsteps), hip.ptr(eng.iter), hip.ptr(grid_lin))
     hip.check(L.mvd_gridattn_tokens(*geo, hip.ptr(feat), hip.ptr(in_feat), hip.ptr(eng.cams), hip.ptr(eng.in_cam), hip.ptr(tokens), V, 0, V,
                                     S, D, float(ga.depth_scale), float(ga.depth_shift), hip.stream()))
     pre = ga.pre_layer_b[0]

@@ -96,13 +96,18 @@ class FrozenCLIPImageEmbedder(nn.Module):
         self.model = _CLIP(*_CONFIGS[arch])
         if model not in _CONFIGS:
             import os
-            if os.path.exists(model):
-                try:
-                    sd = torch.jit.load(model, map_location="cpu").state_dict()       # OpenAI ships TorchScript archives
-                except Exception:
-                    sd = torch.load(model, map_location="cpu")
-                    sd = sd.get("state_dict", sd)
-                self.model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
+            if not os.path.exists(model):      # clip.load() raises on an unknown name / missing file: never run on random weights silently
+                raise FileNotFoundError(f"FrozenCLIPImageEmbedder: '{model}' is neither a known CLIP architecture {sorted(_CONFIGS)} nor "
+                                        "an existing checkpoint file")
+            try:
+                sd = torch.jit.load(model, map_location="cpu").state_dict()       # OpenAI ships TorchScript archives
+            except Exception:
+                sd = torch.load(model, map_location="cpu")
+                sd = sd.get("state_dict", sd)
+            missing, _ = self.model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
+            lost = [k for k in missing if k.startswith("visual.")]
+            if lost:
+                raise KeyError(f"FrozenCLIPImageEmbedder: checkpoint '{model}' lacks {len(lost)} vision-tower tensors (first: {lost[:3]})")
         self.antialias = antialias
         self.register_buffer("mean", torch.Tensor([0.48145466, 0.4578275, 0.40821073]), persistent=False)
         self.register_buffer("std", torch.Tensor([0.26862954, 0.26130258, 0.27577711]), persistent=False)

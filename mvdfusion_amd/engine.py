@@ -92,7 +92,8 @@ class Ctx:
     def gn_slot(self, out, B, HW, C):
         """Reserve the statistics slot of `out` (a (B*HW, C) tensor about to be produced) and remember it for ctx.groupnorm."""
         n = B * 32 * 2
-        assert n <= GN_SLOT_ELEMS and self._gn_next < GN_SLOTS, (B, self._gn_next)
+        if n > GN_SLOT_ELEMS or self._gn_next >= GN_SLOTS:
+            return None                 # more images / normalised tensors than the arena holds: the consumer runs the two-pass kernels
         st = self.gn_arena[self._gn_next * GN_SLOT_ELEMS:self._gn_next * GN_SLOT_ELEMS + n]
         self._gn_next += 1
         self._gn[out.data_ptr()] = (st, B, HW, C)
@@ -123,7 +124,9 @@ class Ctx:
         if out is not None:
             self._gn.pop(out.data_ptr(), None)          # whatever statistics the buffer had are stale now
             if gn is not None and self.gn_from_producer and gn[1] % 16 == 0 and out.shape[-1] % 32 == 0:
-                kw.update(gn_stats=self.gn_slot(out, gn[0], gn[1], out.shape[-1]), gn_hw=gn[1], gn_groups=32)
+                st = self.gn_slot(out, gn[0], gn[1], out.shape[-1])
+                if st is not None:
+                    kw.update(gn_stats=st, gn_hw=gn[1], gn_groups=32)
         return hip.gemm(A, W, out, **kw)
 
     def groupnorm(self, x, y, norm, B, HW, C, silu):

@@ -25,7 +25,7 @@ def make_ddim_timesteps(num_ddim_timesteps, num_ddpm_timesteps):
 class DDIMSampler:
     def __init__(self, model, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, latent_size=32,
                  overwrite_x_noisy=False, z_dim=4, feed_prev_depth=False):
-        assert ddim_discretize == "uniform" and not overwrite_x_noisy and not feed_prev_depth
+        assert ddim_discretize == "uniform" and not overwrite_x_noisy
         self.model = model
         self.ddpm_num_timesteps = model.scheduler.num_timesteps
         self.latent_size, self.eta, self.z_dim = latent_size, ddim_eta, z_dim
@@ -71,7 +71,7 @@ class DDIMSampler:
     def denoise_apply(self, x_target_noisy, batch_cameras, input_latents, input_cameras, clip_embed, time_steps, index,
                       is_step0=False, prev_depth=None, cfg_scale=1.0):
         eps = self.model.apply_model(x_target_noisy, batch_cameras, input_latents, input_cameras, clip_embed, time_steps,
-                                     cfg_scale=cfg_scale)
+                                     prev_depth=prev_depth if self.feed_prev_depth else None, cfg_scale=cfg_scale)      # (:83-86)
         return self.denoise_apply_impl(x_target_noisy, index, eps, is_step0)
 
     @torch.no_grad()
@@ -101,9 +101,13 @@ class DDIMSampler:
         eng.x.copy_(x_T)
         inter = []
         for i in range(n_run):
+            # feed_prev_depth (:135-140): from the second iteration on GridAttn samples depth around the previous step's x0 estimate, which
+            # the step engine keeps in eng.x0 (a second captured graph; the first iteration has no estimate yet)
+            eng.depth_mode = 1 if (self.feed_prev_depth and i > 0) else 0
             eng.step(unconditional_scale, do_update=True, use_graph=use_graph)
             if return_intermediates:
                 inter.append({"t": int(self.ddim_timesteps[total - i - 1]), "xt": eng.x.clone(), "x0": eng.x0.clone()})
+        eng.depth_mode = 0
         from . import hip
         out = hip.check_finite(eng.x.clone(), "DDIMSampler.sample")
         return (out, inter) if return_intermediates else out

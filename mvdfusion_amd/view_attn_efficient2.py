@@ -213,13 +213,16 @@ class GridAttn(nn.Module):
                 all(b.num_heads == 8 and b.mlp.fc1.out_features == 512 for b in blocks))
 
     def run(self, ctx, x, depth_noise, steps, it, cams_rec, in_cam_rec, input_latents, c, vol_out, V, S, D, q0=0, Vq=None,
-            vol_planes=None, vol_planes_col=0, fused=None):
+            vol_planes=None, vol_planes_col=0, fused=None, depth_src=None, depth_steps=None):
         """x (V,5,S,S) noisy latents; c (1,256) time conditioning (t_embed[:1]); vol_out: (>=V*S*S*D, 768) buffer
         whose first Vq*S*S*D rows receive the feature frustum (row = ((v*S + y)*S + x)*D + d) of the query views
         [q0, q0+Vq) (all V views by default; a view-parallel rank passes the range it owns).  vol_planes: optional planes
         buffer receiving the frustum as well, in columns [vol_planes_col, vol_planes_col + 768) of its rows.
         fused: None = the single-launch aggregation kernel (mvd_gridattn_fused) whenever V divides 16, else the unfused chain
-        of token kernel + GEMMs; True / False force one of them."""
+        of token kernel + GEMMs; True / False force one of them.
+        depth_src / depth_steps (overwrite_attn_depth, view_attn_efficient2.py:418-426): a (V,5,S,S) buffer whose channel 4 is the depth
+        map to sample around INSTEAD of the x0-style estimate x[:,4] / sqrt(alpha_bar), with a step table whose sqrt(alpha_bar) column
+        is 1 (x / 1 is exact) and whose depth-std column is unchanged -- the kernels themselves are the same."""
         Vq = V if Vq is None else Vq
         L = hip.lib()
         assert x.shape[1] == 5, "depth wise efficient attention requires 4+1 channels"
@@ -232,6 +235,9 @@ class GridAttn(nn.Module):
                                hip.stream()))
         nseq = Vq * S * S * D
         T = nseq * V
+        dsrc = x if depth_src is None else depth_src
+        dsteps = steps if depth_steps is None else depth_steps
+        assert (depth_src is None) == (depth_steps is None) and dsrc.shape == x.shape
         grid_lin = ctx.ws.bufs.get(("ga.lin", S))
         if grid_lin is None:
             half = 1.0 / float(S)
@@ -246,14 +252,14 @@ class GridAttn(nn.Module):
                 lin = blk.adaLN_modulation[1]
                 hip.gemv(lin.weight, lin.bias, c, vecs[bi * _G4_VEC_BLOCK:bi * _G4_VEC_BLOCK + 1536].view(1, 1536), act_in=hip.ACT_SILU)
             pool = ctx.ws.planes("ga.pool", nseq, self.hidden_size)
-            hip.check(L.mvd_gridattn_fused(hip.ptr(x), hip.ptr(depth_noise), hip.ptr(steps), hip.ptr(it), hip.ptr(grid_lin),
+            hip.check(L.mvd_gridattn_fused(hip.ptr(dsrc), hip.ptr(depth_noise), hip.ptr(dsteps), hip.ptr(it), hip.ptr(grid_lin),
                                            hip.ptr(feat), hip.ptr(in_feat), hip.ptr(cams_rec), hip.ptr(in_cam_rec), hip.ptr(stream),
                                            hip.ptr(vecs), hip.ptr(pool), V, q0, Vq, S, D, float(self.depth_scale),
                                            float(self.depth_shift), hip.stream()))
             ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes, out_planes_col=vol_planes_col)
             return vol_out
         tokens = ctx.ws.planes("ga.tokens", T, hip.TOKEN_LD)
-        hip.check(L.mvd_gridattn_tokens(hip.ptr(x), hip.ptr(depth_noise), hip.ptr(steps), hip.ptr(it), hip.ptr(grid_lin),
+        hip.check(L.mvd_gridattn_tokens(hip.ptr(dsrc), hip.ptr(depth_noise), hip.ptr(dsteps), hip.ptr(it), hip.ptr(grid_lin),
                                         hip.ptr(feat), hip.ptr(in_feat), hip.ptr(cams_rec), hip.ptr(in_cam_rec),
                                         hip.ptr(tokens), V, q0, Vq, S, D, float(self.depth_scale), float(self.depth_shift),
                                         hip.stream()))

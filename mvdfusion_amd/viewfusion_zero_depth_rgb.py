@@ -57,6 +57,11 @@ class StepEngine:
         self.x_in = torch.zeros(B * S * S, 2 * 32, dtype=torch.int16, device=dev)              # UNet input (split planes)
         self.iter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.steps = z(1, hip.STEP_STRIDE)
+        self.steps_nodiv = z(1, hip.STEP_STRIDE)   # the same table with sqrt(alpha_bar) = 1: GridAttn's depth source is used as is
+        self.prev = z(V, 5, S, S)              # channel 4: an explicit overwrite_attn_depth (apply_model(prev_depth=...))
+        self.depth_mode = 0                    # GridAttn samples depth around 0: x[:,4] / sqrt(alpha_bar) (the x0-style estimate);
+                                               # 1: the previous step's x0 estimate self.x0[:,4] (DDIMSampler feed_prev_depth);
+                                               # 2: self.prev[:,4] (view_attn_efficient2.py:418-426)
         self.depth_noise = z(1, V, D, S, S)
         self.ddim_noise = z(1, V, 5, S, S)
         self.f256 = _sinusoid_freqs(256).to(dev)
@@ -78,12 +83,15 @@ class StepEngine:
         if self.steps.shape != steps_table.shape:
             self.graphs.clear()                # table buffers are re-allocated: captured pointers go stale
             self.steps = steps_table.to(dev).contiguous()
+            self.steps_nodiv = self.steps.clone()
             self.depth_noise = depth_noise.to(dev).contiguous()
             self.ddim_noise = ddim_noise.to(dev).contiguous()
         else:
             self.steps.copy_(steps_table)
             self.depth_noise.copy_(depth_noise)
             self.ddim_noise.copy_(ddim_noise)
+        self.steps_nodiv.copy_(self.steps)
+        self.steps_nodiv[:, 1] = 1.0
         self.n_rows = int(steps_table.shape[0])
         self.rewind()
 
@@ -92,6 +100,12 @@ class StepEngine:
         assert 0 <= it < self.n_rows
         self.iter.fill_(it)
         self.done = it
+
+    def depth_geo(self):
+        """(depth source (V,5,S,S), step table) GridAttn's kernels read the depth channel and its std from (see depth_mode)."""
+        if self.depth_mode == 0:
+            return self.x, self.steps
+        return (self.x0 if self.depth_mode == 1 else self.prev), self.steps_nodiv
 
     # -- one iteration -------------------------------------------------------------------------------
     def enqueue(self, cfg_scale, do_update):
@@ -108,9 +122,11 @@ class StepEngine:
         c = ctx.ws.get("vf.c", (1, 256))
         hip.gemv(m.time_embed[2].weight, m.time_embed[2].bias, te1, c)
         # view-aligned features (:303-313)
+        dsrc, dsteps = self.depth_geo()
         m.view_attn.run(ctx, self.x, self.depth_noise, self.steps, self.iter, self.cams, self.in_cam,
                         self.input_latents, c, self.vol, V, S, D, q0=q0, Vq=Vq, vol_planes=self.vol_planes,
-                        vol_planes_col=self.vol_col)
+                        vol_planes_col=self.vol_col, depth_src=None if self.depth_mode == 0 else dsrc,
+                        depth_steps=None if self.depth_mode == 0 else dsteps)
         # cc_projection (:322)
         p = m.cc_projection
         c1 = ctx.ws.get("vf.cc1", (Vq, 768))
@@ -147,7 +163,7 @@ class StepEngine:
             hip.check(L.mvd_advance_iter(hip.ptr(self.iter), st()))
 
     def step(self, cfg_scale, do_update, use_graph=True):
-        key = (float(cfg_scale), bool(do_update))
+        key = (float(cfg_scale), bool(do_update), int(self.depth_mode))
         if self.done >= self.n_rows:
             raise IndexError(f"StepEngine.step: iteration {self.done} is past the {self.n_rows}-row step table "
                              "(set_schedule() / rewind() before stepping again)")
@@ -202,15 +218,18 @@ class ViewFusion(nn.Module):
                  clip_path="", unet_cc_path="", z_scale_factor=0.18215, vae_max_batch=8, objective="noise",
                  loss_type="l2", embed_camera_pose=True, finetune_projection=False, finetune_unet=False,
                  finetune_cross_attn=True, finetune_view_attn=True, feed_prev_depth=False, drop_conditions=False,
-                 vae=None, clip_image_encoder=None, precision="f16x4", **kwargs):
+                 vae=None, clip_image_encoder=None, precision="f16x4", reference_eval_dropout=False, **kwargs):
         super().__init__()
         assert embed_camera_pose, "this build implements the embed_camera_pose=True configuration of configs/*.yaml"
-        assert not feed_prev_depth, "feed_prev_depth=False in every shipped config (viewfusion_zero_depth_rgb.py:39)"
         self.finetune_projection, self.finetune_unet, self.z_scale_factor = finetune_projection, finetune_unet, z_scale_factor
         self.vae_max_batch, self.objective, self.loss_type = vae_max_batch, objective, loss_type
         self.embed_camera_pose, self.finetune_cross_attn, self.finetune_view_attn = \
             embed_camera_pose, finetune_cross_attn, finetune_view_attn
         self.feed_prev_depth, self.drop_conditions = feed_prev_depth, drop_conditions
+        # The reference applies the condition dropout whenever cfg_scale == 1 (is_train=True is hard-wired at :322-330 / unet.py:140),
+        # i.e. also under model.eval() (validation losses, cfg = 1 sampling).  Default here: only in training mode; True reproduces the
+        # reference's eval-mode behaviour bit for bit in distribution (validation curves comparable 1:1).
+        self.reference_eval_dropout = bool(reference_eval_dropout)
         # precision = MFMA operand type x number of partial products of the (hi+lo)(hi+lo) operand split:
         # "f16x4" (default: fp16, all 4 products -- fp32-class; +4 % time over x3 because the GEMMs are operand-delivery
         # bound), "f16x3" (drops lo*lo, ~2^-22), "bf16x3" (~2^-16), "f16" / "bf16" (one product, hi only).  The operand type selects the library
@@ -378,7 +397,6 @@ class ViewFusion(nn.Module):
         With cfg_scale == 1 the reference calls UNetWrapper.forward(is_train=True): when the model was built with
         drop_conditions=True and is in training mode, the per-view condition dropout of unet.py:109-151 is applied
         (``drop_rand`` (V,) optionally injects its torch.rand draw)."""
-        assert prev_depth is None, "feed_prev_depth is not part of the shipped configurations"
         V, _, S, _ = noisy_latents.shape
         D = self.view_attn.n_pts_per_ray
         cfg = cfg_scale != 1.0
@@ -392,8 +410,12 @@ class ViewFusion(nn.Module):
             depth_noise = torch.randn(V, D, S, S, device=noisy_latents.device)
         eng.set_schedule(table, depth_noise.reshape(1, V, D, S, S), torch.zeros(1, V, 5, S, S))
         eng.x.copy_(noisy_latents)
+        eng.depth_mode = 0
+        if prev_depth is not None:             # overwrite_attn_depth (:312; view_attn_efficient2.py:418-426): (V or 1, 1, S, S)
+            eng.prev[:, 4:5].copy_(prev_depth.to(eng.prev.device).expand(V, 1, S, S))
+            eng.depth_mode = 2
         eng.drop_masks = None
-        if not cfg and self.drop_conditions and self.training:
+        if not cfg and self.drop_conditions and (self.training or self.reference_eval_dropout):
             r = torch.rand(V, device=noisy_latents.device) if drop_rand is None else drop_rand.to(noisy_latents.device).float()
             drop_clip, drop_vol = (r > 0.15) & (r <= 0.2), (r > 0.1) & (r <= 0.15)          # get_drop_scheme 'default' (unet.py:109-117)
             drop_cat, drop_all = (r > 0.05) & (r <= 0.1), r <= 0.05
@@ -402,7 +424,7 @@ class ViewFusion(nn.Module):
         try:
             eng.step(cfg_scale, do_update=False, use_graph=eng.drop_masks is None and not getattr(self, "_force_eager", False))
         finally:
-            eng.drop_masks = None
+            eng.drop_masks = None      # (depth_mode stays: the training backward re-derives the geometry from the same depth source)
         return hip.check_finite(eng.eps.clone(), "ViewFusion.apply_model")
 
     def sample(self, batch, trainer_config, cfg_scale, return_input=False, depth=False, verbose=True):
@@ -440,8 +462,9 @@ class ViewFusion(nn.Module):
         sac = self.scheduler.sqrt_alphas_cumprod.to(dev)[t].view(V, 1, 1, 1)
         s1m = self.scheduler.sqrt_one_minus_alphas_cumprod.to(dev)[t].view(V, 1, 1, 1)
         noisy = sac * batch_latents + s1m * noise                                          # scheduler.q_sample (:55-64)
-        pred = self.apply_model(noisy, batch_cameras, input_latents, input_cameras, clip_v_embed, t, depth_noise=depth_noise,
-                                drop_rand=drop_rand)
+        prev_depth = input_latents[:, 4:].clone() if self.feed_prev_depth else None          # (:377-379)
+        pred = self.apply_model(noisy, batch_cameras, input_latents, input_cameras, clip_v_embed, t, prev_depth=prev_depth,
+                                depth_noise=depth_noise, drop_rand=drop_rand)
         if self.objective == "noise":
             target = noise
         elif self.objective == "x_start":

@@ -132,7 +132,7 @@ def gold_cameras():
     print("  cameras: rig / re-basing / project / unproject agree with the reference call sites")
 
 
-def _gridattn_case(V, D, S, seed, t_val, tokens=True, tol=2e-5):
+def _gridattn_case(V, D, S, seed, t_val, tokens=True, tol=2e-5, prev_depth=False):
     from mvdfusion.view_attn_efficient2 import GridAttn
     from mvdfusion.scheduler import DDPMScheduler
     ga = GridAttn(in_channels=5, input_size=S, output_dim=768, num_layers=3, z_near_far_scale=0.8, n_pts_per_ray=D)
@@ -145,23 +145,25 @@ def _gridattn_case(V, D, S, seed, t_val, tokens=True, tol=2e-5):
     t_embed = torch.randn(V, 256, generator=g) * 0.5
     t = torch.full((V,), t_val, dtype=torch.long)
     sched = DDPMScheduler(1000)
+    prev = (torch.randn(V, 1, S, S, generator=g) * 0.4) if prev_depth else None       # overwrite_attn_depth (:418-426)
     torch.manual_seed(4242 + seed)
     with torch.no_grad():
-        ref = ga(x, ref_cams(inp["batch_cameras"]), torch.ones(V), t_embed, t, sched,
+        ref = ga(x, ref_cams(inp["batch_cameras"]), torch.ones(V), t_embed, t, sched, overwrite_attn_depth=prev,
                  input_latents=inp["input_latents"], input_cameras=ref_cams(inp["input_cameras"]))
     torch.manual_seed(4242 + seed)
     depth_noise = torch.randn(V, D, S, S)
     tab = O.ddpm_tables()
     with torch.no_grad():
         mine = O.gridattn_forward(sd, "view_attn.", x, cam_dict(inp["batch_cameras"]), t_embed, t, tab, depth_noise,
-                                  inp["input_latents"], cam_dict(inp["input_cameras"]), n_pts_per_ray=D)
+                                  inp["input_latents"], cam_dict(inp["input_cameras"]), n_pts_per_ray=D, overwrite_attn_depth=prev)
         tokens = O.gridattn_forward(sd, "view_attn.", x, cam_dict(inp["batch_cameras"]), t_embed, t, tab, depth_noise,
                                     inp["input_latents"], cam_dict(inp["input_cameras"]), n_pts_per_ray=D,
                                     return_tokens=True) if tokens else torch.zeros(97, 1, 1)
     e = rel_err(mine, ref)
     print(f"  gridattn V={V} D={D} S={S} t={t_val}: oracle vs reference rel-max err {e:.2e}")
     assert e < tol, e
-    return dict(x=x, t_embed=t_embed, t=t, depth_noise=depth_noise, out=ref, seed=np.int64(seed),
+    extra = dict(prev_depth=prev) if prev_depth else {}
+    return dict(x=x, t_embed=t_embed, t=t, depth_noise=depth_noise, out=ref, seed=np.int64(seed), **extra,
                 tokens_sample=tokens[::97][:, :, :].contiguous(), tokens_stride=np.int64(97))
 
 
@@ -308,6 +310,85 @@ def gold_gridattn_v15():
     c.pop("tokens_sample")
     save("gridattn_v15_d1", out_strided=out[:, ::5, ::7, :, ::3], out_mean=out.mean(), out_std=out.std(),
          out_l2=out.norm(), **c)
+
+
+def gold_gridattn_prev_depth():
+    """overwrite_attn_depth (view_attn_efficient2.py:418-426): the depth channel comes from the caller instead of the x0-estimate."""
+    c = _gridattn_case(4, 1, 32, 6, 301, tokens=False, prev_depth=True)
+    out = c.pop("out")
+    c.pop("tokens_sample")
+    save("gridattn_v4_d1_prevdepth", out_strided=out[:, ::5, ::7, :, ::3], out_mean=out.mean(), out_std=out.std(), out_l2=out.norm(), **c)
+
+
+def gold_sample_feed_prev_depth(model_channels=32, V=2, S=32, steps=3):
+    """The reference's DDIMSampler.sample loop with feed_prev_depth=True (sampler.py:83-84,119-142): from the second iteration on
+    GridAttn samples depth around the PREVIOUS step's x0-estimate.  The loop is truncated to the first `steps` iterations by patching
+    the sampler's timestep list (the per-step arithmetic is untouched); torch's global generator supplies the reference's own draws,
+    replayed for the oracle in the same order."""
+    import torch.nn as nn
+    from mvdfusion.view_attn_efficient2 import GridAttn
+    from mvdfusion.scheduler import DDPMScheduler
+    from mvdfusion.sampler import DDIMSampler
+    from mvdfusion.unet import UNetWrapper
+    from mvdfusion.viewfusion_zero_depth_rgb import ViewFusion
+
+    class Facade(nn.Module):
+        embed_time = ViewFusion.embed_time
+        apply_model = ViewFusion.apply_model
+
+        def __init__(self):
+            super().__init__()
+            self.view_attn = GridAttn(in_channels=5, input_size=S, output_dim=768, num_layers=3, z_near_far_scale=0.8, n_pts_per_ray=1)
+            w = UNetWrapper.__new__(UNetWrapper)
+            nn.Module.__init__(w)
+            w.unet_model = _unet(model_channels, S)
+            w.drop_conditions, w.use_zero_123 = False, True
+            self.unet_model = w
+            self.scheduler = DDPMScheduler(1000)
+            self.cc_projection = nn.Sequential(nn.Linear(796, 768), nn.SiLU(True), nn.Linear(768, 768), nn.SiLU(True), nn.Linear(768, 768))
+            self.time_embed_dim = 256
+            self.time_embed = nn.Sequential(nn.Linear(256, 256), nn.SiLU(True), nn.Linear(256, 256))
+            self.register_buffer("_device", torch.tensor([0.0]), persistent=False)
+
+    m = Facade()
+    for name in ("view_attn", "cc_projection", "time_embed"):
+        fill_ref(getattr(m, name), name + ".")
+    m.eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sampler = DDIMSampler(m, ddim_num_steps=50, ddim_discretize="uniform", ddim_eta=1.0, latent_size=S, z_dim=4, feed_prev_depth=True)
+    inp = syn.make_inputs(V, S, seed=9)
+    bc, ic = ref_cams(inp["batch_cameras"]), ref_cams(inp["input_cameras"])
+    tab, dd = O.ddpm_tables(), O.ddim_schedule(O.ddpm_tables())
+    # the reference loop: x_T = randn, then per step [depth noise in GridAttn, update noise] -- drive it by hand over the first `steps`
+    torch.manual_seed(777)
+    x = torch.randn(V, 5, S, S)
+    x_T = x.clone()
+    prev, xs, x0s = None, [], []
+    for i in range(steps):
+        index = 49 - i
+        ts = torch.full((V,), int(dd["timesteps"][index]), dtype=torch.long)
+        with torch.no_grad():
+            x, x0 = sampler.denoise_apply(x, bc, inp["input_latents"], ic, inp["clip_v_embed"], ts, index, is_step0=False,
+                                          prev_depth=prev, cfg_scale=2.5)
+        prev = x0[:, 4:].clone()
+        xs.append(x)
+        x0s.append(x0)
+    torch.manual_seed(777)
+    xo = torch.randn(V, 5, S, S)
+    prev, dns, sns = None, [], []
+    for i in range(steps):
+        dn, sn = torch.randn(V, 1, S, S), torch.randn(V, 5, S, S)
+        dns.append(dn)
+        sns.append(sn)
+        with torch.no_grad():
+            xo, x0o = O.denoise_step(sd, xo, cam_dict(inp["batch_cameras"]), inp["input_latents"], cam_dict(inp["input_cameras"]),
+                                     inp["clip_v_embed"], tab, dd, 49 - i, dn, sn, cfg_scale=2.5,
+                                     unet_kw=dict(model_channels=model_channels, image_size=S), prev_depth=prev)
+        prev = x0o[:, 4:].clone()
+        e = max(rel_err(xo, xs[i]), rel_err(x0o, x0s[i]))
+        print(f"  feed_prev_depth step {i}: oracle vs reference {e:.2e}")
+        assert e < 5e-5, e
+    save("sample_prevdepth_mc32_v2", x_T=x_T, depth_noise=torch.stack(dns), step_noise=torch.stack(sns), xs=torch.stack(xs), x0s=torch.stack(x0s))
 
 
 def gold_gridattn_v8_s64():
@@ -710,6 +791,8 @@ ALL = {
     "step320_v8": lambda: gold_step(320, 8, 1, "step_mc320_v8_d1", indices=(49,), lean=True),
     "step320_v8_s64": lambda: gold_step(320, 8, 1, "step_mc320_v8_d1_s64", indices=(49,), S=64, lean=True),      # BASELINE configs[3]
     "gridattn_v8_s64": gold_gridattn_v8_s64,
+    "gridattn_prevdepth": gold_gridattn_prev_depth,
+    "sample_prevdepth": gold_sample_feed_prev_depth,
     "unet320_s64": lambda: gold_unet(320, 2, 1, "unet_mc320_v2_d1_s64", S=64, full=False),
     "unet320_d3": lambda: gold_unet(320, 2, 3, "unet_mc320_v2_d3", t_val=501),
     "gridattn_v15": gold_gridattn_v15,

@@ -169,7 +169,7 @@ def gridattn_tokens(feat, in_feat, cams, in_cam, depth, S):
 
 
 def gridattn_forward(sd, pre, noisy_latents, cams, t_embed, t, tables, depth_noise, input_latents, in_cam,
-                     n_pts_per_ray=1, depth_scale=2.0, depth_shift=0.5, return_tokens=False):
+                     n_pts_per_ray=1, depth_scale=2.0, depth_shift=0.5, return_tokens=False, overwrite_attn_depth=None):
     """GridAttn.forward view_attn_efficient2.py:413-442 + aggregate_features :269-410.
 
     depth_noise (V,D,S,S) ~ N(0,1) replaces the in-place torch.normal draw (:431): on CPU
@@ -179,7 +179,10 @@ def gridattn_forward(sd, pre, noisy_latents, cams, t_embed, t, tables, depth_noi
     D = n_pts_per_ray
     sac = tables["sqrt_alphas_cumprod"][t]
     std = tables["sqrt_one_minus_alphas_cumprod"][t] / sac / 10.0
-    dch = noisy_latents[:, 4:] / sac[:, None, None, None]
+    if overwrite_attn_depth is None:
+        dch = noisy_latents[:, 4:] / sac[:, None, None, None]
+    else:                                       # :423-426 (feed_prev_depth): the given depth map replaces the x0-style estimate
+        dch = overwrite_attn_depth
     dch = dch.expand(-1, D, -1, -1)
     samples = dch + std[:, None, None, None] * depth_noise
     depth = torch.clip((samples + 1.0) / 2.0, 0.0, 1.0) * depth_scale + depth_shift
@@ -405,13 +408,13 @@ def cc_projection(sd, clip_v_embed):
 
 
 def apply_model(sd, noisy_latents, cams, input_latents, in_cam, clip_v_embed, t, tables, depth_noise,
-                cfg_scale=2.5, n_pts_per_ray=1, unet_kw=None):
+                cfg_scale=2.5, n_pts_per_ray=1, unet_kw=None, prev_depth=None):
     """ViewFusion.apply_model viewfusion_zero_depth_rgb.py:282-345."""
     unet_kw = unet_kw or {}
     V = noisy_latents.shape[0]
     t_embed = embed_time(sd, t)
     vol = gridattn_forward(sd, "view_attn.", noisy_latents, cams, t_embed, t, tables, depth_noise,
-                           input_latents, in_cam, n_pts_per_ray=n_pts_per_ray)
+                           input_latents, in_cam, n_pts_per_ray=n_pts_per_ray, overwrite_attn_depth=prev_depth)
     il = input_latents.expand(V, -1, -1, -1)
     clip_embed = cc_projection(sd, clip_v_embed)
     pre = "unet_model.unet_model."
@@ -435,12 +438,12 @@ def ddim_update(x, eps, ddim, index, noise):
 
 
 def denoise_step(sd, x, cams, input_latents, in_cam, clip_v_embed, tables, ddim, index, depth_noise, step_noise,
-                 cfg_scale=2.5, n_pts_per_ray=1, unet_kw=None):
+                 cfg_scale=2.5, n_pts_per_ray=1, unet_kw=None, prev_depth=None):
     """DDIMSampler.denoise_apply mvdfusion/sampler.py:69-88."""
     V = x.shape[0]
     t = torch.full((V,), int(ddim["timesteps"][index]), dtype=torch.long)
     eps = apply_model(sd, x, cams, input_latents, in_cam, clip_v_embed, t, tables, depth_noise,
-                      cfg_scale=cfg_scale, n_pts_per_ray=n_pts_per_ray, unet_kw=unet_kw)
+                      cfg_scale=cfg_scale, n_pts_per_ray=n_pts_per_ray, unet_kw=unet_kw, prev_depth=prev_depth)
     return ddim_update(x, eps, ddim, index, step_noise if index > 0 else None)
 
 

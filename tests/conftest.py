@@ -97,3 +97,64 @@ def build_model(mc=320, D=1, S=32, precision=None):
         syn.fill_module_(m)
         _MODELS[key] = m.cuda().eval()
     return _MODELS[key]
+
+
+def clip_kat_case():
+    """A vision transformer whose output can be computed BY HAND (plain numpy loops below, float64): 128 wide, 2 heads, 14x14 patches
+    of a 224^2 image, 2 blocks with  q = k = 0 (uniform attention over the 257 tokens), v = out_proj = identity, c_proj = 0 (the MLP adds 0),
+    patch embedding = (1 + c / 128) x the mean of colour channel c % 3 of the patch, class / positional embeddings that differ per
+    position.  Pins -- independently of oracle/shims.py -- the class token sitting at position 0, the raster order of the patches and
+    their pairing with the positional embedding, the head concatenation order, the number of keys (257, not the padded row count) and
+    ln_pre / ln_1 / ln_post.  Returns (state_dict with keys 'visual.*', image (1,3,224,224) already preprocessed, expected (1,64))."""
+    W, P, g, L, heads, layers = 128, 14, 16, 257, 2, 2
+    gen = torch.Generator().manual_seed(123)
+    img = torch.rand(1, 3, 224, 224, generator=gen) * 2.0 - 1.0
+    sd = {}
+    conv = torch.zeros(W, 3, P, P)
+    for c in range(W):
+        conv[c, c % 3] = (1.0 + c / 128.0) / (P * P)
+    sd["visual.conv1.weight"] = conv
+    sd["visual.class_embedding"] = torch.linspace(-0.5, 0.5, W)
+    sd["visual.positional_embedding"] = 0.02 * torch.arange(L, dtype=torch.float32)[:, None] * torch.cos(torch.arange(W, dtype=torch.float32))[None, :] \
+        + 0.3 * torch.sin(0.37 * torch.arange(W, dtype=torch.float32))[None, :]
+    for n in ("ln_pre", "ln_post"):
+        sd[f"visual.{n}.weight"], sd[f"visual.{n}.bias"] = torch.ones(W), torch.zeros(W)
+    for i in range(layers):
+        b = f"visual.transformer.resblocks.{i}."
+        wqkv = torch.zeros(3 * W, W)
+        wqkv[2 * W:] = torch.eye(W)
+        sd[b + "attn.in_proj_weight"], sd[b + "attn.in_proj_bias"] = wqkv, torch.zeros(3 * W)
+        sd[b + "attn.out_proj.weight"], sd[b + "attn.out_proj.bias"] = torch.eye(W), torch.zeros(W)
+        sd[b + "ln_1.weight"], sd[b + "ln_1.bias"] = torch.ones(W) * (1.0 + 0.1 * i), torch.full((W,), 0.05 * i)
+        sd[b + "ln_2.weight"], sd[b + "ln_2.bias"] = torch.ones(W), torch.zeros(W)
+        sd[b + "mlp.c_fc.weight"] = torch.randn(4 * W, W, generator=gen) * 0.05
+        sd[b + "mlp.c_fc.bias"] = torch.zeros(4 * W)
+        sd[b + "mlp.c_proj.weight"], sd[b + "mlp.c_proj.bias"] = torch.zeros(W, 4 * W), torch.zeros(W)
+    proj = torch.zeros(W, 64)
+    for j in range(64):
+        proj[2 * j, j] = 1.0
+        proj[2 * j + 1, j] = -0.5
+    sd["visual.proj"] = proj
+    # ---- by hand
+    x = img[0].double().numpy()
+    tok = np.zeros((L, W))
+    tok[0] = sd["visual.class_embedding"].double().numpy()
+    for py in range(g):
+        for px in range(g):
+            means = [x[ch, py * P:(py + 1) * P, px * P:(px + 1) * P].sum() / (P * P) for ch in range(3)]
+            for c in range(W):
+                tok[1 + py * g + px, c] = (1.0 + c / 128.0) * means[c % 3]
+    tok += sd["visual.positional_embedding"].double().numpy()
+
+    def ln(v, w=1.0, b=0.0):
+        mu = v.mean(axis=-1, keepdims=True)
+        var = ((v - mu) ** 2).mean(axis=-1, keepdims=True)
+        return (v - mu) / np.sqrt(var + 1e-5) * w + b
+
+    h = ln(tok)
+    for i in range(layers):
+        y = ln(h, 1.0 + 0.1 * i, 0.05 * i)
+        h = h + y.mean(axis=0, keepdims=True)          # uniform attention over all 257 tokens, v = out_proj = identity; the MLP adds 0
+    cls = ln(h[0])
+    expected = cls @ proj.double().numpy()
+    return sd, img, torch.from_numpy(expected).float()[None]

@@ -47,6 +47,22 @@ def test_oracle_gridattn_vs_reference(name, V, D, seed, tval):
     assert abs(float(out.norm()) - float(gd["out_l2"])) / float(gd["out_l2"]) < 1e-5
 
 
+def test_oracle_gridattn_overwrite_attn_depth_vs_reference():
+    """overwrite_attn_depth (view_attn_efficient2.py:418-426; the feed_prev_depth path) of the oracle against the reference's output."""
+    gd = load_golden("gridattn_v4_d1_prevdepth")
+    V, tval = 4, 301
+    sd = {k: v for k, v in syn.det_fill_state_dict(load_spec(32)).items() if k.startswith("view_attn.")}
+    inp = syn.make_inputs(V, 32, int(gd["seed"]))
+    kw = dict(n_pts_per_ray=1)
+    args = (sd, "view_attn.", gd["x"], cams(inp["batch_cameras"]), gd["t_embed"], torch.full((V,), tval, dtype=torch.long), O.ddpm_tables(),
+            gd["depth_noise"], inp["input_latents"], cams(inp["input_cameras"]))
+    with torch.no_grad():
+        out = O.gridattn_forward(*args, overwrite_attn_depth=gd["prev_depth"], **kw)
+        plain = O.gridattn_forward(*args, **kw)
+    assert rel_err(out[:, ::5, ::7, :, ::3], gd["out_strided"]) < 3e-5
+    assert rel_err(plain[:, ::5, ::7, :, ::3], gd["out_strided"]) > 1e-2
+
+
 @pytest.mark.parametrize("name,mc,V,D,tval", [("unet_mc32_v4_d1", 32, 4, 1, 981), ("unet_mc32_v2_d3", 32, 2, 3, 501),
                                               ("unet_mc64_v2_d1", 64, 2, 1, 21), ("unet_mc320_v2_d3", 320, 2, 3, 501)])
 def test_oracle_unet_vs_reference(name, mc, V, D, tval):
@@ -489,3 +505,13 @@ def test_params_signature_tracks_updates_and_does_not_cancel():
     vf._engines["stale"] = object()
     vf.float()
     assert not vf._engines
+
+
+def test_kat_clip_tower_hand_computed():
+    """The oracle's restatement of OpenAI clip's VisionTransformer (a package that is NOT in the reference tree) against a hand-computed
+    case (conftest.clip_kat_case): class token position, patch raster order x positional embedding, 257 keys, head order, LayerNorms."""
+    from conftest import clip_kat_case
+    sd, img, want = clip_kat_case()
+    with torch.no_grad():
+        got = O.clip_encode_image(sd, "visual.", img, heads=2)
+    assert rel_err(got, want) < 1e-5, rel_err(got, want)

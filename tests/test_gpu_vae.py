@@ -474,3 +474,18 @@ def test_clip_image_encoder_vs_reference_golden(name, model):
     # a second call (cached packed weights, static buffers) is bit-identical; a list input is the unconditional zero vector
     assert torch.equal(enc.encode(x), out)
     assert float(enc([""]).abs().max()) == 0.0
+
+
+def test_kat_clip_tower_hand_computed():
+    """The HIP CLIP tower (patch GEMM, LN, QKV + flash attention with 257 keys in 260-row sequences, out_proj, MLP, ln_post, proj) on the
+    hand-computed case of conftest.clip_kat_case -- independent of the reference shims."""
+    from conftest import clip_kat_case
+    from mvdfusion_amd.encoders import FrozenCLIPImageEmbedder
+    from mvdfusion_amd.engine import Ctx
+    sd, img, want = clip_kat_case()
+    enc = FrozenCLIPImageEmbedder(model="tiny-test")
+    missing, unexpected = enc.model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(not k.startswith("visual.") for k in missing), (missing, unexpected)
+    enc = enc.cuda().eval()
+    got = enc._encode_image(Ctx("cuda", enc.precision), img.cuda())
+    assert rel_err(got.cpu(), want) < 2e-5, rel_err(got.cpu(), want)
