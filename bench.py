@@ -395,7 +395,11 @@ def main():
                     "command and workload, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch over the graph-replayed steps only")
         variants, tr_sum, tr_n = [], 0.0, 0
         for k, b in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
-            t = pmc.get(k, {}).get("hbm_bytes_per_launch")
+            ent = pmc.get(k)
+            if ent is None:      # conv_patch_kernel<BM, BN, WM, WN, NS, PI>: the host mirror does not know PI (chosen by the library)
+                cand = [v for kk, v in pmc.items() if kk.startswith(k.rstrip(">"))]
+                ent = cand[0] if len(cand) == 1 else {}
+            t = ent.get("hbm_bytes_per_launch")
             if t is not None:
                 tr_sum += t * b["n"]
                 tr_n += b["n"]

@@ -175,7 +175,7 @@ class StepEngine:
         if g is None:
             # first call runs eagerly (allocates every workspace buffer, packs weights), then capture
             it0 = self.iter.clone()
-            x_keep = self.x.clone()
+            x_keep, x0_keep = self.x.clone(), self.x0.clone()      # (x0: the previous step's estimate is an INPUT under feed_prev_depth)
             hip.AUTOTUNE = True            # pick the GEMM kernel configuration per problem shape (cached)
             try:
                 self.enqueue(cfg_scale, do_update)
@@ -184,6 +184,7 @@ class StepEngine:
             torch.cuda.synchronize()
             self.iter.copy_(it0)
             self.x.copy_(x_keep)
+            self.x0.copy_(x0_keep)
             g = hip.Graph()
             self.ctx.ws.frozen = True      # capture must not allocate: every buffer exists after the eager step
             try:

@@ -586,7 +586,7 @@ def gold_prepare_batch(tag, random_views, with_depths, seed):
     save(tag, seed=np.int64(seed), batch_latents=bl, input_latents=il, clip_v_embed=cv, bc_R=bc.R, bc_T=bc.T,
          bc_f=bc.focal_length, bc_p=bc.principal_point, ic_R=ic.R, ic_T=ic.T, ic_f=ic.focal_length, ic_p=ic.principal_point)
 
-def gold_train_loss(model_channels, V, D, tag, seed, S_img=256, grads_tag=None):
+def gold_train_loss(model_channels, V, D, tag, seed, S_img=256, grads_tag=None, lean=False):
     """The REAL ViewFusion.forward / p_losses (viewfusion_zero_depth_rgb.py:362-397) -- prepare_batch (reference VAE ch=32,
     stub CLIP), shared random timestep, q_sample, GridAttn + UNetWrapper.forward(is_train=True) WITH the condition dropout
     of unet.py:109-151, MSE -- on a seeded 16-view GSO batch.  The seed is chosen so that the dropout masks are not all-keep.
@@ -687,10 +687,14 @@ def gold_train_loss(model_channels, V, D, tag, seed, S_img=256, grads_tag=None):
         blk = [(n, p.grad.detach().clone()) for n, p in named if n.startswith(bp)]
         dcat = grabbed["dcat"]                                 # gradient at the input of the last output block (V, 2 mc, S, S)
         extra = {f"blk11_g{i}": gr for i, (_, gr) in enumerate(blk)}
+        if lean:          # full width: only the two-number fingerprints of every gradient + strided activations' gradients (MBs otherwise)
+            extra = {}
+            g = {k: v.flatten()[:8] for k, v in g.items()}
         save(grads_tag, blk11_names=np.array([n for n, _ in blk]), dcat_strided=dcat[:, :, ::3, ::5].contiguous(), dcat_norm=dcat.norm(),
              **extra, loss=loss_g.detach(), out0_weight=g[hp + "0.weight"], out0_bias=g[hp + "0.bias"], out2_weight=g[hp + "2.weight"],
              out2_bias=g[hp + "2.bias"], dh_strided=dh[:, :, ::3, ::5].contiguous(), dh_norm=dh.norm(),
-             grad_names=np.array([n for n, _ in named]), grad_norms=np.array([float(p.grad.norm()) for _, p in named], dtype=np.float64),
+             grad_names=np.array([n for n, _ in named]), grad_norms=np.array([float(p.grad.double().norm() if lean else p.grad.norm()) for _, p in named], dtype=np.float64),      # (fp32 norm of a
+             # 14.7 M-element gradient is itself only good to ~1e-3: the full-width fixture takes it in float64)
              # projection of every gradient onto a seeded N(0,1) direction (CPU generator, seed 1000 + index): with the norm, a
              # two-number fingerprint per parameter that a wrong layout / sign / missing term cannot match
              grad_projs=np.array([float((p.grad.double().flatten() * torch.randn(p.numel(), generator=torch.Generator().manual_seed(1000 + i))
@@ -800,6 +804,7 @@ ALL = {
     "clip_tiny": lambda: gold_clip("tiny-test", "clip_tiny"),
     "clip_l14": lambda: gold_clip("ViT-L/14", "clip_vit_l14"),
     "train32_d3": lambda: gold_train_loss(32, 4, 3, "train_loss_mc32_v4_d3", seed=31, grads_tag="train_grads_mc32_v4_d3"),
+    "train320_d3": lambda: gold_train_loss(320, 2, 3, "train_loss_mc320_v2_d3", seed=35, grads_tag="train_grads_mc320_v2_d3", lean=True),
     "traj32": lambda: gold_trajectory(32, 4, 1, "traj_mc32_v4_d1", steps=5),
     "traj320": lambda: gold_trajectory(320, 4, 1, "traj_mc320_v4_d1_50steps", steps=50),
     "traj320_f64": lambda: gold_trajectory_f64(320, 4, 1, "traj_mc320_v4_d1_50steps_f64", steps=50),

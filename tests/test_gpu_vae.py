@@ -175,15 +175,15 @@ def test_sample_then_decode_end_to_end():
     assert bool(torch.isfinite(img).all())
 
 
-def _training_setup(gd):
-    """The model / batch / random draws of the reference's training fixtures (oracle/make_golden.py: train32_d3)."""
+def _training_setup(gd, mc=32, V=4):
+    """The model / batch / random draws of the reference's training fixtures (oracle/make_golden.py: train32_d3, train320_d3)."""
     from conftest import model_config
     from mvdfusion_amd import synthetic as syn
     from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
-    V, D, S = 4, 3, 32
+    D, S = 3, 32
     dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
               num_res_blocks=2, attn_resolutions=[], dropout=0.0)
-    cfg = model_config(32, D=D)
+    cfg = model_config(mc, D=D)
     cfg["vae_config"] = dict(target="external.sd1.ldm.models.autoencoder.AutoencoderKL",
                              params=dict(embed_dim=4, ddconfig=dd, lossconfig=dict(target="torch.nn.Identity")))
     m = ViewFusion(clip_image_encoder=syn.StubClipImageEncoder(), **cfg)
@@ -320,14 +320,17 @@ def test_training_unet_gradients_vs_reference_golden():
     assert bool(torch.isfinite(dvol).all()) and float(dvol.abs().max()) > 0
 
 
-def test_training_all_gradients_vs_reference_golden():
+@pytest.mark.parametrize("name,mc,V", [("train_grads_mc32_v4_d3", 32, 4), ("train_grads_mc320_v2_d3", 320, 2)])
+def test_training_all_gradients_vs_reference_golden(name, mc, V):
     """The complete `loss.backward()` (train.py:90-95) on the HIP path: UNet + cc_projection + GridAttn (final layer, softmax-over-V
     pooling, 3 adaLN-Zero DiT blocks with attention over the V views, pre layer, grid_sample backward into the z-embedded latents)
     + time_embed: ALL 994 parameter gradients the reference's autograd produces, fingerprinted by L2 norm and a seeded random
-    projection (train_grads_mc32_v4_d3)."""
-    gd = load_golden("train_grads_mc32_v4_d3")
-    m, batch, tc, draws = _training_setup(gd)
+    projection -- at reduced width (train_grads_mc32_v4_d3) and at the FULL width of configs/mvd_train.yaml (model_channels 320,
+    1 039 M parameters, `finetune_unet: true`: every UNet weight gets a gradient; train_grads_mc320_v2_d3)."""
+    gd = load_golden(name)
+    m, batch, tc, draws = _training_setup(gd, mc=mc, V=V)
     loss, grads = m.gradients(batch, tc, noise_source=draws)
+    assert abs(float(loss) - float(gd["loss"])) / float(gd["loss"]) < 1e-4
     names = [str(n) for n in gd["grad_names"]]
     norms, projs = gd["grad_norms"].double(), gd["grad_projs"].double()
     assert len(names) == 994

@@ -22,12 +22,16 @@ def main():
     ap.add_argument("--depth-samples", type=int, default=3)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--frozen-unet", action="store_true", help="finetune_unet: false (only the cross-attention / view-aligned parameters train); "
+                    "default = configs/mvd_train.yaml:15 finetune_unet: true (all 1 039 M parameters)")
     a = ap.parse_args()
     from conftest import load_spec, model_config
     from mvdfusion_amd import synthetic as syn
     from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
     V, D, S = a.views, a.depth_samples, 32
-    m = ViewFusion(**model_config(a.width, D=D, S=S))
+    cfg = model_config(a.width, D=D, S=S)
+    cfg["finetune_unet"] = not a.frozen_unet
+    m = ViewFusion(**cfg)
     m.load_state_dict(syn.det_fill_state_dict(load_spec(a.width)), strict=False)
     m = m.cuda().train()
     for n, p in m.named_parameters():
@@ -53,6 +57,7 @@ def main():
     dt = sum(times[1:]) / a.steps
     print(json.dumps({"metric": "training-steps/sec (fwd + bwd + AdamW, one scene)", "value": 1.0 / dt, "s_per_step": dt, "first_step_s": times[0],
                       "views": V, "depth_samples": D, "latent": S, "model_channels": a.width, "trainable_parameters": n_train,
+                      "finetune_unet": not a.frozen_unet,
                       "losses": losses, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
                       "note": "backward = recompute-per-block + dgrad/wgrad on the split-operand MFMA GEMM, fp32 VALU attention "
                               "backward; a functional training path, not yet tuned (no graph capture, fresh allocations)"}))

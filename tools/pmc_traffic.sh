@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$R/gpurun_out/pmc_${tag}_$c
   rm -rf $out
-  rocprofv3 --pmc $c --output-format csv -d $out -o pmc -- python $R/bench.py --steps 12 --warmup 1 --no-cpu-baseline "$@" > $out.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out -o pmc -- python $R/bench.py --steps 12 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $out.log 2>&1
   ls $out | head -3
 done
 python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_${tag}_FETCH_SIZE $R/gpurun_out/pmc_${tag}_WRITE_SIZE $R/gpurun_out/pmc_${tag}_traffic.json "$@"

@@ -2,7 +2,7 @@
 # Round artefacts on the GPU box -> gpurun_out/<tag>/ (copied into profiles/ by hand afterwards):
 #   bench lines (V=4 default with cpu_baseline; V=8; V=8 x 64^2), rocprofv3 kernel-trace stats of the default command,
 #   PMC traffic / MFMA passes per workload, shard emulation, step trace summary.
-tag=${1:-r02}
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -10,7 +10,7 @@ cd $R
 # one autotuning per workload, shared by the bench run and every rocprofv3 pass (identical kernels everywhere)
 T4=$O/tuned_v4_s32.json; T8=$O/tuned_v8_s32.json; T864=$O/tuned_v8_s64.json
 rm -f $T4 $T8 $T864
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline --tune-cache $T4 > /dev/null 2>&1
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --tune-cache $T4 > /dev/null 2>&1
 python bench.py --views 8 --steps 10 --warmup 3 --no-cpu-baseline --tune-cache $T8 > /dev/null 2>&1
 python bench.py --views 8 --latent 64 --steps 5 --warmup 2 --no-cpu-baseline --tune-cache $T864 > /dev/null 2>&1
 python bench.py --steps 100 --warmup 5 --tune-cache $T4 > $O/bench_n1.json 2> $O/bench_n1.log
@@ -19,7 +19,7 @@ python bench.py --views 8 --latent 64 --steps 20 --warmup 3 --no-cpu-baseline --
 cd /tmp && export TMPDIR=/tmp
 out=$O/prof
 rm -rf $out
-rocprofv3 --kernel-trace --stats -d $out -o bench --output-format csv -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --tune-cache $T4 > $O/prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out -o bench --output-format csv -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-secondary --tune-cache $T4 > $O/prof.log 2>&1
 cp $out/bench_kernel_stats.csv $O/bench_n1_kernel_stats.csv
 python $R/tools/trace_summary.py $out $O/step_trace_v4.json > $O/step_trace_v4.txt
 rm -rf $out
