@@ -86,7 +86,7 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, floa
 #define MVD_ACT_QUICKGELU 3 /* x * sigmoid(1.702 x): the MLP activation of OpenAI CLIP's vision transformer */
 
 #define MVD_GEMM_TILES 5 /* tile shapes of mvd_gemm_desc.cfg */
-#define MVD_GEMM_LOOPS 7 /* k-loop variants of mvd_gemm_desc.cfg */
+#define MVD_GEMM_LOOPS 8 /* k-loop variants of mvd_gemm_desc.cfg */
 #define MVD_B_PACKED 0   /* B: weight image of mvd_pack_linear_weight / mvd_pack_conv3x3_weight */
 #define MVD_B_PLANES 1   /* B: (N, ldb) row-major split planes (an activation), N % 16 == 0 */
 
@@ -148,8 +148,9 @@ typedef struct mvd_gemm_desc {
    *          ring of up to 8 (4-wave tiles): one workgroup per CU keeps 3 / 7 k-tiles of operands in flight, for the small grids
    *          of the low-resolution levels whose k-loop is otherwise one DMA round trip per k-tile, 6 = the input-patch kernel for
    *          stride-1 padded 3x3 convolutions (tiles 1, 2, 4): the tile's pixels + halo are staged once per 32-channel block and the
-   *          nine taps read shifted slots of that patch (4-6x less A traffic into LDS); mvd_gemm_cfg_supported() tells whether a
-   *          cfg serves a problem
+   *          nine taps read shifted slots of that patch (4-6x less A traffic into LDS), 7 = the wave-specialised kernel (tiles 1, 2,
+   *          4; MVD_EPI_STORE): four consumer wavefronts (fragment reads + MFMAs) and four loader wavefronts (all LDS-DMAs) per
+   *          workgroup; mvd_gemm_cfg_supported() tells whether a cfg serves a problem
    *   order: 0 = n-fastest, 1 = m-fastest order of the output tiles over the 8 XCDs.
    * The host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
    * winner from then on (mvdfusion_amd/hip.py: autotune). */

@@ -410,10 +410,11 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
 
 # mvd_gemm_desc.cfg = 1 + 16 * tile + 2 * loop + order (include/mvd_hip.h)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
-GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
+GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch", "ws")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
                                  # (3 / 4 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
                                  # (stride-1 3x3 convolutions: the input patch is staged once per channel block)
 PATCH_LOOP = 6
+WS_LOOP = 7                      # gemm_ws_kernel: consumer / loader wavefront roles (tiles 1, 2, 4; EPI_STORE)
 
 
 def _cfg_parts(cfg):
@@ -431,7 +432,8 @@ def _cfg_valid(cfg, epi, b_mode=0):
     bm, bn, wm, wn = GEMM_TILES[tile]
     waves = wm * wn
     return (loop not in (2, 3) or waves == 8) and (loop != 3 or tile == 1) and (loop != 5 or waves == 4) and \
-        (loop != PATCH_LOOP or tile in (1, 2, 4)) and (tile < 2 or epi == EPI_STORE)
+        (loop != PATCH_LOOP or tile in (1, 2, 4)) and (tile < 2 or epi == EPI_STORE) and \
+        (loop != WS_LOOP or (tile in (1, 2, 4) and epi == EPI_STORE))
 
 
 _ALL_CONFIGS = tuple(c for c in range(1, 16 * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
@@ -461,6 +463,9 @@ def kernel_symbol(cfg, prec, conv):
     bm, bn, wm, wn = GEMM_TILES[tile]
     if loop == PATCH_LOOP:
         return f"conv_patch_kernel<{bm}, {bn}, {wm}, {wn}, {prec}>"
+    if loop == WS_LOOP:
+        cm, cn = {1: (2, 2), 2: (4, 1), 4: (2, 2)}[tile]
+        return f"gemm_ws_kernel<{bm}, {bn}, {cm}, {cn}, {prec}, {1 if conv else 0}>"
     return f"gemm_kernel<{bm}, {bn}, {wm}, {wn}, {prec}, {1 if conv else 0}, {GEMM_LOOPS[loop]}>"
 
 
@@ -508,7 +513,8 @@ def _autotune(d, A=None, reps=4, trials=3, W_data=None):
     e0, e1 = Event(), Event()
     stats_ptr, d.gn_stats = d.gn_stats, None          # the statistics atomics must run exactly once: only in the real launch
     # split-K: the library's model (0 = auto) or none (1); the timed region includes the reduce kernel of a split GEMM
-    cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode, conv=d.a_mode == A_CONV3X3) if cfg_supported(d, c)
+    skip = {int(t) for t in os.environ.get("MVD_TUNE_EXCLUDE_LOOPS", "").split(",") if t}      # (A/B measurements: e.g. "7" = no role-split kernel)
+    cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode, conv=d.a_mode == A_CONV3X3) if cfg_supported(d, c) and _cfg_parts(c)[1] not in skip
              for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]
     # three cold copies of the packed weight, launched back to back between one pair of events: the eager launch latency (a few us
     # of jitter, the size of the differences being ranked) is paid once per three kernels and hides behind the first one

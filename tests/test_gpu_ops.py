@@ -165,6 +165,15 @@ def test_gemm_geglu(hip, splitk):
     op = hip.planes_like(M, 4 * C, "cuda")
     hip.gemm(Ap, Wp, None, epi=hip.EPI_GEGLU, workspace=ws, splitk=splitk, out_planes=op)
     assert rel_err(planes_to_float(op), ref) < TOL[3] + PL
+    # every kernel configuration that serves the GEGLU epilogue (incl. the wave-specialised kernel with 128 x 32 consumer tiles)
+    base = None
+    for cfg in hip.gemm_configs(hip.EPI_GEGLU)[::2]:
+        out.fill_(float("nan"))
+        hip.gemm(Ap, Wp, out, epi=hip.EPI_GEGLU, workspace=ws, splitk=splitk, cfg=cfg)
+        assert rel_err(out, ref) < TOL[3], cfg
+        if splitk == 1:
+            base = out.clone() if base is None else base
+            assert torch.equal(out, base), cfg
 
 
 @pytest.mark.parametrize("prec", [4, 3, 1])
@@ -392,6 +401,17 @@ def test_qkv_gemm_and_attention(hip, prec, B, H, L, d):
     out = hip.planes_like(B * L, C, "cuda")
     hip.attention(planes, out, B, H, L, d, prec=prec)
     assert rel_err(planes_to_float(out), ref) < 2 * TOL[prec] + PL
+    if prec == 4 and L <= 256:      # every kernel configuration that serves the QKV routing epilogue writes the same operand planes
+        want = None                 # (the call above may have split K: compare the unsplit runs with each other)
+        for cfg in hip.gemm_configs(hip.EPI_QKV)[::2]:
+            for t in planes:
+                t.zero_()
+            hip.gemm(xp, Wp, None, prec=prec, epi=hip.EPI_QKV, qkv=dict(planes=planes, heads=H, dhead=d, L=L), workspace=ws, cfg=cfg, splitk=1)
+            if want is None:
+                want = [t.clone() for t in planes]
+            assert all(torch.equal(a, b) for a, b in zip(planes, want)), cfg
+        hip.attention(planes, out, B, H, L, d, prec=prec)
+        assert rel_err(planes_to_float(out), ref) < 2 * TOL[prec] + PL
 
 
 @pytest.mark.parametrize("pcfg,psplit", [(0, 1), (_hip.make_cfg(2, 1), 1), (_hip.make_cfg(1, 0), 1), (_hip.make_cfg(3, 4), 1), (0, 3)])
