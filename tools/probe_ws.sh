@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/r3p
-python -m pytest tests/test_gpu_ops.py -x -q -k "qkv or geglu or configurations" 2>&1 | tail -3
-for x in "" 7 "6,7" "" 7; do MVD_TUNE_EXCLUDE_LOOPS=$x python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/r3p/bench_$x.json 2> gpurun_out/r3p/bench_$x.err
+mkdir -p gpurun_out/r3q
+python -m pytest tests/test_gpu_ops.py -x -q 2>&1 | tail -3
+python -m pytest tests/test_gpu_model.py -x -q -k "gridattn or denoise_step or graph_replay" 2>&1 | tail -3
+for i in 1 2; do python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/r3q/bench_$i.json 2> gpurun_out/r3q/bench_$i.err
 python -c "
-import json; d=json.load(open('gpurun_out/r3p/bench_$x.json')); print('exclude [$x]', d['value'], d['ms_per_step'], d['roofline']['gemm_share_of_step_ms'])"; done
+import json; d=json.load(open('gpurun_out/r3q/bench_$i.json')); print(d['value'], d['ms_per_step'], d['roofline']['gemm_share_of_step_ms'], {k:(round(v['ms_per_step'],3), v.get('mfma_pipe_frac')) for k,v in d['roofline_groups'].items()})"; done
