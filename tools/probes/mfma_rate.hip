@@ -22,11 +22,18 @@ __global__ __launch_bounds__(512) void k16(float* out, int iters) {
   for (int it = 0; it < iters; it += 2) {
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
-      if (SYNC == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the k-loops' per-k-tile rendezvous
+      if (SYNC == 1 || SYNC == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the k-loops' per-k-tile rendezvous
       if (SYNC == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int j = 0; j < READS; ++j)
-        fr[par ^ 1][j] = *(const h8*)(lds + ((lane * 16 + ((it + par) & 3) * 16384 + j * 1024) & 65535));
+      for (int j = 0; j < READS; ++j) {
+        if (SYNC >= 3 && j < 4) {      // the GEMM's swizzled A-fragment pattern (row = lane & 15 of a 16-row block, chunk (lane >> 4 [+4]) ^ ((row >> 1) & 7))
+          const int frow = lane & 15, fsw = (frow >> 1) & 7, fbase = (frow >> 3) * 1024 + (frow & 7) * 128;
+          const int off = fbase + ((((j & 1) * 4 + (lane >> 4)) ^ fsw) * 16) + (j >> 1) * 2048;
+          fr[par ^ 1][j] = *(const h8*)(lds + ((off + ((it + par) & 3) * 16384) & 65535));
+        } else {
+          fr[par ^ 1][j] = *(const h8*)(lds + ((lane * 16 + ((it + par) & 3) * 16384 + j * 1024) & 65535));
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -104,6 +111,8 @@ int main() {
     printf("16x16x32  acc10  %d waves/SIMD + 14 ds_read_b128 + lgkmcnt(0) + s_barrier per 40 MFMA: %7.1f TFLOP/s\n", threads / 256, 2.0 * 16 * 16 * 32 * 10 * 4 * iters * (threads / 64) * blocks / t / 1e12);
     t = timeit([&] { hipLaunchKernelGGL((k16<10, 14, 2>), dim3(blocks), dim3(threads), 0, 0, out, iters); });
     printf("16x16x32  acc10  %d waves/SIMD + 14 ds_read_b128 + lgkmcnt(0) (no barrier) per 40 MFMA: %7.1f TFLOP/s\n", threads / 256, 2.0 * 16 * 16 * 32 * 10 * 4 * iters * (threads / 64) * blocks / t / 1e12);
+    t = timeit([&] { hipLaunchKernelGGL((k16<10, 14, 3>), dim3(blocks), dim3(threads), 0, 0, out, iters); });
+    printf("16x16x32  acc10  %d waves/SIMD + 14 ds_read_b128 (4 in the swizzled A pattern) + lgkmcnt(0) + s_barrier per 40 MFMA: %7.1f TFLOP/s\n", threads / 256, 2.0 * 16 * 16 * 32 * 10 * 4 * iters * (threads / 64) * blocks / t / 1e12);
     t = timeit([&] { hipLaunchKernelGGL((k16<10, 0, 1>), dim3(blocks), dim3(threads), 0, 0, out, iters); });
     printf("16x16x32  acc10  %d waves/SIMD + s_barrier per 40 MFMA (no reads): %7.1f TFLOP/s\n", threads / 256, 2.0 * 16 * 16 * 32 * 10 * 4 * iters * (threads / 64) * blocks / t / 1e12);
     t = timeit([&] { hipLaunchKernelGGL((k32<4>), dim3(blocks), dim3(threads), 0, 0, out, iters); });
