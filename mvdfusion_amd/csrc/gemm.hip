@@ -169,6 +169,17 @@ __device__ __forceinline__ float2 ln_row_stats(const mvd_gemm_desc& d, int m) {
   return make_float2((float)mean, (float)(1.0 / sqrt(var + (double)d.ln_eps)));
 }
 
+#ifdef MVD_STAMP
+// profiling build (tools/probes/stamp.sh): cycle stamps of workgroups 0 and 100, consumer waves 0..3, into d.workspace (int64[2][4][16])
+#define MVD_STAMP_AT(d, wave, slot)                                                                                       \
+  do {                                                                                                                    \
+    if ((blockIdx.x == 0 || blockIdx.x == 100) && (wave) < 4 && (threadIdx.x & 63) == 0)                                  \
+      ((long long*)(d).workspace)[(blockIdx.x == 100 ? 64 : 0) + (wave) * 16 + (slot)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define MVD_STAMP_AT(d, wave, slot) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------ tile epilogue
 // Shared by gemm_kernel and conv_patch_kernel: the wave's accumulator tile is transposed through LDS (the stage buffers are free: the
 // caller has passed a workgroup barrier after its last fragment read) so that global traffic is row-contiguous 16-byte accesses.
@@ -183,6 +194,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
   const int wm = wave / WN, wn = wave % WN;
   //      (the final barrier above guarantees nobody still reads the stage buffers; each wave owns a private region)
   float* sC = (float*)smem + wave * (WTM * LDW);
+  MVD_STAMP_AT(d, wave, 4);
   {
     const int crow = (lane >> 4) * 4, ccol = lane & 15;   // C layout: row = (lane>>4)*4 + r, col = lane&15
 #pragma unroll
@@ -193,6 +205,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int r = 0; r < 4; ++r) sC[(i * 16 + crow + r) * LDW + j * 16 + ccol] = acc[i][j][r];
   }
   const int wm0 = m0 + wm * WTM, wn0 = n0 + wn * WTN;
+#ifdef MVD_STAMP
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  MVD_STAMP_AT(d, wave, 5);
   if (wn0 >= d.N) return;
   // LayerNorm of the A rows folded in: y = rstd (acc - mean colsum) + bias; {mean, rstd} of the block tile's rows were gathered into LDS
   // by the kernel's prologue (gemm_kernel: ln_gather_rows)
@@ -204,7 +220,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     //  few tens of KB where that hand-off pays, and its cache-wide write-back / invalidate disturbs the operand
     //  streams of the other workgroups.)
     float* ws = d.workspace + (size_t)blockIdx.z * d.M * d.N;
-#pragma unroll
+#pragma unroll 2
     for (int ps = 0; ps < (WTM * C4 + 63) / 64; ++ps) {
       const int idx = ps * 64 + lane;
       const int row = idx / C4, col = (idx - row * C4) * 4;
@@ -217,24 +233,32 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
   if (d.epi == MVD_EPI_GEGLU) {   // wave tile = 16 value columns | 16 gate columns
     const int ocol0 = (wn0 >> 5) * 16;
     const int half = d.N >> 1;
-#pragma unroll
+    // (rolled chunk loops, column operands loaded once: see MVD_EPI_STORE below)
+    const int q = (lane & 3) * 4, col = ocol0 + q;
+    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sg = sv, bv = sv, bg = sv;
+    if (lnf) {
+      sv = *(const float4*)(d.ln_colsum + col);
+      sg = *(const float4*)(d.ln_colsum + half + col);
+    }
+    if (d.bias) {
+      bv = *(const float4*)(d.bias + col);
+      bg = *(const float4*)(d.bias + half + col);
+    }
+#pragma unroll 1
     for (int ps = 0; ps < WTM / 16; ++ps) {
-      const int row = ps * 16 + (lane >> 2), q = (lane & 3) * 4;
+      const int row = ps * 16 + (lane >> 2);
       const int m = wm0 + row;
       if (m >= d.M) continue;
       float4 v = *(const float4*)(sC + row * LDW + q);
       float4 g = *(const float4*)(sC + row * LDW + 16 + q);
-      const int col = ocol0 + q;
       v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
       g.x *= d.acc_scale; g.y *= d.acc_scale; g.z *= d.acc_scale; g.w *= d.acc_scale;
       if (lnf) {
         const float mean = sR[row * 2], rstd = sR[row * 2 + 1];
-        const float4 sv = *(const float4*)(d.ln_colsum + col), sg = *(const float4*)(d.ln_colsum + half + col);
         v.x = (v.x - mean * sv.x) * rstd; v.y = (v.y - mean * sv.y) * rstd; v.z = (v.z - mean * sv.z) * rstd; v.w = (v.w - mean * sv.w) * rstd;
         g.x = (g.x - mean * sg.x) * rstd; g.y = (g.y - mean * sg.y) * rstd; g.z = (g.z - mean * sg.z) * rstd; g.w = (g.w - mean * sg.w) * rstd;
       }
       if (d.bias) {
-        const float4 bv = *(const float4*)(d.bias + col), bg = *(const float4*)(d.bias + half + col);
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
       }
@@ -251,23 +275,24 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       const int dq = mvd_attn_dpad(d.dhead);
       u16* ph = (u16*)(which == 0 ? d.q_hi : d.k_hi);
       u16* pl = (u16*)(which == 0 ? d.q_lo : d.k_lo);
-#pragma unroll
+      const int col = (lane & 7) * 4, n = wn0 + col;
+      const int cc = n - which * C;
+      const int head = cc / d.dhead, dd = cc - head * d.dhead;
+      const float qs = which == 0 ? d.qscale : 1.0f;
+      float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), cs = bb;
+      if (d.bias) bb = *(const float4*)(d.bias + n);        // in_proj bias (nn.MultiheadAttention, timm qkv_bias); SD attention has none
+      if (lnf) cs = *(const float4*)(d.ln_colsum + n);
+#pragma unroll 1
       for (int ps = 0; ps < WTM / 8; ++ps) {
-        const int row = ps * 8 + (lane >> 3), col = (lane & 7) * 4;
-        const int m = wm0 + row, n = wn0 + col;
+        const int row = ps * 8 + (lane >> 3);
+        const int m = wm0 + row;
         if (m >= d.M) continue;
         float4 v = *(const float4*)(sC + row * LDW + col);
-        const int cc = n - which * C;
-        const int head = cc / d.dhead, dd = cc - head * d.dhead;
         const int b = m / d.L, tok = m - b * d.L;
         const size_t idx = ((size_t)(b * d.heads + head) * d.Lpad + tok) * dq + dd;
-        const float qs = which == 0 ? d.qscale : 1.0f;
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.bias) bb = *(const float4*)(d.bias + n);        // in_proj bias (nn.MultiheadAttention, timm qkv_bias); SD attention has none
         v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
         if (lnf) {
           const float mean = sR[row * 2], rstd = sR[row * 2 + 1];
-          const float4 cs = *(const float4*)(d.ln_colsum + n);
           v.x = (v.x - mean * cs.x) * rstd; v.y = (v.y - mean * cs.y) * rstd; v.z = (v.z - mean * cs.z) * rstd; v.w = (v.w - mean * cs.w) * rstd;
         }
         store_planes4(ph, pl, idx, (v.x + bb.x) * qs, (v.y + bb.y) * qs, (v.z + bb.z) * qs, (v.w + bb.w) * qs);
@@ -277,19 +302,20 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       const int col = lane & 31, rsel = lane >> 5;
       const int cc = wn0 + col - 2 * C;
       const int head = cc / d.dhead, dd = cc - head * d.dhead;
-#pragma unroll
+      const float bv = d.bias ? d.bias[wn0 + col] : 0.f;
+      const float csv = lnf ? d.ln_colsum[wn0 + col] : 0.f;
+#pragma unroll 1
       for (int ps = 0; ps < WTM / 8; ++ps) {
         const int row = (ps * 2 + rsel) * 4;
         const int m = wm0 + row;
         if (m >= d.M) continue;
         const int b = m / d.L, tok = m - b * d.L;
         const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
-        const float bv = d.bias ? d.bias[wn0 + col] : 0.f;
         float t4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           t4[i] = sC[(row + i) * LDW + col] * d.acc_scale;
-          if (lnf) t4[i] = (t4[i] - sR[(row + i) * 2] * d.ln_colsum[wn0 + col]) * sR[(row + i) * 2 + 1];
+          if (lnf) t4[i] = (t4[i] - sR[(row + i) * 2] * csv) * sR[(row + i) * 2 + 1];
           t4[i] += bv;
         }
         store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, t4[0], t4[1], t4[2], t4[3]);
@@ -298,24 +324,145 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     return;
   }
   }
-  // MVD_EPI_STORE
+  // MVD_EPI_STORE, in two passes over the wave tile.  A 64-lane chunk is RPC = 64 / C4 whole rows of C4 16-byte columns (80-column wave
+  // tiles: 3 rows on 60 lanes), so a lane keeps its column for the whole tile: no division per chunk, the bias / column scale are
+  // loaded once, every pointer advances by a constant.
+  //   pass 1: epilogue arithmetic on the staged accumulators, final values back into the LDS staging tile; the residual (and the per-view
+  //           bias) of chunk ps + 1 is requested before chunk ps is computed; no global store;
+  //   pass 2: LDS -> global (fp32 and / or planes); no global load.
+  // History (s_memtime stamps, tools/probes/ws_stamp.py; 32x80 wave tile of a 128x80 workgroup tile): one pass, load - compute - store per
+  // chunk, everything unrolled and every option (bias, per-view bias, 3 activations, column scale, residual, fp32 / planes outputs) decided
+  // at run time per chunk: 14.4 k cycles -- more than the whole k-loop of a K = 320 GEMM -- and ~100 KiB of code per kernel.  Two causes:
+  // (1) the stores are conditional, so the compiler cannot count them and waits vmcnt(0) for a load issued after them, i.e. for the
+  // acknowledgement of the previous chunk's stores, once per chunk; (2) ~100 VALU / scalar-branch instructions per chunk with ONE
+  // wavefront per SIMD to issue them.
+  constexpr int RPC = 64 / C4;
+  constexpr int NPS = (WTM + RPC - 1) / RPC;
+  const int lrow = lane / C4, lcol = (lane - lrow * C4) * 4;
+  const int n = wn0 + lcol;
+  const int mrow0 = wm0 + lrow;
+  const bool lane_ok = lane < RPC * C4 && n + 3 < d.n_store;
+  float* const sL = sC + lrow * LDW + lcol;                  // the lane's four values of chunk 0; chunk ps: + ps * RPC * LDW
+  const int rows_ok = min(WTM - lrow, d.M - mrow0);          // chunk ps is valid for this lane iff ps * RPC < rows_ok
+  auto pass1 = [&](auto act_c, auto res_c, auto bb_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    constexpr bool HAS_RES = decltype(res_c)::value, HAS_BB = decltype(bb_c)::value;
+    // Chunks are processed in GROUPS: all residual / per-view bias requests of a group first, then its arithmetic -- one exposed
+    // round trip per group (~850 cycles when all 256 CUs reach their epilogues together; a chunk's arithmetic is ~100).  The requests and
+    // the LDS reads are UNCONDITIONAL (lanes / chunks outside the tile read the zero page / the lane's first chunk) so that the compiler can
+    // batch and count them: a load under a branch forces vmcnt(0).  No value is carried from one group to the next (a register pipeline
+    // across the back edge of the rolled loop makes the compiler rotate registers behind a vmcnt(0)).
+    constexpr int GRP = NPS <= 11 ? NPS : (NPS + 1) / 2, NGRP = (NPS + GRP - 1) / GRP;
+    const float scale = d.acc_scale;
+    const bool has_bias = d.bias != nullptr, has_cs = d.colscale != nullptr;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (has_bias && lane_ok) b = *(const float4*)(d.bias + n);
+    if (has_cs && lane_ok) cs = *(const float4*)(d.colscale + n);
+    // (the activation variants are compiled for "residual and per-view bias present"; an absent operand reads the zero page)
+    const float* const zero = (const float*)g_zero_page;
+    const bool use_res = HAS_RES && d.res != nullptr, use_bb = HAS_BB && d.bias_b != nullptr;
+    // (one pointer select per lane, outside the loops; inside, only integer offsets are selected -- a select between two POINTERS in
+    //  the loop body is compiled into control flow with a load on either side)
+    const bool lane_any = lane_ok && rows_ok > 0;
+    const float* const rbase = use_res && lane_any ? d.res + (size_t)mrow0 * d.ldr + n : zero;
+    const size_t rstep = use_res && lane_any ? (size_t)RPC * d.ldr : 0;
+    const float* const bbase = use_bb && lane_any ? d.bias_b + n : zero;
+    const int rpb = use_bb ? d.rows_per_batch : 1, ldbb = use_bb && lane_any ? d.ldbb : 0;
+#pragma unroll 1
+    for (int g = 0; g < NGRP; ++g) {
+      float4 qr[GRP], qb[GRP], qv[GRP];
 #pragma unroll
-  for (int ps = 0; ps < (WTM * C4 + 63) / 64; ++ps) {
-    const int idx = ps * 64 + lane;
-    const int row = idx / C4, col = (idx - row * C4) * 4;
-    const int m = wm0 + row, n = wn0 + col;
-    if (idx >= WTM * C4 || m >= d.M || n >= d.N) continue;
-    const float4 v = *(const float4*)(sC + row * LDW + col);
-    if (n + 3 < d.n_store) {
-      const float4 f = epi_store4(d, m, n, v);
-      if (d.gn_stats || d.rs_out) *(float4*)(sC + row * LDW + col) = f;      // final values back into the staging tile for the statistics passes
-    } else {
-      epi_store_elem(d, m, n, v.x);
-      epi_store_elem(d, m, n + 1, v.y);
-      epi_store_elem(d, m, n + 2, v.z);
-      epi_store_elem(d, m, n + 3, v.w);
+      for (int j = 0; j < GRP; ++j) {
+        const int ps = g * GRP + j;
+        const bool ok = lane_ok && ps * RPC < rows_ok;
+        const int pc = ok ? ps : 0;                  // chunks past the tile re-read the lane's first chunk
+        if (HAS_RES) qr[j] = *(const float4*)(rbase + (size_t)pc * rstep);
+        if (HAS_BB) qb[j] = *(const float4*)(bbase + (size_t)((mrow0 + pc * RPC) / rpb) * ldbb);
+        qv[j] = *(const float4*)(sL + pc * (RPC * LDW));
+      }
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        const int ps = g * GRP + j;
+        float4 v = qv[j];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        if (has_bias) {
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (HAS_BB) {
+          v.x += qb[j].x; v.y += qb[j].y; v.z += qb[j].z; v.w += qb[j].w;
+        }
+        if (ACT != MVD_ACT_NONE) {
+          v.x = apply_act(v.x, ACT); v.y = apply_act(v.y, ACT); v.z = apply_act(v.z, ACT); v.w = apply_act(v.w, ACT);
+        }
+        if (has_cs) {
+          v.x *= cs.x; v.y *= cs.y; v.z *= cs.z; v.w *= cs.w;
+        }
+        if (HAS_RES) {
+          v.x += qr[j].x; v.y += qr[j].y; v.z += qr[j].z; v.w += qr[j].w;
+        }
+        if (lane_ok && ps * RPC < rows_ok) *(float4*)(sL + ps * (RPC * LDW)) = v;
+      }
+    }
+  };
+  {
+    using std::integral_constant;
+    const integral_constant<bool, true> yes{};
+    const integral_constant<bool, false> no{};
+    if (d.act == MVD_ACT_NONE) {
+      if (d.res) {
+        if (d.bias_b) pass1(integral_constant<int, MVD_ACT_NONE>{}, yes, yes);
+        else pass1(integral_constant<int, MVD_ACT_NONE>{}, yes, no);
+      } else {
+        if (d.bias_b) pass1(integral_constant<int, MVD_ACT_NONE>{}, no, yes);
+        else pass1(integral_constant<int, MVD_ACT_NONE>{}, no, no);
+      }
+    } else if (d.act == MVD_ACT_SILU) pass1(integral_constant<int, MVD_ACT_SILU>{}, yes, yes);
+    else if (d.act == MVD_ACT_GELU) pass1(integral_constant<int, MVD_ACT_GELU>{}, yes, yes);
+    else pass1(integral_constant<int, MVD_ACT_QUICKGELU>{}, yes, yes);
+  }
+  if (d.n_store & 3 || d.n_store < d.N) {      // ragged n_store edge: element by element (load, compute, store)
+    if (lane < RPC * C4 && n < d.N && n + 3 >= d.n_store) {
+#pragma unroll 1
+      for (int ps = 0; ps * RPC < rows_ok; ++ps)
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) epi_store_elem(d, mrow0 + ps * RPC, n + e, sL[ps * (RPC * LDW) + e]);
     }
   }
+  MVD_STAMP_AT(d, wave, 9);
+  if (lane_ok) {
+    float* po = d.out ? d.out + (size_t)mrow0 * d.ldo + n : nullptr;
+    u16* psp = d.out_sp ? (u16*)d.out_sp + sp_index((size_t)mrow0, d.ldp, n) : nullptr;
+    const size_t ostep = (size_t)RPC * d.ldo, sstep = (size_t)RPC * 2 * d.ldp;
+#pragma unroll 1
+    for (int p0 = 0; p0 * RPC < rows_ok; p0 += 4) {
+      float4 f[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = *(const float4*)(sL + ((p0 + j) * RPC < rows_ok ? p0 + j : 0) * (RPC * LDW));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if ((p0 + j) * RPC >= rows_ok) break;
+        if (po) {
+          *(float4*)po = f[j];
+          po += ostep;
+        }
+        if (psp) {
+          u16 h[4], l[4];
+          split_op16(f[j].x, h[0], l[0]);
+          split_op16(f[j].y, h[1], l[1]);
+          split_op16(f[j].z, h[2], l[2]);
+          split_op16(f[j].w, h[3], l[3]);
+          *(uint2*)psp = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+          *(uint2*)(psp + 32) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+          psp += sstep;
+        }
+      }
+    }
+  }
+  MVD_STAMP_AT(d, wave, 6);
+#ifdef MVD_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MVD_STAMP_AT(d, wave, 7);
   if (d.rs_out) {
     // per-row {sum, sum of squares} of the stored values over this wave tile's columns -> slot wn0 / WTN of the row (a LayerNorm folded
     // into the consumer GEMM sums the slots in order: deterministic, no atomics).  One lane per row, 16-byte LDS reads.
@@ -341,7 +488,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     const int jmax = cg < 64 ? cg : 64;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
+#pragma unroll 1
     for (int c0 = 0; c0 < WTN; c0 += 64) {
       const int col = c0 + lane, n = wn0 + col;
       const bool okc = col < WTN && n < d.n_store;
@@ -358,7 +505,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       // 16-row slabs are summed in row order first; shorter images: one pair per slab
       const bool whole = d.gn_hw % WTM == 0;
       float s1 = 0.f, q1 = 0.f;
-#pragma unroll
+#pragma unroll 1
       for (int sl = 0; sl < WTM / 16; ++sl) {
         const int ms = wm0 + sl * 16;
         if (ms >= d.M) break;
@@ -843,6 +990,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  MVD_STAMP_AT(d, wave, 0);
   int tile;
   {
     const int nb = p.tiles_n * p.tiles_m, bid = blockIdx.x;
@@ -1037,7 +1185,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
       for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(ah[i], bh[j], acc[i][j], 0, 0, 0);
   };
   op16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+  MVD_STAMP_AT(d, wave, 1);
   wait_vm_and_barrier<0>();                                           // barrier P
+  MVD_STAMP_AT(d, wave, 2);
   read_frags(0, fah[0], fal[0], fbh[0], fbl[0]);
   int br = 1 % NBUF;
   auto step = [&](auto parity, int it) {
@@ -1059,8 +1209,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
   }
   if (it < nkt) step(integral_constant<int, 0>{}, it);
   if (it + 1 < nkt) step(integral_constant<int, 1>{}, it + 1);
+  MVD_STAMP_AT(d, wave, 3);
   __syncthreads();
   tile_epilogue<BM, BN, CM, CN>(p, acc, smem, m0, n0, lane, wave, AMODE == MVD_A_DENSE && d.ln_stats != nullptr ? s_rows : nullptr);
+  MVD_STAMP_AT(d, wave, 8);
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 convolution, input patch in LDS

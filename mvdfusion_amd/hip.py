@@ -11,6 +11,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # two flavours of the same sources: fp16 MFMA operands (default) and bf16 (-DMVD_OPERAND_BF16)
 LIB_PATHS = {"f16": os.path.join(_HERE, "csrc", "libmvd_hip.so"), "bf16": os.path.join(_HERE, "csrc", "libmvd_hip_bf16.so")}
+if os.environ.get("MVD_HIP_LIB"):        # A/B measurements: another build of the same ABI (tools/probes/ab_build.sh)
+    LIB_PATHS["f16"] = os.environ["MVD_HIP_LIB"]
 LIB_PATH = LIB_PATHS["f16"]
 OPERAND_FORMAT = os.environ.get("MVD_OPERAND_FORMAT", "f16")   # chosen before the first call, fixed per process
 
