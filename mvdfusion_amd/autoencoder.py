@@ -351,6 +351,7 @@ class AutoencoderKL(nn.Module):
             ctx.gemm(mo, self._q, moments, ldo=moments.shape[1])
         finally:
             hip.AUTOTUNE = False
+            hip.release_tuning_buffers()
         self._tuned.add(("enc", B, R))
         return DiagonalGaussianDistribution(moments[:, :C2].reshape(B, H, W, C2).permute(0, 3, 1, 2).contiguous())
 
@@ -372,6 +373,7 @@ class AutoencoderKL(nn.Module):
             out, H, W = self.decoder.run(ctx, pq, B, S)
         finally:
             hip.AUTOTUNE = False
+            hip.release_tuning_buffers()
         self._tuned.add((B, S))
         return out[:, :self.decoder.out_ch].reshape(B, H, W, self.decoder.out_ch).permute(0, 3, 1, 2).contiguous()
 

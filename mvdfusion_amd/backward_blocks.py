@@ -112,8 +112,9 @@ def resblock_backward(tape, rb, x, emb, dout, B, H, W):
     g = {}
     da2, g["out_layers.3.weight"], g["out_layers.3.bias"] = tape.conv_bwd(a2, conv2.weight, dout, B, H, W)
     dh1, g["out_layers.0.weight"], g["out_layers.0.bias"] = bw.groupnorm_backward(_c(h1), _c(da2), gn2.weight, gn2.bias, B, HW, Co, gn2.eps, True)
-    da1, g["in_layers.2.weight"], _ = tape.conv_bwd(a1, conv1.weight, dh1, B, H, W)
-    db1 = bw.col_sum(_c(dh1), B * HW, Co)                                   # also the gradient of the time-embedding vector: always needed
+    da1, g["in_layers.2.weight"], db1 = tape.conv_bwd(a1, conv1.weight, dh1, B, H, W)
+    if db1 is None:                                                         # conv1 frozen: the column sum is still the gradient of the
+        db1 = bw.col_sum(_c(dh1), B * HW, Co)                               # time-embedding vector (always needed)
     g["in_layers.2.bias"] = db1
     # the time-embedding vector is added per channel to every row: its gradient is the same column sum
     g["emb_layers.1.bias"] = db1.clone()

@@ -503,6 +503,13 @@ def _flush_caches():
     _TRASH.add_(1.0)
 
 
+def release_tuning_buffers():
+    """Free the 640 MB cache-flush buffer of the cold-weight tuner (the callers that open a tuning window -- the step engine's eager
+    warm-up, the VAE's first encode / decode of a shape -- call this when they close it; the next window re-allocates it)."""
+    global _TRASH
+    _TRASH = None
+
+
 def _autotune(d, A=None, reps=4, trials=3, W_data=None):
     """Time the kernel configurations (tile x loop variant x tile order; split-K follows from the library's model)
     on the actual operands -- the op is idempotent -- and return the fastest.

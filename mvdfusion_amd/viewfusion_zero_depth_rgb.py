@@ -181,6 +181,7 @@ class StepEngine:
                 self.enqueue(cfg_scale, do_update)
             finally:
                 hip.AUTOTUNE = False
+                hip.release_tuning_buffers()
             torch.cuda.synchronize()
             self.iter.copy_(it0)
             self.x.copy_(x_keep)
