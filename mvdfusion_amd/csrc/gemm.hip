@@ -617,6 +617,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  MVD_STAMP_AT(d, wave, 0);
   // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (each XCD has a private 4 MiB L2).  Give every XCD a
   // contiguous range of output tiles in n-fastest order, so the n-tiles that re-read one A row panel (and the
   // neighbouring m-tiles that share the conv halo) hit the same L2 instead of 8 different ones.
@@ -852,8 +853,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       }
     }
     ln_gather_rows();
+    MVD_STAMP_AT(d, wave, 1);
     if (nkt >= LEAD) wait_vm_and_barrier<(LEAD - 1) * LPS>();
     else wait_vm_and_barrier<0>();
+    MVD_STAMP_AT(d, wave, 2);
     for (int ph = 0; ph <= 2 * nkt; ++ph) {
       const int u = ph - grp;
       if (u >= 0 && u < 2 * nkt) {
@@ -892,8 +895,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       }
     }
     ln_gather_rows();
+    MVD_STAMP_AT(d, wave, 1);
     if (nkt >= NBUF) wait_vm_and_barrier<(NBUF - 1) * LPS>();   // k-tile 0 landed, the newer ones stay in flight
     else wait_vm_and_barrier<0>();
+    MVD_STAMP_AT(d, wave, 2);
     read_frags(0, fah[0], fal[0], fbh[0], fbl[0]);
     int bs = 0, br = NBUF > 1 ? 1 : 0;              // buffer staged next (= it % NBUF), buffer read next (= (it + 1) % NBUF)
     auto step = [&](auto parity, auto steady, int it) {
@@ -950,7 +955,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   }
 
   // ---- epilogue (the final barrier above guarantees nobody still reads the stage buffers; each wave owns a private region)
+  MVD_STAMP_AT(d, wave, 3);
   tile_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, lane, wave, AMODE == MVD_A_DENSE && d.ln_stats != nullptr ? s_rows : nullptr);
+  MVD_STAMP_AT(d, wave, 8);
 }
 
 // ------------------------------------------------------------------------------------------------ wave-specialised GEMM
