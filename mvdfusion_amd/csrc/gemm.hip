@@ -266,6 +266,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       if (d.out) *(float4*)(d.out + (size_t)m * d.ldo + col) = v;
       if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, col, v.x, v.y, v.z, v.w);
     }
+    MVD_STAMP_AT(d, wave, 9);
+    MVD_STAMP_AT(d, wave, 6);
+    MVD_STAMP_AT(d, wave, 7);
     return;
   }
   if (d.epi == MVD_EPI_QKV) {     // a 32-column aligned wave tile lies inside one of q / k / v
@@ -939,7 +942,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     stage(0);
     advance_tap();
     ln_gather_rows();
+    MVD_STAMP_AT(d, wave, 1);
     wait_vm_and_barrier<0>();
+    MVD_STAMP_AT(d, wave, 2);
     int buf = 0;
     for (int it = 0; it < nkt; ++it) {
       if (it + 1 < nkt) {
