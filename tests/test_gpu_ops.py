@@ -146,6 +146,61 @@ def test_gemm_epilogues(hip):
     assert rel_err(out, F.linear(A, W, b) + bb.repeat_interleave(M // 4, 0)) < TOL[4]
 
 
+# one configuration per tile shape (+ the role-split kernel): the tile epilogue is shared code, its chunk mapping depends on the wave tile
+_EPI_CFGS = [_hip.make_cfg(0, 4), _hip.make_cfg(1, 0), _hip.make_cfg(1, 2), _hip.make_cfg(2, 4), _hip.make_cfg(3, 4), _hip.make_cfg(4, 4),
+             _hip.make_cfg(2, _hip.WS_LOOP), _hip.make_cfg(4, _hip.WS_LOOP)]
+
+
+@pytest.mark.parametrize("cfg", _EPI_CFGS)
+@pytest.mark.parametrize("M,N", [(200, 328), (300, 50), (96, 320), (37, 4)])
+def test_gemm_store_epilogue_matrix(hip, cfg, M, N):
+    """Every option of the store epilogue (bias, per-view bias, activation, column scale, residual, fp32 and / or planes output) on ragged
+    shapes: rows that end inside a wave tile, a column count that is not a multiple of 4 / 16 / the tile width (element path),
+    per-view bias with FEWER rows per view than a wave tile -- for every wave-tile geometry."""
+    K = 96
+    A = torch.randn(M, K, generator=g(11))
+    W = torch.randn(N, K, generator=g(12)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(13))
+    R = torch.randn(M, N, generator=g(14))
+    gate = torch.randn(N, generator=g(15))
+    rpb = 8
+    nb = (M + rpb - 1) // rpb
+    bb = torch.randn(nb, N, generator=g(16))
+    bbr = bb.repeat_interleave(rpb, 0)[:M]
+    Ap = hip.split_planes(A.cuda())
+    ws = torch.empty(4 * 1024 * 1024, device="cuda")
+    Wb, W0 = hip.pack_linear(W.cuda(), b.cuda()), hip.pack_linear(W.cuda())
+    lin, lin0 = F.linear(A, W, b), F.linear(A, W)
+    Np = (N + 3) // 4 * 4                      # row pitch of fp32 outputs / residuals: a multiple of 4 (16-byte rows)
+    out = torch.empty(M, Np, device="cuda")
+    Rc = torch.zeros(M, Np, device="cuda")
+    Rc[:, :N] = R.cuda()
+    bbc = torch.zeros(nb, Np, device="cuda")
+    bbc[:, :N] = bb.cuda()
+    cases = [
+        (dict(res=Rc), Wb, lin + R),
+        (dict(), W0, lin0),
+        (dict(bias_b=bbc, rows_per_batch=rpb), Wb, lin + bbr),
+        (dict(bias_b=bbc, rows_per_batch=rpb, res=Rc, colscale=gate.cuda(), act=hip.ACT_QUICKGELU), Wb,
+         R + gate * ((lin + bbr) * torch.sigmoid(1.702 * (lin + bbr)))),
+        (dict(act=hip.ACT_SILU, colscale=gate.cuda()), Wb, gate * F.silu(lin)),
+        (dict(act=hip.ACT_GELU, res=Rc), Wb, R + F.gelu(lin)),
+    ]
+    for kw, Wp, ref in cases:
+        out.fill_(-7.0)
+        hip.gemm(Ap, Wp, out, workspace=ws, cfg=cfg, splitk=1, **kw)
+        assert rel_err(out[:, :N], ref) < TOL[4], (cfg, sorted(kw))
+        assert bool((out[:, N:] == -7.0).all()), "columns past N must not be written"
+    if N % 32 == 0:      # planes output next to / instead of the fp32 output
+        op = hip.planes_like(M, N, "cuda")
+        out.fill_(-7.0)
+        hip.gemm(Ap, Wb, out, workspace=ws, cfg=cfg, splitk=1, res=Rc, out_planes=op)
+        assert rel_err(out, lin + R) < TOL[4] and rel_err(planes_to_float(op), lin + R) < TOL[4] + PL
+        op2 = hip.planes_like(M, N, "cuda")
+        hip.gemm(Ap, Wb, None, workspace=ws, cfg=cfg, splitk=1, bias_b=bbc, rows_per_batch=rpb, out_planes=op2)
+        assert rel_err(planes_to_float(op2), lin + bbr) < TOL[4] + PL
+
+
 @pytest.mark.parametrize("splitk", [0, 1, 3])
 def test_gemm_geglu(hip, splitk):
     M, C = 256, 64
