@@ -212,6 +212,74 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(const float* __rest
   }
 }
 
+// The same apply for SMALL tensors (fewer than 2 M elements: the 16 x 16 / 8 x 8 / 4 x 4 levels).  A thread keeps ONE 16-byte column (TX = the
+// largest divisor of C / 4 that fits the block, TY = 256 / TX rows per pass, column slabs in grid.z) and derives the coefficients of its four
+// channels itself (fp64 mean / rstd of its one or two groups): no LDS tables, no barriers, no division in the loop, and the tensor spreads over
+// 128 - 512 blocks instead of the 16 - 64 of the row-chunk kernel, whose per-block prologue (tables for ALL channels behind two barriers) took
+// longer than the data: 8 x 4x4 x 2560: 10.5 -> 3.5 us, 8 x 8x8 x 1280: 6.7 -> 3.7 us, 8 x 16x16 x 640: 5.2 -> 4.8 us; the 32 x 32 level stays on the
+// row-chunk kernel (6.3 vs 6.9 us) -- profiles/r03_gn_apply_time.log.  Same arithmetic per element => identical results.
+__global__ __launch_bounds__(256) void gn_apply_stats_cols_kernel(const float* __restrict__ x, u16* __restrict__ y_sp,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const long long* __restrict__ stats, int HW, int C, int groups, int rows_per_block,
+                                                             int TX, float eps, int silu) {
+  const int b = blockIdx.y;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+  if (ty >= TY) return;
+  const int C4 = C >> 2, cg = C / groups;
+  const int col4 = blockIdx.z * TX + tx, c = col4 * 4;
+  const int r_end = min(HW, ((int)blockIdx.x + 1) * rows_per_block);
+  int r = blockIdx.x * rows_per_block + ty;
+  const float4* xp = (const float4*)x + ((size_t)b * HW + r) * C4 + col4;
+  const size_t xstep = (size_t)TY * C4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < r_end) v = *xp;                                  // in flight under the coefficient arithmetic below
+  const float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
+  float a[4], bb[4];
+  const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+  int gprev = -1;
+  float mk = 0.f, rk = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = (c + k) / cg;
+    if (g != gprev) {                                      // (a column's four channels lie in one or two groups unless the groups are narrower than 4)
+      const long long* p = stats + ((size_t)b * groups + g) * 2;
+      const double inv = 1.0 / (double)MVD_GN_FIXED_SCALE;
+      const double n = (double)HW * cg;
+      const double m = (double)p[0] * inv / n;
+      double var = (double)p[1] * inv / n - m * m;
+      if (var < 0.0) var = 0.0;
+      mk = (float)m;
+      rk = (float)(1.0 / sqrt(var + (double)eps));
+      gprev = g;
+    }
+    a[k] = rk * gmv[k];
+    bb[k] = btv[k] - mk * a[k];
+  }
+  for (; r < r_end; r += TY) {
+    float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r + TY < r_end) vn = *(xp + xstep);
+    xp += xstep;
+    v.x = v.x * a[0] + bb[0];
+    v.y = v.y * a[1] + bb[1];
+    v.z = v.z * a[2] + bb[2];
+    v.w = v.w * a[3] + bb[3];
+    if (silu & 2) {
+      v.x = (float)(_Float16)v.x;
+      v.y = (float)(_Float16)v.y;
+      v.z = (float)(_Float16)v.z;
+      v.w = (float)(_Float16)v.w;
+    }
+    if (silu & 1) {
+      v.x = silu_f(v.x);
+      v.y = silu_f(v.y);
+      v.z = silu_f(v.z);
+      v.w = silu_f(v.w);
+    }
+    store_sp4(y_sp, (size_t)b * HW + r, C, c, v.x, v.y, v.z, v.w);
+    v = vn;
+  }
+}
+
 // Row softmax of a (rows, cols) fp32 logit matrix, scaled first; probabilities written as split planes (the A operand of
 // the P*V GEMM).  One wave per row, cols <= 4096 held in registers (the VAE AttnBlock has one head over h*w <= 4096 keys).
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, u16* __restrict__ y_sp, int rows, int cols,
@@ -348,9 +416,19 @@ extern "C" int mvd_groupnorm_from_stats(const float* x, void* y_sp, const float*
   MVD_CHECK_ARG(x && y_sp && gamma && beta && stats, "mvd_groupnorm_from_stats: null pointer");
   MVD_CHECK_ARG(C % 32 == 0 && B > 0 && HW > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C <= GN_MAX_C,
                 "mvd_groupnorm_from_stats: bad shape (C=%d groups=%d)", C, groups);
-  const int chunks = gn_chunks(HW);
-  hipLaunchKernelGGL(gn_apply_stats_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, x, (u16*)y_sp, gamma, beta, stats, HW, C,
-                     groups, chunks, eps, silu);
+  if ((size_t)B * HW * C < ((size_t)2 << 20)) {
+    const int C4 = C / 4;
+    int TX = C4 < 256 ? C4 : 256;
+    while (C4 % TX) --TX;                                  // largest divisor of C / 4 that fits a 256-thread block
+    const int TY = 256 / TX;
+    const int rows_per_block = TY * 4;                     // <= 4 rows per thread
+    hipLaunchKernelGGL(gn_apply_stats_cols_kernel, dim3(cdiv(HW, rows_per_block), B, C4 / TX), dim3(256), 0, (hipStream_t)stream, x,
+                       (u16*)y_sp, gamma, beta, stats, HW, C, groups, rows_per_block, TX, eps, silu);
+  } else {
+    const int chunks = gn_chunks(HW);
+    hipLaunchKernelGGL(gn_apply_stats_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, x, (u16*)y_sp, gamma, beta, stats, HW, C,
+                       groups, chunks, eps, silu);
+  }
   MVD_CHECK_LAUNCH("mvd_groupnorm_from_stats");
   return 0;
 }
