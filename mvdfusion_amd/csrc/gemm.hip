@@ -110,7 +110,9 @@ __device__ __forceinline__ void epi_geglu_elem(const mvd_gemm_desc& d, int m, in
 }
 
 // four consecutive columns n..n+3 of row m (all inside N): coalesced 16-byte traffic; returns the final values
-__device__ __forceinline__ float4 epi_store4(const mvd_gemm_desc& d, int m, int n, float4 v) {
+// (epi_value4: operands + arithmetic, epi_put4: the stores -- callers with several rows per thread run all the values before the first store:
+//  a load behind a conditional store waits for its acknowledgement)
+__device__ __forceinline__ float4 epi_value4(const mvd_gemm_desc& d, int m, int n, float4 v) {
   v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
   if (d.bias) {
     const float4 b = *(const float4*)(d.bias + n);
@@ -131,8 +133,15 @@ __device__ __forceinline__ float4 epi_store4(const mvd_gemm_desc& d, int m, int 
     const float4 r = *(const float4*)(d.res + (size_t)m * d.ldr + n);
     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
   }
+  return v;
+}
+__device__ __forceinline__ void epi_put4(const mvd_gemm_desc& d, int m, int n, const float4& v) {
   if (d.out) *(float4*)(d.out + (size_t)m * d.ldo + n) = v;
   if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, n, v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 epi_store4(const mvd_gemm_desc& d, int m, int n, float4 v) {
+  v = epi_value4(d, m, n, v);
+  epi_put4(d, m, n, v);
   return v;
 }
 
@@ -1562,8 +1571,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmParams p) 
       }
     }
 #pragma unroll
+    for (int r = 0; r < RPT; ++r) v[r] = epi_value4(d, m0 + rg * RPT + r, n, v[r]);
+#pragma unroll
     for (int r = 0; r < RPT; ++r) {
-      const float4 f = epi_store4(d, m0 + rg * RPT + r, n, v[r]);
+      const float4 f = v[r];
+      epi_put4(d, m0 + rg * RPT + r, n, f);
       s.x += f.x; s.y += f.y; s.z += f.z; s.w += f.w;
       q.x += f.x * f.x; q.y += f.y * f.y; q.z += f.z * f.z; q.w += f.w * f.w;
     }
