@@ -1,6 +1,7 @@
 // GroupNorm (channels-last, optional fused SiLU) and LayerNorm.  HBM/L2-bound kernels: every access is a
 // full-row coalesced float4 stream; statistics are accumulated in fp32 per thread over a few rows and combined
 // in fp64 in a fixed order (deterministic, no atomics).
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/mvd_hip.h"
 
@@ -212,12 +213,13 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(const float* __rest
   }
 }
 
-// The same apply for SMALL tensors (fewer than 2 M elements: the 16 x 16 / 8 x 8 / 4 x 4 levels).  A thread keeps ONE 16-byte column (TX = the
+// The same apply, the default: a thread keeps ONE 16-byte column (TX = the
 // largest divisor of C / 4 that fits the block, TY = 256 / TX rows per pass, column slabs in grid.z) and derives the coefficients of its four
 // channels itself (fp64 mean / rstd of its one or two groups): no LDS tables, no barriers, no division in the loop, and the tensor spreads over
 // 128 - 512 blocks instead of the 16 - 64 of the row-chunk kernel, whose per-block prologue (tables for ALL channels behind two barriers) took
-// longer than the data: 8 x 4x4 x 2560: 10.5 -> 3.5 us, 8 x 8x8 x 1280: 6.7 -> 3.7 us, 8 x 16x16 x 640: 5.2 -> 4.8 us; the 32 x 32 level stays on the
-// row-chunk kernel (6.3 vs 6.9 us) -- profiles/r03_gn_apply_time.log.  Same arithmetic per element => identical results.
+// longer than the data: 8 x 4x4 x 2560: 10.5 -> 3.4 us, 8 x 8x8 x 2560: 11.0 -> 4.6, 8 x 16x16 x 1920: 10.9 -> 7.7, 8 x 32x32 x 960: 13.8 -> 13.6; only
+// 320-channel tensors of 32 x 32 and larger images stay on the row-chunk kernel (6.3 vs 6.8 us) -- profiles/r03_gn_apply_time.log.  Same
+// arithmetic per element => identical results.
 __global__ __launch_bounds__(256) void gn_apply_stats_cols_kernel(const float* __restrict__ x, u16* __restrict__ y_sp,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const long long* __restrict__ stats, int HW, int C, int groups, int rows_per_block,
@@ -416,7 +418,9 @@ extern "C" int mvd_groupnorm_from_stats(const float* x, void* y_sp, const float*
   MVD_CHECK_ARG(x && y_sp && gamma && beta && stats, "mvd_groupnorm_from_stats: null pointer");
   MVD_CHECK_ARG(C % 32 == 0 && B > 0 && HW > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C <= GN_MAX_C,
                 "mvd_groupnorm_from_stats: bad shape (C=%d groups=%d)", C, groups);
-  if ((size_t)B * HW * C < ((size_t)2 << 20)) {
+  // the column-per-thread kernel everywhere except the widest-and-thinnest tensors (32 x 32 and larger images with <= 320 channels: 80
+  // columns leave 16 of 256 threads idle and the row-chunk kernel is 3 - 8 % faster there; profiles/r03_gn_apply_time.log)
+  if (!(C <= 320 && HW >= 1024)) {
     const int C4 = C / 4;
     int TX = C4 < 256 ? C4 : 256;
     while (C4 % TX) --TX;                                  // largest divisor of C / 4 that fits a 256-thread block

@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 import torch
 from mvdfusion_amd import hip
 
-for (B, HW, C) in ((8, 1024, 320), (8, 1024, 960), (8, 256, 640), (8, 64, 1280), (8, 16, 2560)):
+for (B, HW, C) in ((8, 1024, 320), (8, 1024, 640), (8, 1024, 960), (8, 256, 640), (8, 256, 1280), (8, 256, 1920), (8, 64, 1280), (8, 64, 2560), (8, 16, 2560),
+                   (16, 1024, 320), (16, 1024, 960), (16, 4096, 320)):
     x = torch.randn(B * HW, C, device="cuda")
     y = hip.planes_like(B * HW, C, "cuda")
     gamma, beta = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
