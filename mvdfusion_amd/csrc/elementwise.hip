@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void area_pool_kernel(const float4* __restrict
     const int b = (int)(r / So);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int dy = 0; dy < f; ++dy)
-      for (int dx = 0; dx < f; ++dx) {
+#pragma unroll 8
+      for (int dx = 0; dx < f; ++dx) {      // (unrolled: the window's loads of a row go out together; the additions keep their order)
         const float4 v = vol[((((size_t)b * S + oy * f + dy) * S + ox * f + dx) * D + d) * C4 + c];
         acc.x += v.x;
         acc.y += v.y;
