@@ -215,7 +215,7 @@ def _pack_scale(w):
     """Power of two that brings max|w| to [1024, 2048): the low half of the fp16 split then stays a normal number for
     every weight within 2^-13 of the largest one (exact to undo: the GEMM multiplies its accumulator by 1/scale)."""
     import math
-    mx = float(w.abs().max())
+    mx = float(torch.linalg.vector_norm(w.reshape(-1), ord=float("inf")))      # max|w| in ONE reduction (abs().max() is two kernels and a temporary)
     if not (mx > 0.0) or not math.isfinite(mx):
         return 1.0
     return 2.0 ** (10 - math.floor(math.log2(mx)))
