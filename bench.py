@@ -28,7 +28,6 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_16BIT_DENSE_PEAK = 2.5e15  # FLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (dense; not the 2:1-sparse figure)
 HBM_PEAK = 8.0e12               # B/s (spec; ~6.3 TB/s achievable), same guide
@@ -40,15 +39,17 @@ def log(*a):
 
 
 def build(V, S, D, precision, sd=None):
-    from conftest import load_spec, model_config
     from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.configs import model_config
     from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
     t0 = time.time()
-    if sd is None:
-        sd = syn.det_fill_state_dict(load_spec(320))
     m = ViewFusion(**model_config(320, D=D, S=S, precision=precision))
-    missing, unexpected = m.load_state_dict(sd, strict=False)
-    assert not unexpected and all(k.startswith("scheduler.") for k in missing), (missing[:5], unexpected[:5])
+    if sd is None:      # deterministic non-zero fill keyed by the parameter names (the reference zero-inits every residual branch: SURVEY T1)
+        syn.fill_module_(m)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.startswith("scheduler.")}
+    else:
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.startswith("scheduler.") for k in missing), (missing[:5], unexpected[:5])
     m = m.cuda().eval()
     log(f"[bench] model built in {time.time() - t0:.1f}s")
     return m, sd

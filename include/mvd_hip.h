@@ -297,8 +297,9 @@ int mvd_gridattn_tokens(const float* x, const float* depth_noise, const float* s
                         mvd_stream_t stream);
 /* Fused G1-G4 (:269-397): tokens are generated in registers and pushed through pre_layer_b, the 3 DiTBlocks over the V views,
  * and the weight_layer softmax pooling in ONE launch; output = the pooled (Vq*S*S*D, 256) rows as split planes (the final
- * Linear 256->768 is a plain mvd_gemm).  V must divide 16 (1, 2, 4, 8, 16: a wavefront owns 16 token rows = 16/V points);
- * other view counts use the unfused kernels above / below.
+ * Linear 256->768 is a plain mvd_gemm).  1 <= V <= 16: a wavefront owns 16 token rows = 16 / Vp points, Vp = the next power of
+ * two >= V; the Vp - V padding slots of a point are masked as attention keys and in the pooling (the reference ships V = 15, 7, 5:
+ * configs/mvd_gso.yaml:97, mvd_train.yaml:90,97); Vq*S*S*D*Vp must be a multiple of 64.  V > 16: the unfused kernels above / below.
  *   wstream : the aggregation weights as fp16 (bf16) hi + lo in the kernel's consumption order, mvd_gridattn_fused_slots()
  *             slots of 32 KiB (layout: csrc/gridattn_fused.hip header; packer: mvdfusion_amd/view_attn_efficient2.py)
  *   vecs    : mvd_gridattn_fused_vec_floats() floats -- per DiT block [adaLN modulation of this step 1536 | b_qkv 768 |

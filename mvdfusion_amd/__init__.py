@@ -5,3 +5,5 @@ hand-written HIP kernels behind the C ABI declared in ``include/mvd_hip.h`` (``m
 Importing the package never needs a GPU; calling any op without the built library raises loudly.
 """
 __version__ = "0.1.0"
+
+from .configs import install_aliases, model_config  # noqa: E402,F401

@@ -130,14 +130,14 @@ class _TransformerCore(nn.Module):
         qkv = dict(planes=planes, heads=self.n_heads, dhead=self.d_head, L=L)
         if t_planes is not None:
             fold = self.attn1.packed_qkv_ln(self.norm1)
-            ctx.gemm(t_planes, fold.w, None, epi=hip.EPI_QKV, qkv=qkv, ln=(t_stats, fold))
+            ctx.gemm(t_planes, fold.w, None, epi=hip.EPI_QKV, qkv=qkv, ln=(t_stats, fold), kind="qkv")
         else:
             ln = ctx.ws.planes(tag + ".ln", M, C)
             ctx.layernorm(t, ln, self.norm1, M, C)
-            ctx.gemm(ln, self.attn1.packed("qkv"), None, epi=hip.EPI_QKV, qkv=qkv)
+            ctx.gemm(ln, self.attn1.packed("qkv"), None, epi=hip.EPI_QKV, qkv=qkv, kind="qkv")
         if o is None:
             o = ctx.ws.planes(tag + ".o", M, C)
-        hip.attention(planes, o, B, self.n_heads, L, self.d_head, prec=ctx.prec)
+        hip.attention(planes, o, B, self.n_heads, L, self.d_head, prec=ctx.prec_of("attn"))
         return o
 
     def cat5(self, ctx, M, tag):
@@ -150,12 +150,12 @@ class _TransformerCore(nn.Module):
         C = self.dim
         if t2_stats is not None:
             fold = self.ff.packed_geglu_ln(self.norm3)
-            ctx.gemm(cat5[:, 2 * 4 * C:], fold.w, None, M=M, lda=5 * C, epi=hip.EPI_GEGLU, out_planes=cat5, ln=(t2_stats, fold))
+            ctx.gemm(cat5[:, 2 * 4 * C:], fold.w, None, M=M, lda=5 * C, epi=hip.EPI_GEGLU, out_planes=cat5, ln=(t2_stats, fold), kind="geglu")
         else:
             ln = ctx.ws.planes(tag + ".ln", M, C)
             ctx.layernorm(t2, ln, self.norm3, M, C)
-            ctx.gemm(ln, self.ff.packed_geglu(), None, epi=hip.EPI_GEGLU, out_planes=cat5)      # columns [0, 4C)
-        ctx.gemm(cat5, w_merged, out, res=x, gn=gn)
+            ctx.gemm(ln, self.ff.packed_geglu(), None, epi=hip.EPI_GEGLU, out_planes=cat5, kind="geglu")      # columns [0, 4C)
+        ctx.gemm(cat5, w_merged, out, res=x, gn=gn, kind="ffproj")
         return out
 
 
@@ -197,7 +197,7 @@ class SpatialTransformer(nn.Module):
         t = ctx.ws.get("tf.t", (M, C))
         fold = ctx.ln_fold
         tp, rs1, rs2 = (ctx.ws.planes("tf.tp", M, C), ctx.row_stats("tf.rs1", M, C), ctx.row_stats("tf.rs2", M, C)) if fold else (None,) * 3
-        ctx.gemm(n, w_in, t, out_planes=tp, row_stats=rs1)
+        ctx.gemm(n, w_in, t, out_planes=tp, row_stats=rs1, kind="proj")
         o = tb.self_attn(ctx, t, B, L, "tf", t_planes=tp, t_stats=rs1)
         # attn2 on the length-1 CLIP context: per-view vector to_out(to_v(ctx_b)), broadcast over the pixels
         a2 = tb.attn2
@@ -211,7 +211,7 @@ class SpatialTransformer(nn.Module):
             ctx.gemv_rows(a2.to_out[0].weight, a2.to_out[0].bias, v1, vec)
         t2 = ctx.ws.get("tf.t2", (M, C))
         cat5 = tb.cat5(ctx, M, "tf")
-        ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2)
+        ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2, kind="out")
         if out is None:
             out = ctx.act((M, C))
         return tb.feed_forward_proj(ctx, t2, cat5, w_ffproj, x, out, M, "tf", gn=(B, L), t2_stats=rs2)
@@ -263,29 +263,29 @@ class ViewAlignedFeatureTransformer(nn.Module):
         t = ctx.ws.get("tf.t", (M, C))
         fold = ctx.ln_fold
         tp, rs1, rs2 = (ctx.ws.planes("tf.tp", M, C), ctx.row_stats("tf.rs1", M, C), ctx.row_stats("tf.rs2", M, C)) if fold else (None,) * 3
-        ctx.gemm(n, w_in, t, out_planes=tp, row_stats=rs1)
+        ctx.gemm(n, w_in, t, out_planes=tp, row_stats=rs1, kind="proj")
         t2b = ctx.ws.get("tf.t2b", (M, C))
         cat5 = tb.cat5(ctx, M, "tf")
         if D == 1:
             assert vol_col == C and vol.shape[-1] == 2 * (C + 768), (vol_col, C, vol.shape)
             tb.self_attn(ctx, t, B, L, "tf", o=vol, t_planes=tp, t_stats=rs1)            # o -> columns [0, C) of the [o | vol] operand
-            ctx.gemm(vol, self.packed_ovol(), t2b, res=t, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2)
+            ctx.gemm(vol, self.packed_ovol(), t2b, res=t, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2, kind="out")
         else:
             o = tb.self_attn(ctx, t, B, L, "tf", t_planes=tp, t_stats=rs1)
             t2 = ctx.ws.get("tf.t2", (M, C))
-            ctx.gemm(o, tb.attn1.packed("out"), t2, res=t)
+            ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, kind="out")
             a2 = tb.attn2.packed
             ln2 = ctx.ws.planes("tf.ln", M, C)
             ctx.layernorm(t2, ln2, tb.norm2, M, C)
             q = ctx.ws.get("tf.q2", (M, C))
-            ctx.gemm(ln2, a2("q"), q)
+            ctx.gemm(ln2, a2("q"), q, kind="xattn")
             k = ctx.ws.get("tf.k2", (M * D, C))
             v = ctx.ws.get("tf.v2", (M * D, C))
-            ctx.gemm(vol, a2("k"), k)
-            ctx.gemm(vol, a2("v"), v)
+            ctx.gemm(vol, a2("k"), k, kind="xattn")
+            ctx.gemm(vol, a2("v"), v, kind="xattn")
             o2 = ctx.ws.planes("tf.o2", M, C)
             hip.check(hip.lib().mvd_pixel_cross_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o2), M, D, tb.n_heads, tb.d_head, hip.stream()))
-            ctx.gemm(o2, a2("out"), t2b, res=t2, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2)
+            ctx.gemm(o2, a2("out"), t2b, res=t2, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2, kind="xattn")
         if out is None:
             out = ctx.act((M, C))
         return tb.feed_forward_proj(ctx, t2b, cat5, w_ffproj, x, out, M, "tf", gn=(B, L), t2_stats=rs2)

@@ -308,7 +308,7 @@ class AutoencoderKL(nn.Module):
         self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         hip.set_operand_format("bf16" if precision.startswith("bf16") else "f16")
-        self.precision = {"x3": hip.PREC_X3, "x4": hip.PREC_X4}.get(precision[-2:], hip.PREC_X1)
+        self.precision = hip.parse_precision(precision)[1]
         self._ctx, self._pq, self._q, self._tuned, self._packed_sig = None, None, None, set(), None
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)

@@ -1,0 +1,97 @@
+"""Model configuration of the reference's yaml files as plain dicts, and the zero-edit drop-in switch.
+
+``model_config`` is the ``model.params`` block of ``configs/mvd_gso.yaml:3-74`` (the part the hot path reads) with the
+widths / latent side / depth samples the benches and tests vary.
+
+``install_aliases()`` registers this package's modules under the reference's dotted names in ``sys.modules`` --
+``mvdfusion.viewfusion_zero_depth_rgb``, ``mvdfusion.unet``, ``utils.load_model``, ``external.sd1.ldm.models.autoencoder`` ... --
+so that the reference's drivers (``demo.py:21``: ``from utils.load_model import instantiate_from_config``; the yaml
+``target:`` strings resolved by ``importlib.import_module``, ``utils/load_model.py:10-25``) run UNCHANGED on the HIP path:
+
+    import mvdfusion_amd; mvdfusion_amd.install_aliases()      # e.g. from sitecustomize.py, or `python -m mvdfusion_amd.run demo.py ...`
+    # ... demo.py / train.py exactly as shipped
+
+No reference file is copied: the aliases point at this package's own mirrors.
+"""
+import importlib
+import importlib.machinery
+import importlib.util
+import sys
+import types
+
+UNET_PARAMS = dict(image_size=32, in_channels=10, out_channels=5, model_channels=320, attention_resolutions=[4, 2, 1],
+                   num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                   use_view_aligned_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=True,
+                   legacy=False)
+
+DEFAULT_PRECISION = "f16x4"
+
+
+def model_config(mc=320, D=1, S=32, precision=None, **overrides):
+    """The `params:` block of configs/mvd_gso.yaml (model part) as a dict; mc = model_channels, D = n_pts_per_ray, S = latent side."""
+    up = dict(UNET_PARAMS)
+    up["model_channels"] = mc
+    up["image_size"] = S
+    cfg = dict(
+        view_attn_config=dict(target="mvdfusion.view_attn_efficient2.GridAttn",
+                              params=dict(in_channels=5, input_size=S, output_dim=768, num_layers=3,
+                                          z_near_far_scale=0.8, n_pts_per_ray=D)),
+        unet_config=dict(target="mvdfusion.unet.UNetModel", params=up),
+        ddpm_config=dict(target="mvdfusion.scheduler.DDPMScheduler", params=dict(timesteps=1000)),
+        vae_path=None, unet_path=None, z_scale_factor=0.18215, objective="noise", loss_type="l2",
+        embed_camera_pose=True, finetune_projection=True, finetune_unet=False, finetune_cross_attn=True,
+        finteune_view_attn=True, drop_conditions=True, precision=precision or DEFAULT_PRECISION)
+    cfg.update(overrides)
+    return cfg
+
+
+def state_dict_spec(model):
+    """[(state_dict key, shape)] of a module -- what synthetic.det_fill_state_dict needs to build the deterministic non-zero fill."""
+    return [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+
+
+# reference module path -> module of this package that mirrors it (same class names inside)
+ALIASES = {
+    "mvdfusion.viewfusion_zero_depth_rgb": "mvdfusion_amd.viewfusion_zero_depth_rgb",
+    "mvdfusion.view_attn_efficient2": "mvdfusion_amd.view_attn_efficient2",
+    "mvdfusion.unet": "mvdfusion_amd.unet",
+    "mvdfusion.attention": "mvdfusion_amd.attention",
+    "mvdfusion.scheduler": "mvdfusion_amd.scheduler",
+    "mvdfusion.sampler": "mvdfusion_amd.sampler",
+    "utils.load_model": "mvdfusion_amd.load_model",
+    "external.sd1.ldm.models.autoencoder": "mvdfusion_amd.autoencoder",
+    "external.sd1.ldm.modules.encoders.modules": "mvdfusion_amd.encoders",
+}
+_PARENTS = ("mvdfusion", "utils", "external", "external.sd1", "external.sd1.ldm", "external.sd1.ldm.models",
+            "external.sd1.ldm.modules", "external.sd1.ldm.modules.encoders")
+
+
+def install_aliases(force=False):
+    """Register the mirrors under the reference's dotted module names (see the module docstring).  Packages of the reference that are
+    importable already (the reference checkout on sys.path) are left alone unless `force`: only the listed leaf modules are replaced,
+    so `utils.vis_utils`, the datasets etc. of a reference checkout keep working next to the aliased hot path.  Returns the names set."""
+    done = []
+    for name in _PARENTS:
+        if name in sys.modules:
+            continue
+        try:
+            if importlib.util.find_spec(name) is not None:      # a real package of that name is importable: keep it
+                importlib.import_module(name)
+                continue
+        except (ImportError, ValueError, AttributeError):
+            pass
+        pkg = types.ModuleType(name)
+        pkg.__path__ = []                                        # a namespace-like package: submodules come from sys.modules
+        pkg.__spec__ = importlib.machinery.ModuleSpec(name, loader=None, is_package=True)
+        sys.modules[name] = pkg
+        done.append(name)
+    for ref, mine in ALIASES.items():
+        if ref in sys.modules and not force and getattr(sys.modules[ref], "__name__", "") == mine:
+            continue
+        mod = importlib.import_module(mine)
+        sys.modules[ref] = mod
+        parent, _, leaf = ref.rpartition(".")
+        if parent in sys.modules:
+            setattr(sys.modules[parent], leaf, mod)
+        done.append(ref)
+    return done

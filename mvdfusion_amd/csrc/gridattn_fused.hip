@@ -5,8 +5,11 @@
 //          MLP 256->512->256, gated residuals), weight_layer softmax over V, weighted sum
 // and writes the pooled (Nseq, 256) rows as split planes for the last Linear 256->768 (a plain mvd_gemm).
 //
-// Mapping.  Token rows are ordered ((query view, pixel, depth sample), reference view): V consecutive rows = one 3-D point =
-// one attention sequence.  A wavefront owns 16 consecutive rows for the whole kernel; a workgroup is 4 wavefronts (64 rows).
+// Mapping.  Token rows are ordered ((query view, pixel, depth sample), reference view slot): Vp consecutive rows = one 3-D point =
+// one attention sequence, Vp = the next power of two >= V (so a sequence never straddles a wavefront's 16 rows).  Slots vr >= V are
+// PADDING: they run the arithmetic on a copy of the last reference view (finite values), are masked out as attention KEYS and in the
+// softmax-over-V pooling, and are never stored -- the reference's view counts 15 / 7 / 5 / 3 (configs/mvd_gso.yaml:97, mvd_train.yaml:90,97)
+// take this kernel at 16 / 8 / 8 / 4 slots.  A wavefront owns 16 consecutive rows for the whole kernel; a workgroup is 4 wavefronts (64 rows).
 // Activations never touch LDS or HBM: every GEMM is computed as  out^T = W x^T  (MFMA A operand = 16 weight rows, B operand =
 // the wave's 16 activation rows), so a lane holds, for row (lane & 15), four consecutive output channels 16j + 4(lane>>4) + r
 // of each 16-channel tile j -- exactly the register image of the NEXT GEMM's B fragment once the weight k-order inside
@@ -38,7 +41,7 @@ struct G4Params {
   const unsigned char* wstream;   // nslots x 32 KiB
   const float* vecs;              // G4_VEC_GRANULES * 256 floats
   u16* pooled_sp;                 // (Nseq, 256) split planes
-  int V, q0, Vq, S, D, nslots;
+  int V, Vp, lv, q0, Vq, S, D, nslots;      // Vp = 2^lv >= V: rows per 3-D point (reference views padded to a power of two)
   float depth_scale, depth_shift;
 };
 
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
   const float* svec = (const float*)(smem + G4_RING_SLOTS * G4_SLOT_BYTES);
-  const int V = p.V, S = p.S, D = p.D, SS = S * S;
+  const int V = p.V, Vp = p.Vp, lv = p.lv, S = p.S, D = p.D, SS = S * S;
 
   // ------------------------------------------------------------------ LDS-DMA engine
   const unsigned char* wsrc = p.wstream + (size_t)wave * 8192 + lane * 16;   // this wave copies granules [8 wave, 8 wave + 8) of a slot
@@ -226,8 +229,10 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
 
   // ------------------------------------------------------------------ G1-G3: this lane's row of the token matrix
   const size_t t_row = (size_t)blockIdx.x * 64 + wave * 16 + r16;
-  const size_t pt = t_row / V;
-  const int vr = (int)(t_row - pt * V);
+  const size_t pt = t_row >> lv;
+  const int vslot = (int)(t_row & (size_t)(Vp - 1));
+  const bool pad_row = vslot >= V;                       // padding slot: computed like the last real view, masked below
+  const int vr = pad_row ? V - 1 : vslot;
   const int d = (int)(pt % D);
   const int pix = (int)((pt / D) % SS);
   const int b = p.q0 + (int)(pt / ((size_t)D * SS));
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
       bool ok[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        ok[r] = (4 * g + r) / V == r16 / V;
+        ok[r] = ((4 * g + r) >> lv) == (r16 >> lv) && ((4 * g + r) & (Vp - 1)) < V;
         if (ok[r]) mx = fmaxf(mx, st[r]);
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -555,25 +560,25 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
     }
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
-    const float lg = part + svec[G4_VEC_MISC + 512];
-    // the V rows of a point are V consecutive lanes (r16): reduce over the low log2(V) lane bits
+    const float lg = pad_row ? -INFINITY : part + svec[G4_VEC_MISC + 512];
+    // the Vp slots of a point are Vp consecutive lanes (r16): reduce over the low log2(Vp) lane bits (slot 0 is always real)
     float mx = lg;
-    for (int o = 1; o < V; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    const float e = expf(lg - mx);
+    for (int o = 1; o < Vp; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float e = pad_row ? 0.f : expf(lg - mx);
     float den = e;
-    for (int o = 1; o < V; o <<= 1) den += __shfl_xor(den, o, 64);
+    for (int o = 1; o < Vp; o <<= 1) den += __shfl_xor(den, o, 64);
     const float pw = e / den;
-    const size_t prow = t_row / V;
+    const size_t prow = t_row >> lv;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       float v0 = h[j][0] * pw, v1 = h[j][1] * pw, v2 = h[j][2] * pw, v3 = h[j][3] * pw;
-      for (int o = 1; o < V; o <<= 1) {
+      for (int o = 1; o < Vp; o <<= 1) {
         v0 += __shfl_xor(v0, o, 64);
         v1 += __shfl_xor(v1, o, 64);
         v2 += __shfl_xor(v2, o, 64);
         v3 += __shfl_xor(v3, o, 64);
       }
-      if (vr == 0) store_sp4(p.pooled_sp, prow, 256, 16 * j + 4 * g, v0, v1, v2, v3);
+      if (vslot == 0) store_sp4(p.pooled_sp, prow, 256, 16 * j + 4 * g, v0, v1, v2, v3);
     }
   }
 }
@@ -590,16 +595,19 @@ extern "C" int mvd_gridattn_fused(const float* x, const float* depth_noise, cons
                                   int Vq, int S, int D, float depth_scale, float depth_shift, mvd_stream_t stream) {
   MVD_CHECK_ARG(x && depth_noise && steps && iter && grid_lin && feat && in_feat && cams && in_cam && wstream && vecs && pooled_sp,
                 "mvd_gridattn_fused: null pointer");
-  MVD_CHECK_ARG(V == 1 || V == 2 || V == 4 || V == 8 || V == 16, "mvd_gridattn_fused: V=%d must divide 16 (use the unfused path)", V);
+  MVD_CHECK_ARG(V >= 1 && V <= 16, "mvd_gridattn_fused: V=%d outside [1, 16] (use the unfused path)", V);
+  int lv = 0;
+  while ((1 << lv) < V) ++lv;
+  const int Vp = 1 << lv;
   MVD_CHECK_ARG(q0 >= 0 && Vq > 0 && q0 + Vq <= V && S > 1 && D > 0, "mvd_gridattn_fused: bad shape");
   MVD_CHECK_ARG(((uintptr_t)wstream & 15) == 0 && ((uintptr_t)vecs & 15) == 0 && ((uintptr_t)pooled_sp & 127) == 0,
                 "mvd_gridattn_fused: wstream / vecs must be 16-byte, pooled_sp 128-byte aligned");
-  const size_t T = (size_t)Vq * S * S * D * V;
-  MVD_CHECK_ARG(T % 64 == 0, "mvd_gridattn_fused: token count %zu must be a multiple of 64", T);
+  const size_t T = (size_t)Vq * S * S * D * Vp;           // token rows incl. the padding slots
+  MVD_CHECK_ARG(T % 64 == 0, "mvd_gridattn_fused: padded token count %zu must be a multiple of 64", T);
   G4Params p;
   p.x = x; p.depth_noise = depth_noise; p.steps = steps; p.iter = iter; p.grid_lin = grid_lin; p.feat = feat;
   p.in_feat = in_feat; p.cams = cams; p.in_cam = in_cam; p.wstream = (const unsigned char*)wstream; p.vecs = vecs;
-  p.pooled_sp = (u16*)pooled_sp; p.V = V; p.q0 = q0; p.Vq = Vq; p.S = S; p.D = D; p.nslots = 23 + 3 * 64;
+  p.pooled_sp = (u16*)pooled_sp; p.V = V; p.Vp = Vp; p.lv = lv; p.q0 = q0; p.Vq = Vq; p.S = S; p.D = D; p.nslots = 23 + 3 * 64;
   p.depth_scale = depth_scale; p.depth_shift = depth_shift;
   hipLaunchKernelGGL(g4_fused_kernel, dim3((unsigned)(T / 64)), dim3(256), 0, (hipStream_t)stream, p);
   MVD_CHECK_LAUNCH("mvd_gridattn_fused");

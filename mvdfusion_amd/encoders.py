@@ -111,7 +111,7 @@ class FrozenCLIPImageEmbedder(nn.Module):
         self.antialias = antialias
         self.register_buffer("mean", torch.Tensor([0.48145466, 0.4578275, 0.40821073]), persistent=False)
         self.register_buffer("std", torch.Tensor([0.26862954, 0.26130258, 0.27577711]), persistent=False)
-        self.precision = {"x3": hip.PREC_X3, "x4": hip.PREC_X4}.get(precision[-2:], hip.PREC_X1)
+        self.precision = hip.parse_precision(precision)[1]       # (a per-class policy addresses the UNet's layer classes only)
         self._ctx, self._packed_sig = None, None
 
     def preprocess(self, x):

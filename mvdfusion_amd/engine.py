@@ -61,10 +61,11 @@ class Ctx:
     gn_from_producer = True         # False: every GroupNorm runs its own statistics kernel (A/B measurement, bench.py --gn-two-pass)
     ln_fold = True                  # False: LayerNorm kernels instead of the fold into the QKV / GEGLU GEMMs (A/B: bench.py --ln-kernels)
 
-    def __init__(self, device, prec=hip.PREC_X4):
+    def __init__(self, device, prec=hip.PREC_X4, policy=None):
         self.device = torch.device(device)
         self.ws = Workspace(device)
-        self.prec = prec
+        self.prec = prec            # default number of partial products (hip.PREC_*)
+        self.policy = dict(policy or {})      # layer class (hip.PREC_KINDS) -> products, where it differs from the default
         self.B = 0                  # views in the UNet batch (2V with classifier-free guidance)
         self.D = 1                  # depth samples per ray
         self.context = None         # (B, 768) projected CLIP context
@@ -117,9 +118,13 @@ class Ctx:
         return self.ws.get(f"act{i}", key)
 
     # -- op helpers bound to this context
-    def gemm(self, A, W, out, gn=None, **kw):
-        """gn=(B, HW): `out` feeds a GroupNorm over (B, HW, N) -- the GEMM emits its statistics (see gn_slot)."""
-        kw.setdefault("prec", self.prec)
+    def prec_of(self, kind):
+        return self.policy.get(kind, self.prec)
+
+    def gemm(self, A, W, out, gn=None, kind=None, **kw):
+        """gn=(B, HW): `out` feeds a GroupNorm over (B, HW, N) -- the GEMM emits its statistics (see gn_slot).
+        kind: the layer class of the precision policy (hip.PREC_KINDS)."""
+        kw.setdefault("prec", self.prec_of(kind))
         kw.setdefault("workspace", self.gemm_ws)
         if out is not None:
             self._gn.pop(out.data_ptr(), None)          # whatever statistics the buffer had are stale now

@@ -17,6 +17,25 @@ LIB_PATH = LIB_PATHS["f16"]
 OPERAND_FORMAT = os.environ.get("MVD_OPERAND_FORMAT", "f16")   # chosen before the first call, fixed per process
 
 PREC_X1, PREC_X3, PREC_X4 = 1, 3, 4
+# Layer classes a precision policy may address (Ctx.gemm(kind=...), Ctx.prec_of): the number of partial products of the
+# (hi + lo)(hi + lo) operand split is chosen per class, not per model.
+PREC_KINDS = ("conv", "skip", "proj", "qkv", "attn", "out", "geglu", "ffproj", "xattn", "ga")
+
+
+def parse_precision(name):
+    """'f16x4' / 'f16x3' / 'bf16x3' / 'f16' / 'bf16' -> (operand format, default products, {}); a policy string
+    'f16x4:conv=3,geglu=3' (default x4, the named layer classes of PREC_KINDS at x3) -> (format, 4, {'conv': 3, 'geglu': 3})."""
+    base, _, over = name.partition(":")
+    fmt = "bf16" if base.startswith("bf16") else "f16"
+    default = {"x3": PREC_X3, "x4": PREC_X4}.get(base[-2:], PREC_X1)
+    policy = {}
+    for item in filter(None, over.split(",")):
+        k, _, v = item.partition("=")
+        k = k.strip()
+        if k not in PREC_KINDS or int(v) not in (PREC_X1, PREC_X3, PREC_X4):
+            raise ValueError(f"precision policy '{name}': '{item}' is not <kind>=<1|3|4> with kind in {PREC_KINDS}")
+        policy[k] = int(v)
+    return fmt, default, policy
 A_DENSE, A_CONV3X3 = 0, 1
 EPI_STORE, EPI_GEGLU, EPI_QKV = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_QUICKGELU = 0, 1, 2, 3

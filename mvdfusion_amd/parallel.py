@@ -82,7 +82,13 @@ def sample_view_parallel(model, batch_cameras, input_latents, input_cameras, cli
     eng.x.copy_(x_T)
 
     def local_step(i, x):
+        # feed_prev_depth (mvdfusion/sampler.py:83-84,135-140): from the second iteration on GridAttn samples the depth of a QUERY view
+        # around that view's previous x0 estimate -- a row this rank produced itself (eng.x0[q0:q0+Vq]), so no extra exchange is needed
+        eng.depth_mode = 1 if (samp.feed_prev_depth and i > 0) else 0
         eng.step(cfg_scale, do_update=True, use_graph=use_graph)
 
-    run_view_parallel(eng.x, n_run, local_step, ex, force_collective=force_collective)
+    try:
+        run_view_parallel(eng.x, n_run, local_step, ex, force_collective=force_collective)
+    finally:
+        eng.depth_mode = 0          # engines are cached per (V, S, D, cfg, shard): never leak a depth mode into the next caller
     return eng.x.clone()

@@ -47,7 +47,7 @@ class Upsample(nn.Module):
             out = ctx.act((ctx.B * 4 * H * W, self.out_channels))
         xp = hip.split_planes(x, ctx.ws.planes("updown.x", ctx.B * H * W, self.channels))   # raw residual stream -> planes
         ctx.gemm(xp, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=2 * H, Wout=2 * W,
-                                            stride=1, upsample=1), gn=(ctx.B, 4 * H * W))
+                                            stride=1, upsample=1), gn=(ctx.B, 4 * H * W), kind="conv")
         return out, 2 * H, 2 * W
 
 
@@ -66,7 +66,7 @@ class Downsample(nn.Module):
             out = ctx.act((ctx.B * Ho * Wo, self.out_channels))
         xp = hip.split_planes(x, ctx.ws.planes("updown.x", ctx.B * H * W, self.channels))
         ctx.gemm(xp, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self.channels, Hout=Ho, Wout=Wo, stride=2,
-                                            upsample=0), gn=(ctx.B, Ho * Wo))
+                                            upsample=0), gn=(ctx.B, Ho * Wo), kind="conv")
         return out, Ho, Wo
 
 
@@ -105,7 +105,7 @@ class ResBlock(TimestepBlock):
         ctx.groupnorm(x, a, self.in_layers[0], B, H * W, Ci, silu=True)
         h = ctx.ws.get("res.h", (M, Co))
         # conv bias + Linear(SiLU(emb)) are folded into one per-step bias vector (UNetModel._time_biases)
-        ctx.gemm(a, w1, h, conv=dict(Cin=Ci, **geo), bias=False, bias_b=ctx.emb_bias[self], rows_per_batch=M, gn=(B, H * W))
+        ctx.gemm(a, w1, h, conv=dict(Cin=Ci, **geo), bias=False, bias_b=ctx.emb_bias[self], rows_per_batch=M, gn=(B, H * W), kind="conv")
         a2 = ctx.ws.planes("res.a2", M, Co)
         ctx.groupnorm(h, a2, self.out_layers[0], B, H * W, Co, silu=True)
         skip = x
@@ -113,10 +113,10 @@ class ResBlock(TimestepBlock):
             if x_planes is None:
                 x_planes = hip.split_planes(x, ctx.ws.planes("res.xp", M, Ci))
             skip = ctx.ws.get("res.skip", (M, Co))
-            ctx.gemm(x_planes, wsk, skip)
+            ctx.gemm(x_planes, wsk, skip, kind="skip")
         if out is None:
             out = ctx.act((M, Co))
-        ctx.gemm(a2, w2, out, conv=dict(Cin=Co, **geo), res=skip, gn=(B, H * W))
+        ctx.gemm(a2, w2, out, conv=dict(Cin=Co, **geo), res=skip, gn=(B, H * W), kind="conv")
         return out
 
 
@@ -144,7 +144,7 @@ class _StemConv(nn.Conv2d):
         if self._p is None:
             self._p = hip.pack_conv3x3(self.weight, self.bias)
         ctx.gemm(x, self._p, out, conv=dict(B=ctx.B, Hin=H, Win=W, Cin=self._p.conv_cin, Hout=H, Wout=W, stride=1,
-                                            upsample=0), gn=(ctx.B, H * W))
+                                            upsample=0), gn=(ctx.B, H * W), kind="conv")
         return out
 
 
@@ -317,7 +317,7 @@ class UNetModel(nn.Module):
         ctx.groupnorm(h, a, self.out[0], B, H * W, self.model_channels, silu=True)
         y = ctx.ws.get("head", (M, 8))
         ctx.gemm(a, self._head, y, conv=dict(B=B, Hin=H, Win=W, Cin=self.model_channels, Hout=H, Wout=W, stride=1,
-                                             upsample=0), ldo=8)
+                                             upsample=0), ldo=8, kind="conv")
         self._head_saved = (h, a)          # input of the head and planes of SiLU(GN(h)): what backward.unet_head_backward needs
         return y
 

@@ -140,15 +140,15 @@ class DiTBlock(nn.Module):
         ln = ctx.ws.planes("ga.ln", T, C)
         hip.layernorm(h, ln, sc1, sh1, T, C, eps=1e-6, w_plus_one=True)
         qkv = ctx.ws.get("ga.qkv", (T, 3 * C))
-        ctx.gemm(ln, wqkv, qkv)
+        ctx.gemm(ln, wqkv, qkv, kind="ga")
         att = ctx.ws.planes("ga.att", T, C)
         hip.check(hip.lib().mvd_view_mha(hip.ptr(qkv), hip.ptr(att), T // V, V, self.num_heads, C // self.num_heads,
                                          hip.stream()))
-        ctx.gemm(att, wproj, h_alt, res=h, colscale=g1)
+        ctx.gemm(att, wproj, h_alt, res=h, colscale=g1, kind="ga")
         hip.layernorm(h_alt, ln, sc2, sh2, T, C, eps=1e-6, w_plus_one=True)
         f1 = ctx.ws.planes("ga.f1", T, wfc1.N)
-        ctx.gemm(ln, wfc1, None, act=hip.ACT_GELU, out_planes=f1)
-        ctx.gemm(f1, wfc2, h, res=h_alt, colscale=g2)
+        ctx.gemm(ln, wfc1, None, act=hip.ACT_GELU, out_planes=f1, kind="ga")
+        ctx.gemm(f1, wfc2, h, res=h_alt, colscale=g2, kind="ga")
         return h
 
 
@@ -208,8 +208,11 @@ class GridAttn(nn.Module):
         return self._fused
 
     def fused_supported(self, V, T):
+        """Whether the single-launch aggregation kernel serves V reference views / T = nseq * V tokens: any 1 <= V <= 16 (the kernel
+        pads the views of a 3-D point to the next power of two and masks the padding: the reference's 15 / 7 / 5 views included)."""
         blocks = self.aggregation_transformer.layer_list
-        return (V in (1, 2, 4, 8, 16) and T % 64 == 0 and self.hidden_size == 256 and len(blocks) == 3 and
+        Vp = 1 << max(int(V) - 1, 0).bit_length()
+        return (1 <= V <= 16 and (T // V * Vp) % 64 == 0 and T % V == 0 and self.hidden_size == 256 and len(blocks) == 3 and
                 all(b.num_heads == 8 and b.mlp.fc1.out_features == 512 for b in blocks))
 
     def run(self, ctx, x, depth_noise, steps, it, cams_rec, in_cam_rec, input_latents, c, vol_out, V, S, D, q0=0, Vq=None,
@@ -218,7 +221,7 @@ class GridAttn(nn.Module):
         whose first Vq*S*S*D rows receive the feature frustum (row = ((v*S + y)*S + x)*D + d) of the query views
         [q0, q0+Vq) (all V views by default; a view-parallel rank passes the range it owns).  vol_planes: optional planes
         buffer receiving the frustum as well, in columns [vol_planes_col, vol_planes_col + 768) of its rows.
-        fused: None = the single-launch aggregation kernel (mvd_gridattn_fused) whenever V divides 16, else the unfused chain
+        fused: None = the single-launch aggregation kernel (mvd_gridattn_fused) whenever V <= 16, else the unfused chain
         of token kernel + GEMMs; True / False force one of them.
         depth_src / depth_steps (overwrite_attn_depth, view_attn_efficient2.py:418-426): a (V,5,S,S) buffer whose channel 4 is the depth
         map to sample around INSTEAD of the x0-style estimate x[:,4] / sqrt(alpha_bar), with a step table whose sqrt(alpha_bar) column
@@ -256,7 +259,7 @@ class GridAttn(nn.Module):
                                            hip.ptr(feat), hip.ptr(in_feat), hip.ptr(cams_rec), hip.ptr(in_cam_rec), hip.ptr(stream),
                                            hip.ptr(vecs), hip.ptr(pool), V, q0, Vq, S, D, float(self.depth_scale),
                                            float(self.depth_shift), hip.stream()))
-            ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes, out_planes_col=vol_planes_col)
+            ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes, out_planes_col=vol_planes_col, kind="ga")
             return vol_out
         tokens = ctx.ws.planes("ga.tokens", T, hip.TOKEN_LD)
         hip.check(L.mvd_gridattn_tokens(hip.ptr(dsrc), hip.ptr(depth_noise), hip.ptr(dsteps), hip.ptr(it), hip.ptr(grid_lin),
@@ -265,7 +268,7 @@ class GridAttn(nn.Module):
                                         hip.stream()))
         h = ctx.ws.get("ga.h", (T, self.hidden_size))
         h_alt = ctx.ws.get("ga.h_alt", (T, self.hidden_size))
-        ctx.gemm(tokens, w_pre, h, act=hip.ACT_GELU)
+        ctx.gemm(tokens, w_pre, h, act=hip.ACT_GELU, kind="ga")
         for blk in self.aggregation_transformer.layer_list:
             h = blk.run(ctx, h, h_alt, c, T, V)
         wl = self.aggregation_transformer.weight_layer
@@ -273,5 +276,5 @@ class GridAttn(nn.Module):
         hip.check(L.mvd_view_pool(hip.ptr(h), hip.ptr(wl.weight), hip.ptr(wl.bias), hip.ptr(pool), nseq, V, self.hidden_size,
                                   hip.stream()))
         # the frustum is consumed as fp32 (area pooling) and as planes (level-0 to_k / to_v GEMMs): write both
-        ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes, out_planes_col=vol_planes_col)
+        ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes, out_planes_col=vol_planes_col, kind="ga")
         return vol_out

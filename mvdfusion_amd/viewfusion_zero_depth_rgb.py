@@ -35,10 +35,10 @@ def _sinusoid_freqs(dim, max_period=10000):
 class StepEngine:
     """One denoising iteration (GridAttn -> CFG-batched UNet -> CFG combine [+ DDIM update]) on static buffers."""
 
-    def __init__(self, model, V, S, D, cfg, device, prec, q0=0, Vq=None):
+    def __init__(self, model, V, S, D, cfg, device, prec, q0=0, Vq=None, policy=None):
         self.m, self.V, self.S, self.D, self.cfg = model, V, S, D, bool(cfg)
         self.q0, self.Vq = q0, (V if Vq is None else Vq)   # query views owned by this rank (view-parallel sharding)
-        self.ctx = Ctx(device, prec)
+        self.ctx = Ctx(device, prec, policy)
         dev = self.ctx.device
         B = 2 * self.Vq if cfg else self.Vq
         self.B = B
@@ -236,9 +236,10 @@ class ViewFusion(nn.Module):
         # "f16x4" (default: fp16, all 4 products -- fp32-class; +4 % time over x3 because the GEMMs are operand-delivery
         # bound), "f16x3" (drops lo*lo, ~2^-22), "bf16x3" (~2^-16), "f16" / "bf16" (one product, hi only).  The operand type selects the library
         # flavour and is fixed per process.
-        hip.set_operand_format("bf16" if precision.startswith("bf16") else "f16")
+        # A policy string "f16x4:conv=3,geglu=3" sets the products per layer class (hip.PREC_KINDS).
+        fmt, self.precision, self.precision_policy = hip.parse_precision(precision)
+        hip.set_operand_format(fmt)
         self.precision_name = precision
-        self.precision = {"x3": hip.PREC_X3, "x4": hip.PREC_X4}.get(precision[-2:], hip.PREC_X1)
 
         def params(cfg):
             return dict(cfg.get("params", cfg)) if hasattr(cfg, "get") else dict(cfg)
@@ -321,7 +322,7 @@ class ViewFusion(nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError("mvdfusion_amd.ViewFusion runs on the GPU only (model.cuda() first); "
                                    "there is no CPU path in the product")
-            e = StepEngine(self, V, S, D, cfg, dev, self.precision, q0=q0, Vq=Vq)
+            e = StepEngine(self, V, S, D, cfg, dev, self.precision, q0=q0, Vq=Vq, policy=self.precision_policy)
             self._engines[key] = e
         return e
 

@@ -312,6 +312,14 @@ def gold_gridattn_v15():
          out_l2=out.norm(), **c)
 
 
+def gold_gridattn_small(V, D, seed, t_val, tag):
+    """View counts the reference's configs ship that are not powers of two (mvd_train.yaml: 5 and 7 views): the fused kernel pads them."""
+    c = _gridattn_case(V, D, 32, seed, t_val, tokens=False)
+    out = c.pop("out")
+    c.pop("tokens_sample")
+    save(tag, out_strided=out[:, ::5, ::7, :, ::3], out_mean=out.mean(), out_std=out.std(), out_l2=out.norm(), **c)
+
+
 def gold_gridattn_prev_depth():
     """overwrite_attn_depth (view_attn_efficient2.py:418-426): the depth channel comes from the caller instead of the x0-estimate."""
     c = _gridattn_case(4, 1, 32, 6, 301, tokens=False, prev_depth=True)
@@ -800,10 +808,15 @@ ALL = {
     "unet320_s64": lambda: gold_unet(320, 2, 1, "unet_mc320_v2_d1_s64", S=64, full=False),
     "unet320_d3": lambda: gold_unet(320, 2, 3, "unet_mc320_v2_d3", t_val=501),
     "gridattn_v15": gold_gridattn_v15,
+    "gridattn_v7": lambda: gold_gridattn_small(7, 1, 8, 621, "gridattn_v7_d1"),          # configs/mvd_train.yaml:97 (7 views)
+    "gridattn_v5_d3": lambda: gold_gridattn_small(5, 3, 9, 161, "gridattn_v5_d3"),       # configs/mvd_train.yaml:90 (5 views, D = 3)
+    "step320_v15": lambda: gold_step(320, 15, 1, "step_mc320_v15_d1", indices=(49,), lean=True),     # configs/mvd_gso.yaml:97 as shipped
+    "step320_v8_d3": lambda: gold_step(320, 8, 3, "step_mc320_v8_d3", indices=(30,), lean=True),     # forward of BASELINE configs[4]'s geometry
     "ckpt_remap": gold_ckpt_remap,
     "clip_tiny": lambda: gold_clip("tiny-test", "clip_tiny"),
     "clip_l14": lambda: gold_clip("ViT-L/14", "clip_vit_l14"),
     "train32_d3": lambda: gold_train_loss(32, 4, 3, "train_loss_mc32_v4_d3", seed=31, grads_tag="train_grads_mc32_v4_d3"),
+    "train320_v8_d3": lambda: gold_train_loss(320, 8, 3, "train_loss_mc320_v8_d3", seed=37, grads_tag="train_grads_mc320_v8_d3", lean=True),   # BASELINE configs[4]
     "train320_d3": lambda: gold_train_loss(320, 2, 3, "train_loss_mc320_v2_d3", seed=35, grads_tag="train_grads_mc320_v2_d3", lean=True),
     "traj32": lambda: gold_trajectory(32, 4, 1, "traj_mc32_v4_d1", steps=5),
     "traj320": lambda: gold_trajectory(320, 4, 1, "traj_mc320_v4_d1_50steps", steps=50),

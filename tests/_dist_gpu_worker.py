@@ -26,6 +26,7 @@ def main():
     from mvdfusion_amd import synthetic as syn
     from mvdfusion_amd.parallel import sample_view_parallel
     m = build_model(32)
+    m.ddim.feed_prev_depth = len(sys.argv) > 4 and sys.argv[4] == "feed_prev_depth"      # sampler.py:83-84,135-140 under sharding
     S, D = 32, 1
     inp = syn.make_inputs(V, S, seed=4)
     dn, sn = syn.step_noise(V, S, D, 50, seed=4)              # every rank draws the FULL noise from the same seed
@@ -44,6 +45,8 @@ def main():
                            unconditional_scale=2.5, depth=True, verbose=False, x_T=inp["x_T"].cuda(), num_steps=steps)
         d = (x - x1).double()
         out.update(max_abs_diff=float(d.abs().max()), rmse=float((d ** 2).mean().sqrt()), finite=bool(torch.isfinite(x).all()))
+    m.ddim.feed_prev_depth = False
+    out["feed_prev_depth"] = len(sys.argv) > 4 and sys.argv[4] == "feed_prev_depth"
     dist.barrier()
     print("DISTJSON " + json.dumps(out), flush=True)
     dist.destroy_process_group()

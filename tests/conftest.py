@@ -57,30 +57,14 @@ def rmse(a, b):
     return float(((a - b) ** 2).mean().sqrt())
 
 
-UNET_PARAMS = dict(image_size=32, in_channels=10, out_channels=5, model_channels=320, attention_resolutions=[4, 2, 1],
-                   num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
-                   use_view_aligned_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=True,
-                   legacy=False)
+from mvdfusion_amd.configs import UNET_PARAMS  # noqa: E402,F401  (the yaml's model block lives in the package: mvdfusion_amd/configs.py)
+from mvdfusion_amd import configs as _configs  # noqa: E402
 
-
-DEFAULT_PRECISION = "bf16x3" if os.environ.get("MVD_OPERAND_FORMAT") == "bf16" else "f16x4"
+DEFAULT_PRECISION = "bf16x3" if os.environ.get("MVD_OPERAND_FORMAT") == "bf16" else _configs.DEFAULT_PRECISION
 
 
 def model_config(mc=320, D=1, S=32, precision=None):
-    """The `params:` block of configs/mvd_gso.yaml (model part) as a dict."""
-    precision = precision or DEFAULT_PRECISION
-    up = dict(UNET_PARAMS)
-    up["model_channels"] = mc
-    up["image_size"] = S
-    return dict(
-        view_attn_config=dict(target="mvdfusion.view_attn_efficient2.GridAttn",
-                              params=dict(in_channels=5, input_size=S, output_dim=768, num_layers=3,
-                                          z_near_far_scale=0.8, n_pts_per_ray=D)),
-        unet_config=dict(target="mvdfusion.unet.UNetModel", params=up),
-        ddpm_config=dict(target="mvdfusion.scheduler.DDPMScheduler", params=dict(timesteps=1000)),
-        vae_path=None, unet_path=None, z_scale_factor=0.18215, objective="noise", loss_type="l2",
-        embed_camera_pose=True, finetune_projection=True, finetune_unet=False, finetune_cross_attn=True,
-        finteune_view_attn=True, drop_conditions=True, precision=precision)
+    return _configs.model_config(mc, D, S, precision or DEFAULT_PRECISION)
 
 
 _MODELS = {}

@@ -22,10 +22,10 @@ def _free_port():
     return p
 
 
-def _run(backend, V, steps, worker="_dist_gpu_worker.py", nproc=2):
+def _run(backend, V, steps, worker="_dist_gpu_worker.py", nproc=2, extra=()):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", worker), backend, str(V), str(steps)]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", worker), backend, str(V), str(steps), *extra]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     recs, dec, pos = [], json.JSONDecoder(), 0          # (the two ranks' lines may interleave on one line)
     while True:
@@ -58,6 +58,48 @@ def test_two_rank_view_parallel_on_one_gpu(V):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         json.dump({"backend": used, "records": recs}, open(os.path.join(out, "dist_2rank_one_gpu.json"), "w"))
+
+
+def test_two_rank_view_parallel_feed_prev_depth():
+    """feed_prev_depth (mvdfusion/sampler.py:83-84,135-140) under view sharding: two ranks, from the second iteration on each
+    rank's GridAttn samples depth around ITS OWN previous x0 rows; the sharded trajectory must equal the unsharded sampler's (which is
+    pinned to the reference's own loop by test_sampler_feed_prev_depth_vs_reference_golden), and differ from the plain algorithm's."""
+    steps, V = 3, 4
+    r, recs = _run("nccl", V, steps, extra=("feed_prev_depth",))
+    if r.returncode != 0 or len(recs) != 2:
+        r, recs = _run("gloo", V, steps, extra=("feed_prev_depth",))
+    assert r.returncode == 0 and len(recs) == 2, r.stderr[-3000:]
+    rec0 = [x for x in recs if x["rank"] == 0][0]
+    assert all(x["replicas_identical"] and x["feed_prev_depth"] for x in recs)
+    assert rec0["finite"] and rec0["rmse"] < 1e-5 and rec0["max_abs_diff"] < 1e-4, rec0
+
+
+def test_view_parallel_feed_prev_depth_single_process():
+    """The same property without a process group (world 1): sample_view_parallel honours feed_prev_depth, resets the engine's depth
+    mode afterwards, and the flag changes the trajectory."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import build_model, rmse
+    from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.parallel import sample_view_parallel
+    m = build_model(32)
+    V, S, D, steps = 4, 32, 1, 3
+    inp = syn.make_inputs(V, S, seed=4)
+    dn, sn = syn.step_noise(V, S, D, 50, seed=4)
+    args = (inp["batch_cameras"], inp["input_latents"], inp["input_cameras"], inp["clip_v_embed"])
+    outs = {}
+    for flag in (False, True):
+        m.ddim.feed_prev_depth = flag
+        try:
+            xs = sample_view_parallel(m, *args, 2.5, inp["x_T"].cuda(), dn, sn, num_steps=steps)
+            assert m.engine(V, S, D, True, q0=0, Vq=V).depth_mode == 0
+            m.ddim.noise_source = lambda *a: (dn, sn)
+            x1 = m.ddim.sample(*args, unconditional_scale=2.5, depth=True, verbose=False, x_T=inp["x_T"].cuda(), num_steps=steps)
+        finally:
+            m.ddim.feed_prev_depth, m.ddim.noise_source = False, None
+        assert rmse(xs, x1) < 1e-6, (flag, rmse(xs, x1))
+        outs[flag] = xs.cpu()
+    assert rmse(outs[True], outs[False]) > 1e-4
 
 
 def test_two_rank_ddp_training_step():

@@ -175,7 +175,7 @@ def test_sample_then_decode_end_to_end():
     assert bool(torch.isfinite(img).all())
 
 
-def _training_setup(gd, mc=32, V=4):
+def _training_setup(gd, mc=32, V=4, **overrides):
     """The model / batch / random draws of the reference's training fixtures (oracle/make_golden.py: train32_d3, train320_d3)."""
     from conftest import model_config
     from mvdfusion_amd import synthetic as syn
@@ -184,6 +184,7 @@ def _training_setup(gd, mc=32, V=4):
     dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
               num_res_blocks=2, attn_resolutions=[], dropout=0.0)
     cfg = model_config(mc, D=D)
+    cfg.update(overrides)
     cfg["vae_config"] = dict(target="external.sd1.ldm.models.autoencoder.AutoencoderKL",
                              params=dict(embed_dim=4, ddconfig=dd, lossconfig=dict(target="torch.nn.Identity")))
     m = ViewFusion(clip_image_encoder=syn.StubClipImageEncoder(), **cfg)
@@ -353,6 +354,50 @@ def test_training_all_gradients_vs_reference_golden(name, mc, V):
     print(f"all {len(names)} parameter gradients compared, worst relative deviation {worst:.2e}")
     assert not missing, missing[:10]
     assert not bad, bad[:10]
+
+
+def test_training_config4_v8_d3_full_width_vs_reference_golden():
+    """BASELINE configs[4] AS WRITTEN (configs/mvd_train.yaml:15,28: `finetune_unet: true`, n_pts_per_ray 3; V = 8 views per scene,
+    full-width UNet, 1 039 M trainable parameters; train.py:86-95): the loss and ALL 994 parameter gradients of `loss.backward()` against
+    the REAL reference's autograd at that size (train_grads_mc320_v8_d3: float64 L2 norm + seeded random projection per gradient), plus
+    the size-independent properties -- every gradient finite, a second evaluation bit-identical, the loss equal to the forward-only
+    value (p_losses), frozen / trainable bookkeeping: with `finetune_unet: true` every UNet parameter is trainable."""
+    gd = load_golden("train_grads_mc320_v8_d3")
+    m, batch, tc, draws = _training_setup(gd, mc=320, V=8, finetune_unet=True)
+    assert all(p.requires_grad for p in m.unet_model.parameters())
+    loss, grads = m.gradients(batch, tc, noise_source=draws, only_trainable=True)
+    assert abs(float(loss) - float(gd["loss"])) / float(gd["loss"]) < 1e-4, (float(loss), float(gd["loss"]))
+    names = [str(n) for n in gd["grad_names"]]
+    norms, projs = gd["grad_norms"].double(), gd["grad_projs"].double()
+    assert len(names) == 994
+    missing, bad, worst = [], [], 0.0
+    keep = {}
+    for i, n in enumerate(names):
+        if grads.get(n) is None:
+            missing.append(n)
+            continue
+        assert bool(torch.isfinite(grads[n]).all()), n
+        if i % 7 == 0:
+            keep[n] = grads[n].clone()
+        gq = grads[n].detach().double().cpu().flatten()
+        r = torch.randn(gq.numel(), generator=torch.Generator().manual_seed(1000 + i)).double()
+        nr, pr = float(norms[i]), float(projs[i])
+        e_n, e_p = abs(float(gq.norm()) - nr), abs(float((gq * r).sum()) - pr)
+        tol = 1e-4 * nr + 2e-8 * gq.numel() ** 0.5
+        if e_n > tol or e_p > tol:
+            bad.append((n, nr, e_n, e_p))
+        if nr > 1e-6:
+            worst = max(worst, e_n / nr, e_p / nr)
+    print(f"configs[4]: all {len(names)} gradients compared at V=8, D=3, full width; worst relative deviation {worst:.2e}")
+    assert not missing, missing[:10]
+    assert not bad, bad[:10]
+    del grads
+    loss2, grads2 = m.gradients(batch, tc, noise_source=draws, only_trainable=True)
+    assert torch.equal(loss, loss2)
+    diff = [k for k, v in keep.items() if not torch.equal(v, grads2[k])]
+    assert not diff, diff[:10]
+    fwd = m.p_losses(batch, tc, noise_source=draws)
+    assert abs(float(fwd) - float(loss)) <= 1e-6 * abs(float(loss)), (float(fwd), float(loss))
 
 
 def test_training_backward_is_bit_reproducible():
