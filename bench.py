@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_16BIT_DENSE_PEAK = 2.5e15  # FLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (dense; not the 2:1-sparse figure)
 HBM_PEAK = 8.0e12               # B/s (spec; ~6.3 TB/s achievable), same guide
-ROUND = "r03"
+ROUND = "r04"
 
 
 def log(*a):
@@ -103,7 +103,7 @@ def profile_kernel_groups(m, eng, cfg_scale):
             + (4.0 * M * N if kw.get("qkv") else 0.0)
         abytes = 4.0 * rows_in * k_in + 4.0 * W.N * Kp + n_out      # A planes + packed W (hi+lo = 4 B/elem) + outputs / residual
         recs.append(dict(sym=hip.kernel_symbol(hip.LAST_CFG, kw.get("prec", 4), bool(conv)), M=M, N=N, K=Kp,
-                         flops=2.0 * M * N * Kp, bytes=abytes, ev=(e0, e1)))
+                         flops=2.0 * M * N * Kp, bytes=abytes, prec=kw.get("prec", 4), ev=(e0, e1)))
         return r
 
     def timed_attention(planes, out, B, heads, L, dhead, prec=hip.PREC_X4, Lkeys=0):
@@ -173,10 +173,11 @@ def profile_kernel_groups(m, eng, cfg_scale):
     by = {}
     for r in recs:
         ms = r["ev"][0].elapsed_ms(r["ev"][1])
-        b = by.setdefault(r["sym"], dict(n=0, ms=0.0, flops=0.0, bytes=0.0))
+        b = by.setdefault(r["sym"], dict(n=0, ms=0.0, flops=0.0, bytes=0.0, mfma_flops=0.0))
         b["n"] += 1
         b["ms"] += ms
         b["flops"] += r["flops"]
+        b["mfma_flops"] += r["flops"] * r["prec"]
         b["bytes"] += r["bytes"]
     gsum = {}
     for k, lst in groups.items():
@@ -254,7 +255,8 @@ def main():
     ap.add_argument("--views", type=int, default=None)
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--depth-samples", type=int, default=1)
-    ap.add_argument("--precision", default="f16x4", choices=["f16x4", "f16x3", "bf16x3", "f16", "bf16"])
+    ap.add_argument("--precision", default=None, help="f16x4 | f16x3 | bf16x3 | f16 | bf16, or a per-layer-class policy "
+                    "'f16x4:conv=3,geglu=3' (mvdfusion_amd.hip.parse_precision); default: mvdfusion_amd.configs.DEFAULT_PRECISION")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (0 = all host cores)")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -305,7 +307,10 @@ def main():
     S, D, cfg_scale = a.latent, a.depth_samples, 2.5
 
     from mvdfusion_amd import hip
+    from mvdfusion_amd.configs import DEFAULT_PRECISION
     from mvdfusion_amd.parallel import ViewExchange
+    a.precision = a.precision or DEFAULT_PRECISION
+    p_fmt, p_default, p_policy = hip.parse_precision(a.precision)
     if a.tune_cache and os.path.exists(a.tune_cache):
         log(f"[bench] {hip.load_tuned(a.tune_cache)} tuned GEMM configurations loaded from {a.tune_cache}")
     m, sd = build(V, S, D, a.precision)
@@ -357,10 +362,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "rccl_ranks": world if backend == "nccl" else 0,
             "scaling": "strong" if N > 1 else "weak", "vs_baseline": None,
-            "dtype": {"f16x4": "f16x4 (fp16 MFMA operands split hi+lo, all 4 partial products, fp32 accumulate)",
-                      "f16x3": "f16x3 (fp16 MFMA operands split hi+lo, 3 products, fp32 accumulate)",
-                      "bf16x3": "bf16x3 (bf16 MFMA operands split hi+lo, 3 products, fp32 accumulate)",
-                      "f16": "f16 (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)"}[a.precision],
+            "dtype": f"{a.precision} ({p_fmt} MFMA operands" + (f" split hi+lo, {p_default} partial products" if p_default > 1 else "") +
+                     (f"; layer classes at other counts: {p_policy}" if p_policy else "") + ", fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": workload_label(V, S, D, N, cfg_scale),
                        "views": V, "latent": S, "depth_samples": D, "cfg_scale": cfg_scale,
@@ -382,15 +385,15 @@ def main():
         # tile / loop variants the autotuner picks per shape).  Headline = the whole family (every GEMM launch of the
         # step); `variants` lists each instantiation under the symbol rocprofv3 reports, for cross-checking
         # profiles/<round>_bench_n1_kernel_stats.csv.
-        nprod = {"f16x4": 4, "f16x3": 3, "bf16x3": 3}.get(a.precision, 1)
         n_all = sum(b["n"] for b in by.values())
         fl_all = sum(b["flops"] for b in by.values())
+        nprod = sum(b["mfma_flops"] for b in by.values()) / fl_all      # FLOP-weighted mean of the partial products per MAC (precision policy)
         by_all = sum(b["bytes"] for b in by.values())
         ach = fl_all / (tot * 1e-3)
         # HBM traffic: only from PMC passes of THIS workload (tools/pmc_traffic.sh <tag> --views V --latent S ...), else null
         pmc, tsrc = {}, None
         tfile = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic_v{V}_s{S}_d{D}.json")
-        if os.path.exists(tfile) and a.precision == "f16x4":
+        if os.path.exists(tfile):
             pmc = json.load(open(tfile))["kernels"]
             tsrc = (f"profiles/{os.path.basename(tfile)}: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
                     "command and workload, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch over the graph-replayed steps only; averaged over "
@@ -432,9 +435,10 @@ def main():
                 continue
             e = {"launches_per_step": g["n"], "ms_per_step": g["ms"]}
             if g["flops"]:
+                np_g = 4 if k.startswith("gridattn") else (p_policy.get("attn", p_default) if k == "attention" else nprod)
                 e.update(bound="mfma", achieved=g["flops"] / (g["ms"] * 1e-3) / 1e12, peak=MFMA_16BIT_DENSE_PEAK / 1e12,
                          unit="TFLOP/s", frac=g["flops"] / (g["ms"] * 1e-3) / MFMA_16BIT_DENSE_PEAK,
-                         mfma_pipe_frac=nprod * g["flops"] / (g["ms"] * 1e-3) / MFMA_16BIT_DENSE_PEAK)
+                         mfma_products_per_mac=np_g, mfma_pipe_frac=np_g * g["flops"] / (g["ms"] * 1e-3) / MFMA_16BIT_DENSE_PEAK)
             else:
                 e.update(bound="hbm", achieved=g["bytes"] / (g["ms"] * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                          frac=g["bytes"] / (g["ms"] * 1e-3) / HBM_PEAK)

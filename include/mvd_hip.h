@@ -86,7 +86,8 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, floa
 #define MVD_ACT_QUICKGELU 3 /* x * sigmoid(1.702 x): the MLP activation of OpenAI CLIP's vision transformer */
 
 #define MVD_GEMM_TILES 5 /* tile shapes of mvd_gemm_desc.cfg */
-#define MVD_GEMM_LOOPS 8 /* k-loop variants of mvd_gemm_desc.cfg */
+#define MVD_GEMM_LOOPS 9 /* k-loop variants of mvd_gemm_desc.cfg */
+#define MVD_GEMM_CFG_STRIDE 32 /* cfg = 1 + MVD_GEMM_CFG_STRIDE * tile + 2 * loop + order */
 #define MVD_B_PACKED 0   /* B: weight image of mvd_pack_linear_weight / mvd_pack_conv3x3_weight */
 #define MVD_B_PLANES 1   /* B: (N, ldb) row-major split planes (an activation), N % 16 == 0 */
 
@@ -137,7 +138,7 @@ typedef struct mvd_gemm_desc {
   int splitk;
   float* workspace;
   size_t workspace_elems;
-  /* kernel configuration: 0 = built-in heuristic; otherwise cfg = 1 + 16 * tile + 2 * loop + order with
+  /* kernel configuration: 0 = built-in heuristic; otherwise cfg = 1 + MVD_GEMM_CFG_STRIDE * tile + 2 * loop + order with
    *   tile : 0 = 64x64 (4 waves)  1 = 128x128 (8 waves)  2 = 128x80 (4 waves)  3 = 64x80 (4 waves)  4 = 128x160 (8 waves);
    *          tiles >= 2 (the 80-column family for N = 320 * k: no N padding, 256 workgroups at M = 8192, N = 320) serve
    *          MVD_EPI_STORE only
@@ -150,7 +151,9 @@ typedef struct mvd_gemm_desc {
    *          stride-1 padded 3x3 convolutions (tiles 1, 2, 4): the tile's pixels + halo are staged once per 32-channel block and the
    *          nine taps read shifted slots of that patch (4-6x less A traffic into LDS), 7 = the wave-specialised kernel (tiles 1, 2,
    *          4; MVD_EPI_STORE): four consumer wavefronts (fragment reads + MFMAs) and four loader wavefronts (all LDS-DMAs) per
-   *          workgroup; mvd_gemm_cfg_supported() tells whether a cfg serves a problem
+   *          workgroup, 8 = the same kernel with REGISTER-staged operand delivery (the loader wavefronts issue ordinary 16-byte global
+   *          loads, hold NBUF - 2 k-tiles of their share in VGPRs and ds_write_b128 each k-tile into its LDS slot one iteration before it
+   *          is read -- same LDS image and MFMA order as 7: bit-identical); mvd_gemm_cfg_supported() tells whether a cfg serves a problem
    *   order: 0 = n-fastest, 1 = m-fastest order of the output tiles over the 8 XCDs.
    * The host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
    * winner from then on (mvdfusion_amd/hip.py: autotune). */

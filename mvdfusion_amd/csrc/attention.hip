@@ -7,6 +7,9 @@
 //  * pixel_xattn_kernel : 1 query x D context tokens per pixel (DualAttnetionBlock attn2), VALU.
 //  * view_mha_kernel  : timm Attention core over the V reference views of GridAttn (sequence length V <= 16), VALU.
 //  * view_pool_kernel : weight_layer + softmax over V + weighted sum.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "common.hpp"
 #include "../../include/mvd_hip.h"
 
@@ -19,8 +22,19 @@ constexpr int KV_TILE = 64;
 // the MFMAs of tile t and written to LDS after them -- into the other buffer with one barrier per key tile (NBUF = 2, head dims
 // <= 64), or into the same buffer between two barriers (NBUF = 1: the wide heads, whose tiles would not leave room for two
 // workgroups per CU).  With QT = 2 the K / V^T fragments read from LDS feed two query tiles (half the LDS traffic per MFMA).
+// Scheduling hint for a region that holds NM MFMAs and independent VALU work: NM groups of [1 MFMA, NV VALU instructions]
+template <int G, int NM, int NV>
+__device__ __forceinline__ void mfma_valu_pattern() {
+  if constexpr (G < NM) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    mfma_valu_pattern<G + 1, NM, NV>();
+  }
+}
+
+// (second launch bound = wavefronts per SIMD the register allocation must leave room for: the head dims <= 64 run two workgroups per CU)
 template <int DQ, int DV, int NS, int QT, int NBUF>
-__global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
+__global__ __launch_bounds__(256, (DQ <= 64 ? 2 : 1)) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
                                                    const u16* __restrict__ k_hi, const u16* __restrict__ k_lo,
                                                    const u16* __restrict__ vt_hi, const u16* __restrict__ vt_lo,
                                                    u16* __restrict__ out_sp, int ldo, int H, int L, int Lk, int Lpad, int dhead) {
@@ -130,6 +144,174 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * KV_TILE, buf = NBUF == 2 ? (t & 1) : 0;
     if (t + 1 < ntiles) load_tile(kv0 + KV_TILE);      // in flight under the MFMAs below
+
+    if constexpr (QT == 2 && DQ <= 48) {
+      // ---- two query tiles per wavefront, PHASED (round 4): the softmax of one query tile is VALU work (max / exp2 / sum / hi+lo split:
+      //      ~140 instructions) and the products of the other one are MFMA work, so the k-tile runs as
+      //        A: S(q0) = K Q0^T                       (MFMA)
+      //        B: S(q1) = K Q1^T   ||  softmax(q0)     (MFMA || VALU, interleaved by the scheduling hints below)
+      //        C: O(q0) += V^T P0  ||  softmax(q1)
+      //        D: O(q1) += V^T P1                      (MFMA)
+      //      with every K fragment of the tile read from LDS up front (one round trip per tile instead of one per 8 MFMAs) and the V^T
+      //      fragments requested during phase B.  Per accumulator the MFMA order is the one of the un-phased loop (k-steps in order,
+      //      lo*lo, lo*hi, hi*lo, hi*hi, then the 16-deep tail), so the results are BIT-IDENTICAL to it -- and to the one-tile-per-wave
+      //      kernel (tests/test_gpu_ops.py::test_attention_phased_equals_single_tile).  Consecutive MFMAs hit different accumulators (the
+      //      four key sub-tiles / the DT output tiles) instead of the same one back to back.
+      constexpr int QSn = QS > 0 ? QS : 1;
+      op16x8 kfh[4][QSn], kfl[4][QSn];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int ks = 0; ks < QS; ++ks) {
+          kfh[kt][ks] = *(const op16x8*)&sK[buf][0][kt * 16 + c][ks * 32 + g * 8];
+          if (NS >= 3) kfl[kt][ks] = *(const op16x8*)&sK[buf][NPL - 1][kt * 16 + c][ks * 32 + g * 8];
+        }
+      }
+      auto phased = [&](auto rag_c) __attribute__((always_inline)) {
+      constexpr bool RAG = decltype(rag_c)::value;     // the ragged last tile (keys past Lk masked) is its own copy: the common tile stays ONE basic block
+      f32x4 s[QT][4];
+      auto qk_tile = [&](auto t2c) {
+        constexpr int t2 = decltype(t2c)::value;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[t2][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < QS; ++ks) {
+          if (NS == 4) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x32(kfl[kt][ks], ql[t2][ks], s[t2][kt], 0, 0, 0);
+          }
+          if (NS >= 3) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x32(kfl[kt][ks], qh[t2][ks], s[t2][kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x32(kfh[kt][ks], ql[t2][ks], s[t2][kt], 0, 0, 0);
+          }
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x32(kfh[kt][ks], qh[t2][ks], s[t2][kt], 0, 0, 0);
+        }
+        if (TAIL) {      // (the 16-channel tail fragments are read per query tile: 16 registers that need not live through phases A - B)
+          op4_t kh4[4], kl4[4];
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            kh4[kt] = *(const op4_t*)&sK[buf][0][kt * 16 + c][QS * 32 + g * 4];
+            if (NS >= 3) kl4[kt] = *(const op4_t*)&sK[buf][NPL - 1][kt * 16 + c][QS * 32 + g * 4];
+          }
+          if (NS == 4) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kl4[kt], qtl[t2], s[t2][kt]);
+          }
+          if (NS >= 3) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kl4[kt], qth[t2], s[t2][kt]);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kh4[kt], qtl[t2], s[t2][kt]);
+          }
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kh4[kt], qth[t2], s[t2][kt]);
+        }
+      };
+      op16x8 ph[QT][2], pl2[QT][2];
+      auto softmax_tile = [&](auto t2c) {
+        constexpr int t2 = decltype(t2c)::value;
+        if (RAG) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kv0 + kt * 16 + g * 4 + r >= Lk) s[t2][kt][r] = -INFINITY;
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[t2][kt][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run[t2], mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[t2] - m_new);
+        m_run[t2] = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s[t2][kt][r] = __builtin_amdgcn_exp2f(s[t2][kt][r] - m_new);
+            psum += s[t2][kt][r];
+          }
+        l_run[t2] = l_run[t2] * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[t2][i] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          union { op16x8 v; u16 e[8]; } H8, L8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float pv = j < 4 ? s[t2][2 * u][j] : s[t2][2 * u + 1][j - 4];
+            if (NS >= 3) {
+              split_op16(pv, H8.e[j], L8.e[j]);
+            } else {
+              H8.e[j] = to_op_bits(pv);
+            }
+          }
+          ph[t2][u] = H8.v;
+          if (NS >= 3) pl2[t2][u] = L8.v;
+        }
+      };
+      // (the V^T fragments of a 32-key half are read right before its MFMAs, once per query tile: holding all of them across phases
+      //  B - D costs 48 registers and the second wavefront per SIMD)
+      auto pv_tile = [&](auto t2c) {
+        constexpr int t2 = decltype(t2c)::value;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          op16x8 vfh[DT][2], vfl[DT][2];
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            union { op16x8 v; uint2 h2[2]; } VH, VL;
+            VH.h2[0] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 4 * g];
+            VH.h2[1] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 16 + 4 * g];
+            vfh[dt][u] = VH.v;
+            if (NS >= 3) {
+              VL.h2[0] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 4 * g];
+              VL.h2[1] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 16 + 4 * g];
+              vfl[dt][u] = VL.v;
+            }
+          }
+          if (NS == 4) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[t2][dt] = MVD_MFMA_16x16x32(vfl[dt][u], pl2[t2][u], o[t2][dt], 0, 0, 0);
+          }
+          if (NS >= 3) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[t2][dt] = MVD_MFMA_16x16x32(vfl[dt][u], ph[t2][u], o[t2][dt], 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[t2][dt] = MVD_MFMA_16x16x32(vfh[dt][u], pl2[t2][u], o[t2][dt], 0, 0, 0);
+          }
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[t2][dt] = MVD_MFMA_16x16x32(vfh[dt][u], ph[t2][u], o[t2][dt], 0, 0, 0);
+        }
+      };
+      using std::integral_constant;
+      constexpr int NQK = 4 * (QS * NS + (TAIL ? NS : 0));      // MFMAs of one S tile
+      constexpr int NPV = DT * 2 * NS;                           // MFMAs of one O update
+      // A
+      qk_tile(integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      // B: the MFMAs of S(q1) with the softmax of q0 between them (4 VALU slots per 16-cycle MFMA), V^T fragment reads sprinkled in
+      qk_tile(integral_constant<int, 1>{});
+      softmax_tile(integral_constant<int, 0>{});
+      if (!RAG) mfma_valu_pattern<0, NQK, 4>();
+      __builtin_amdgcn_sched_barrier(0);
+      // C
+      pv_tile(integral_constant<int, 0>{});
+      softmax_tile(integral_constant<int, 1>{});
+      if (!RAG) mfma_valu_pattern<0, NPV, 5>();
+      __builtin_amdgcn_sched_barrier(0);
+      // D
+      pv_tile(integral_constant<int, 1>{});
+      };
+      if (kv0 + KV_TILE > Lk) phased(std::integral_constant<bool, true>{});
+      else phased(std::integral_constant<bool, false>{});
+    } else {
     // ---- S^T = K Q^T for every query tile of the wave: s[t2][kt][r] = S[q = c of tile t2][key = kv0 + kt*16 + g*4 + r].  The K
     //      fragments are read from LDS ONCE per key sub-tile and feed all QT query tiles (tiles past L compute on zero / padding rows
     //      and are never stored: no branches in the loop body, one basic block to schedule).
@@ -256,6 +438,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ q_hi,
         for (int t2 = 0; t2 < QT; ++t2) o[t2][dt] = MVD_MFMA_16x16x32(VH.v, ph[t2][u], o[t2][dt], 0, 0, 0);
       }
     }
+    }      // (un-phased body)
     if (NBUF == 2) {
       if (t + 1 < ntiles) write_tile(buf ^ 1);         // the other buffer: its readers finished before the previous barrier
       __syncthreads();
@@ -446,7 +629,9 @@ int launch_attn(const void* q_hi, const void* q_lo, const void* k_hi, const void
   const int dq = mvd_attn_dpad(dhead), dv = mvd_attn_dpad(dhead);
   // two query tiles per wavefront once that still leaves >= 2 workgroups per CU (long sequences); small heads only
   const long wg2 = (long)((Lpad + 127) / 128) * H * B;
-  const bool two = dq <= 96 && wg2 >= 512;
+  // (MVD_ATTN_QT1=1: debugging knob -- always the one-tile-per-wavefront kernel, whose per-query arithmetic the two-tile kernel must
+  //  reproduce bit for bit: tests/test_gpu_ops.py::test_attention_phased_equals_single_tile)
+  const bool two = dq <= 96 && wg2 >= 512 && getenv("MVD_ATTN_QT1") == nullptr;
   const dim3 block(256);
 #define MVD_ATTN_CASE(DQ, DV)                                                                                            \
   if (dq == DQ && dv == DV) {                                                                                            \

@@ -985,7 +985,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 //   before barrier B_t : loaders have waited until THEIR share of k-tile t+1 landed; consumers until their reads of k-tile t returned
 //   after  barrier B_t : loaders stage k-tile t+NBUF into the buffer of k-tile t (its fragments sit in registers), then wait for k-tile
 //                        t+2 (the NBUF-2 newer stages stay in flight); consumers read the fragments of k-tile t+1 and run the MFMAs of t.
-template <int BM, int BN, int CM, int CN, int NS, int AMODE>
+// LM (loader mode): 0 = LDS-DMA (global_load_lds_dwordx4, counted vmcnt); 1 = through REGISTERS: the loader wavefronts issue ordinary
+// global_load_dwordx4 for k-tile t + NBUF, keep NBUF - 2 k-tiles of their share in VGPRs (the consumers' register allocation is
+// kernel-wide: the loaders have ~160 idle registers) and write a k-tile into its LDS slot with ds_write_b128 one iteration before the
+// consumers read it.  Same LDS image, same barriers, same MFMA order => bit-identical; the tuner decides per shape which delivery
+// path is faster (LDS-DMA: ~1 KiB per 60-185 issue cycles and wave; ds_write_b128: ~13 cycles per KiB-instruction).
+template <int BM, int BN, int CM, int CN, int NS, int AMODE, int LM = 0>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
   constexpr int NC = CM * CN, NL = 4;
   static_assert(NC == 4, "four consumer wavefronts (one per SIMD) + four loader wavefronts");
@@ -1130,6 +1135,90 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
         for (int i = 0; i < AI; ++i) a_off[i] = s_tab[a_tab[i] + c_tap];
       }
     };
+    if constexpr (LM == 1) {
+      // ---- register-staged delivery.  RD = NBUF - 2 register stages: stage j % RD holds k-tile j from its issue (iteration j - NBUF,
+      //      right after barrier B_{j-NBUF}: slot j % NBUF is free then) until it is written to LDS in iteration j - 2 (before barrier
+      //      B_{j-1}, after which the consumers read it).  The loop is unrolled by RD so that every register stage is a compile-time index.
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+      constexpr int RD = NBUF - 2;
+      u32x4 regs[RD][LPS];
+      auto fetch = [&](auto rs_c) {                  // issue the loads of the next k-tile (consecutive calls walk kt0, kt0 + 1, ...)
+        constexpr int RS = decltype(rs_c)::value;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+          const u16* src;
+          if (AMODE == MVD_A_DENSE) {
+            src = a_cur[i];
+            a_cur[i] += a_step[i];
+          } else {
+            src = a_off[i] >= 0 ? (const u16*)d.A + (unsigned)(a_off[i] + c_cb * 64 + a_chunk[i]) : zero;
+          }
+          regs[RS][i] = *(const u32x4*)src;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+          regs[RS][AI + i] = *(const u32x4*)b_cur[i];
+          b_cur[i] += b_step[i];
+        }
+        if (AMODE != MVD_A_DENSE) {
+          if (++c_tap == 9) {
+            c_tap = 0;
+            ++c_cb;
+          }
+#pragma unroll
+          for (int i = 0; i < AI; ++i) a_off[i] = s_tab[a_tab[i] + c_tap];
+        }
+      };
+      auto put = [&](auto rs_c, int buf) {           // this wave's granules of one k-tile: registers -> LDS slot `buf` (lane-linear 1 KiB each)
+        constexpr int RS = decltype(rs_c)::value;
+        unsigned char* sbase = smem + buf * STAGE + lane * 16;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *(u32x4*)(sbase + (lw + i * NL) * 1024) = regs[RS][i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *(u32x4*)(sbase + (A_GRAN + lw + i * NL) * 1024) = regs[RS][AI + i];
+      };
+      using std::integral_constant;
+      // prologue: k-tiles 0 and 1 go straight to LDS, k-tiles 2 .. NBUF - 1 wait in the register stages (k-tile j in stage j % RD)
+      if (0 < nkt) {
+        fetch(integral_constant<int, 0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        put(integral_constant<int, 0>{}, 0);
+      }
+      if (1 < nkt) {
+        fetch(integral_constant<int, 0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        put(integral_constant<int, 0>{}, 1);
+      }
+      unroll_steps<0, RD>([&](auto j) {
+        constexpr int J = decltype(j)::value;
+        if (2 + J < nkt) fetch(integral_constant<int, (2 + J) % RD>{});
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                  // barrier P: k-tiles 0 and 1 written
+      // iteration `it` (after B_it): write k-tile it + 2 (stage (it + 2) % RD, the OLDEST loads in flight) into slot (it + 2) % NBUF, then
+      // refill that stage with k-tile it + NBUF (slot it % NBUF was released by B_it; the stage by the write just issued)
+      int it = 0, wslot = 2 % NBUF;
+      auto body = [&](auto rs_c, int itx) {
+        asm volatile("s_barrier" ::: "memory");                                            // B_itx
+        if (itx + 2 < nkt) {
+          // loads in flight: k-tiles itx + 2 .. min(itx + NBUF - 1, nkt - 1): the oldest must have returned
+          const int newer = (itx + NBUF - 1 < nkt ? NBUF - 1 : nkt - 1 - itx) - 2;         // stages issued after it (0 .. RD - 1)
+          if (newer >= RD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((RD - 1) * LPS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          put(rs_c, wslot);
+        }
+        if (itx + NBUF < nkt) fetch(rs_c);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 // the writes landed before B_{itx+1}
+        wslot = wslot + 1 == NBUF ? 0 : wslot + 1;
+      };
+      for (; it < nkt; it += RD) {
+        unroll_steps<0, RD>([&](auto j) {
+          constexpr int J = decltype(j)::value;
+          if (it + J < nkt) body(integral_constant<int, (2 + J) % RD>{}, it + J);
+        });
+      }
+      __syncthreads();
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NBUF; ++q)
       if (q < nkt) stage(q);
@@ -1151,6 +1240,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
   }
 
   // ================================================================== CONSUMER wavefronts
+#if defined(MVD_WS_VARIANT) && (MVD_WS_VARIANT & 2)
+  __builtin_amdgcn_s_setprio(3);      // (probe build: the MFMA stream outranks its SIMD's loader wavefront at the issue arbiter)
+#endif
   const int cm = wave / CN, cn = wave % CN;
   if (AMODE == MVD_A_DENSE && d.ln_stats != nullptr && tid < BM) {       // LayerNorm fold: {mean, rstd} of the tile's rows (BM <= 256 threads)
     const float2 st = m0 + tid < d.M ? ln_row_stats(d, m0 + tid) : make_float2(0.f, 0.f);
@@ -1220,6 +1312,11 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
       constexpr int NM = TM * TN * NS, NR = (TM + TN) * (NS >= 3 ? 2 : 1);
       sched_reads_early<0, NR, NM>();
     }
+#if defined(MVD_WS_VARIANT) && (MVD_WS_VARIANT & 1)
+    // (probe build, tools/probes/ws_variants.sh: keep every MFMA of a k-tile in front of the next k-tile's barrier -- without it the
+    //  scheduler sinks about half of them behind it, so the barriers of a pair of k-tiles sit 20 and 60 MFMAs apart)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     br = br + 1 == NBUF ? 0 : br + 1;
   };
   using std::integral_constant;
@@ -1604,13 +1701,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmParams p) 
   gn_stats_add(d.gn_stats, m0 / d.gn_hw, g, d.gn_groups, ss, qq);
 }
 
-// Tile configurations (mvd_gemm_desc.cfg = 1 + 16 * tile + 2 * loop + order; 0 = built-in heuristic).
+// Tile configurations (mvd_gemm_desc.cfg = 1 + MVD_GEMM_CFG_STRIDE * tile + 2 * loop + order; 0 = built-in heuristic).
 //   tile : 0 = 64x64 (2x2 waves)  1 = 128x128 (2x4)  2 = 128x80 (4x1)  3 = 64x80 (4x1)  4 = 128x160 (4x2)
 //          (a 256x128 tile -- 128x32 wave tiles, 64 MFMAs per k-tile and wave against 20 fragment reads and 6 DMAs -- was built and
 //          measured in round 3: equal or slower on every shape of the step, profiles/r03_gemm_tile256_probe.log; dropped)
 //   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop, 2 = staggered wave groups, 3 LDS buffers (8-wave tiles 1 and
 //          4 only), 3 = staggered, 4 LDS buffers (tile 1 only: 128 KiB), 4 = register-pipelined loop over a ring of <= 4 LDS buffers,
-//          5 = over a ring of <= 8 (4-wave tiles 0, 2, 3 only: the 8-wave tiles fit 4), 6 = conv_patch_kernel (stride-1 3x3 convolutions, tiles 1, 2, 4)
+//          5 = over a ring of <= 8 (4-wave tiles 0, 2, 3 only: the 8-wave tiles fit 4), 6 = conv_patch_kernel (stride-1 3x3 convolutions, tiles 1, 2, 4),
+//          7 = gemm_ws_kernel (consumer / loader wavefronts, LDS-DMA delivery), 8 = gemm_ws_kernel with register-staged delivery (LM = 1)
 //   order : 0 = n-fastest tile order, 1 = m-fastest
 // The 80-column family serves MVD_EPI_STORE only (GEGLU / QKV epilogues address 32-column wave tiles).
 struct TileInfo {
@@ -1664,17 +1762,17 @@ void launch_cfg(GemmParams& p, hipStream_t s) {
   if (conv && ns == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, MVD_A_CONV3X3, STAGES>), grid, block, 0, s, p);
 }
 
-template <int BM, int BN, int CM, int CN>
+template <int BM, int BN, int CM, int CN, int LM = 0>
 void launch_ws(GemmParams& p, hipStream_t s) {
   dim3 grid(p.tiles_n * p.tiles_m, 1, p.splits), block(512);
   const bool conv = p.d.a_mode == MVD_A_CONV3X3;
   const int ns = p.d.prec;
-  if (!conv && ns == 4) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 4, MVD_A_DENSE>), grid, block, 0, s, p);
-  if (!conv && ns == 3) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 3, MVD_A_DENSE>), grid, block, 0, s, p);
-  if (!conv && ns == 1) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 1, MVD_A_DENSE>), grid, block, 0, s, p);
-  if (conv && ns == 4) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 4, MVD_A_CONV3X3>), grid, block, 0, s, p);
-  if (conv && ns == 3) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 3, MVD_A_CONV3X3>), grid, block, 0, s, p);
-  if (conv && ns == 1) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 1, MVD_A_CONV3X3>), grid, block, 0, s, p);
+  if (!conv && ns == 4) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 4, MVD_A_DENSE, LM>), grid, block, 0, s, p);
+  if (!conv && ns == 3) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 3, MVD_A_DENSE, LM>), grid, block, 0, s, p);
+  if (!conv && ns == 1) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 1, MVD_A_DENSE, LM>), grid, block, 0, s, p);
+  if (conv && ns == 4) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 4, MVD_A_CONV3X3, LM>), grid, block, 0, s, p);
+  if (conv && ns == 3) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 3, MVD_A_CONV3X3, LM>), grid, block, 0, s, p);
+  if (conv && ns == 1) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, CM, CN, 1, MVD_A_CONV3X3, LM>), grid, block, 0, s, p);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1703,8 +1801,8 @@ static int patch_shares(const mvd_gemm_desc& d, const TileInfo& ti) {
 
 static bool cfg_supported(const mvd_gemm_desc& d, int cfg) {
   if (cfg == 0) return true;
-  if (cfg < 0 || cfg > 16 * MVD_GEMM_TILES) return false;
-  const int tile = (cfg - 1) / 16, loop = ((cfg - 1) % 16) >> 1;
+  if (cfg < 0 || cfg > MVD_GEMM_CFG_STRIDE * MVD_GEMM_TILES) return false;
+  const int tile = (cfg - 1) / MVD_GEMM_CFG_STRIDE, loop = ((cfg - 1) % MVD_GEMM_CFG_STRIDE) >> 1;
   if (loop >= MVD_GEMM_LOOPS) return false;
   if (tile >= 2 && d.epi != MVD_EPI_STORE) return false;
   const int waves = kTiles[tile].waves;
@@ -1712,7 +1810,7 @@ static bool cfg_supported(const mvd_gemm_desc& d, int cfg) {
   if (loop == 3 && tile != 1) return false;
   if (loop == 5 && waves != 4) return false;
   if (loop == 6) return (tile == 1 || tile == 2 || tile == 4) && patch_shares(d, kTiles[tile]) > 0;
-  if (loop == 7) return (tile == 1 || tile == 2 || tile == 4) && d.epi == MVD_EPI_STORE;
+  if (loop == 7 || loop == 8) return (tile == 1 || tile == 2 || tile == 4) && d.epi == MVD_EPI_STORE;
   return true;
 }
 
@@ -1788,10 +1886,10 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   p.nt16 = d.N / 16;
   // ---- kernel configuration: explicit (cfg >= 1) or the built-in heuristic (128x128 once the grid fills the chip, else 64x64)
   int tile, loop = 0, order = -1;
-  MVD_CHECK_ARG(d.cfg >= 0 && d.cfg <= 16 * MVD_GEMM_TILES, "mvd_gemm: bad cfg %d", d.cfg);
+  MVD_CHECK_ARG(d.cfg >= 0 && d.cfg <= MVD_GEMM_CFG_STRIDE * MVD_GEMM_TILES, "mvd_gemm: bad cfg %d", d.cfg);
   if (d.cfg >= 1) {
-    tile = (d.cfg - 1) / 16;
-    loop = ((d.cfg - 1) % 16) >> 1;
+    tile = (d.cfg - 1) / MVD_GEMM_CFG_STRIDE;
+    loop = ((d.cfg - 1) % MVD_GEMM_CFG_STRIDE) >> 1;
     order = (d.cfg - 1) & 1;
     MVD_CHECK_ARG(cfg_supported(d, d.cfg), "mvd_gemm: cfg %d (tile %d, loop %d) does not serve this problem (include/mvd_hip.h: cfg)", d.cfg, tile,
                   loop);
@@ -1826,34 +1924,37 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   if (loop == 6) p.kt_per_split = 9 * cdiv(p.nk / 9, splits);       // conv_patch_kernel: a split is a run of whole channel blocks
   p.splits = cdiv(p.nk, p.kt_per_split);
   hipStream_t s = (hipStream_t)stream;
-  switch (tile * 8 + loop) {
+  switch (tile * 16 + loop) {
     case 0: launch_cfg<64, 64, 2, 2, 2>(p, s); break;
     case 1: launch_cfg<64, 64, 2, 2, 3>(p, s); break;
     case 4: launch_cfg<64, 64, 2, 2, 6>(p, s); break;
     case 5: launch_cfg<64, 64, 2, 2, 7>(p, s); break;
-    case 8: launch_cfg<128, 128, 2, 4, 2>(p, s); break;
-    case 9: launch_cfg<128, 128, 2, 4, 3>(p, s); break;
-    case 10: launch_cfg<128, 128, 2, 4, 4>(p, s); break;
-    case 11: launch_cfg<128, 128, 2, 4, 5>(p, s); break;
-    case 12: launch_cfg<128, 128, 2, 4, 6>(p, s); break;
-    case 16: launch_cfg<128, 80, 4, 1, 2>(p, s); break;
-    case 17: launch_cfg<128, 80, 4, 1, 3>(p, s); break;
-    case 20: launch_cfg<128, 80, 4, 1, 6>(p, s); break;
-    case 21: launch_cfg<128, 80, 4, 1, 7>(p, s); break;
-    case 24: launch_cfg<64, 80, 4, 1, 2>(p, s); break;
-    case 25: launch_cfg<64, 80, 4, 1, 3>(p, s); break;
-    case 28: launch_cfg<64, 80, 4, 1, 6>(p, s); break;
-    case 29: launch_cfg<64, 80, 4, 1, 7>(p, s); break;
-    case 32: launch_cfg<128, 160, 4, 2, 2>(p, s); break;
-    case 33: launch_cfg<128, 160, 4, 2, 3>(p, s); break;
-    case 34: launch_cfg<128, 160, 4, 2, 4>(p, s); break;
-    case 36: launch_cfg<128, 160, 4, 2, 6>(p, s); break;
-    case 14: launch_patch<128, 128, 2, 4>(p, s, patch_shares(d, ti)); break;
-    case 22: launch_patch<128, 80, 4, 1>(p, s, patch_shares(d, ti)); break;
-    case 38: launch_patch<128, 160, 4, 2>(p, s, patch_shares(d, ti)); break;
-    case 15: launch_ws<128, 128, 2, 2>(p, s); break;
-    case 23: launch_ws<128, 80, 4, 1>(p, s); break;
-    case 39: launch_ws<128, 160, 2, 2>(p, s); break;
+    case 16: launch_cfg<128, 128, 2, 4, 2>(p, s); break;
+    case 17: launch_cfg<128, 128, 2, 4, 3>(p, s); break;
+    case 18: launch_cfg<128, 128, 2, 4, 4>(p, s); break;
+    case 19: launch_cfg<128, 128, 2, 4, 5>(p, s); break;
+    case 20: launch_cfg<128, 128, 2, 4, 6>(p, s); break;
+    case 32: launch_cfg<128, 80, 4, 1, 2>(p, s); break;
+    case 33: launch_cfg<128, 80, 4, 1, 3>(p, s); break;
+    case 36: launch_cfg<128, 80, 4, 1, 6>(p, s); break;
+    case 37: launch_cfg<128, 80, 4, 1, 7>(p, s); break;
+    case 48: launch_cfg<64, 80, 4, 1, 2>(p, s); break;
+    case 49: launch_cfg<64, 80, 4, 1, 3>(p, s); break;
+    case 52: launch_cfg<64, 80, 4, 1, 6>(p, s); break;
+    case 53: launch_cfg<64, 80, 4, 1, 7>(p, s); break;
+    case 64: launch_cfg<128, 160, 4, 2, 2>(p, s); break;
+    case 65: launch_cfg<128, 160, 4, 2, 3>(p, s); break;
+    case 66: launch_cfg<128, 160, 4, 2, 4>(p, s); break;
+    case 68: launch_cfg<128, 160, 4, 2, 6>(p, s); break;
+    case 22: launch_patch<128, 128, 2, 4>(p, s, patch_shares(d, ti)); break;
+    case 38: launch_patch<128, 80, 4, 1>(p, s, patch_shares(d, ti)); break;
+    case 70: launch_patch<128, 160, 4, 2>(p, s, patch_shares(d, ti)); break;
+    case 23: launch_ws<128, 128, 2, 2>(p, s); break;
+    case 39: launch_ws<128, 80, 4, 1>(p, s); break;
+    case 71: launch_ws<128, 160, 2, 2>(p, s); break;
+    case 24: launch_ws<128, 128, 2, 2, 1>(p, s); break;
+    case 40: launch_ws<128, 80, 4, 1, 1>(p, s); break;
+    case 72: launch_ws<128, 160, 2, 2, 1>(p, s); break;
     default: MVD_CHECK_ARG(false, "mvd_gemm: no kernel for tile %d loop %d", tile, loop);
   }
   MVD_CHECK_LAUNCH("mvd_gemm");

@@ -429,21 +429,24 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     return out
 
 
-# mvd_gemm_desc.cfg = 1 + 16 * tile + 2 * loop + order (include/mvd_hip.h)
+# mvd_gemm_desc.cfg = 1 + CFG_STRIDE * tile + 2 * loop + order (include/mvd_hip.h: MVD_GEMM_CFG_STRIDE)
+CFG_STRIDE = 32
+TUNE_CACHE_VERSION = 4             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
-GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch", "ws")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
+GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch", "ws", "ws-reg")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
                                  # (3 / 4 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
                                  # (stride-1 3x3 convolutions: the input patch is staged once per channel block)
 PATCH_LOOP = 6
 WS_LOOP = 7                      # gemm_ws_kernel: consumer / loader wavefront roles (tiles 1, 2, 4; EPI_STORE)
+WSR_LOOP = 8                     # ... with register-staged operand delivery (global_load -> VGPR -> ds_write_b128) instead of LDS-DMA
 
 
 def _cfg_parts(cfg):
-    return (cfg - 1) // 16, ((cfg - 1) % 16) >> 1, (cfg - 1) & 1          # tile, loop, order
+    return (cfg - 1) // CFG_STRIDE, ((cfg - 1) % CFG_STRIDE) >> 1, (cfg - 1) & 1          # tile, loop, order
 
 
 def make_cfg(tile, loop, order=0):
-    return 1 + 16 * tile + 2 * loop + order
+    return 1 + CFG_STRIDE * tile + 2 * loop + order
 
 
 def _cfg_valid(cfg, epi, b_mode=0):
@@ -454,10 +457,10 @@ def _cfg_valid(cfg, epi, b_mode=0):
     waves = wm * wn
     return (loop not in (2, 3) or waves == 8) and (loop != 3 or tile == 1) and (loop != 5 or waves == 4) and \
         (loop != PATCH_LOOP or tile in (1, 2, 4)) and (tile < 2 or epi == EPI_STORE) and \
-        (loop != WS_LOOP or (tile in (1, 2, 4) and epi == EPI_STORE))
+        (loop not in (WS_LOOP, WSR_LOOP) or (tile in (1, 2, 4) and epi == EPI_STORE))
 
 
-_ALL_CONFIGS = tuple(c for c in range(1, 16 * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
+_ALL_CONFIGS = tuple(c for c in range(1, CFG_STRIDE * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
 GEMM_CONFIGS = tuple(c for c in _ALL_CONFIGS if _cfg_parts(c)[1] != PATCH_LOOP)       # serve every problem kind (dense and conv)
 PATCH_CONFIGS = tuple(c for c in _ALL_CONFIGS if _cfg_parts(c)[1] == PATCH_LOOP)      # stride-1 padded 3x3 convolutions only
 GEMM_CONFIGS_CONV = GEMM_CONFIGS + PATCH_CONFIGS
@@ -484,9 +487,9 @@ def kernel_symbol(cfg, prec, conv):
     bm, bn, wm, wn = GEMM_TILES[tile]
     if loop == PATCH_LOOP:
         return f"conv_patch_kernel<{bm}, {bn}, {wm}, {wn}, {prec}>"
-    if loop == WS_LOOP:
+    if loop in (WS_LOOP, WSR_LOOP):
         cm, cn = {1: (2, 2), 2: (4, 1), 4: (2, 2)}[tile]
-        return f"gemm_ws_kernel<{bm}, {bn}, {cm}, {cn}, {prec}, {1 if conv else 0}>"
+        return f"gemm_ws_kernel<{bm}, {bn}, {cm}, {cn}, {prec}, {1 if conv else 0}, {1 if loop == WSR_LOOP else 0}>"
     return f"gemm_kernel<{bm}, {bn}, {wm}, {wn}, {prec}, {1 if conv else 0}, {GEMM_LOOPS[loop]}>"
 
 
@@ -495,14 +498,27 @@ def save_tuned(path):
     counter passes of one profiling session -- launch identical kernels."""
     import json
     with open(path, "w") as f:
-        json.dump([[list(k), list(v)] for k, v in _TUNED.items()], f)
+        json.dump({"version": TUNE_CACHE_VERSION, "cfg_stride": CFG_STRIDE, "operand_format": OPERAND_FORMAT,
+                   "entries": [[list(k), list(v)] for k, v in _TUNED.items()]}, f)
 
 
 def load_tuned(path):
+    """Load a cache written by save_tuned.  A file of another encoding (version / cfg stride / operand format) is REJECTED as a whole,
+    and entries whose cfg is not a valid configuration of this build are dropped (an old cache must never launch the wrong
+    kernels silently).  Returns the number of entries taken."""
     import json
-    for k, v in json.load(open(path)):
+    doc = json.load(open(path))
+    if not isinstance(doc, dict) or doc.get("version") != TUNE_CACHE_VERSION or doc.get("cfg_stride") != CFG_STRIDE or \
+            doc.get("operand_format") != OPERAND_FORMAT:
+        return 0
+    n = 0
+    for k, v in doc["entries"]:
+        cfg = int(v[0])
+        if cfg != 0 and not (1 <= cfg <= CFG_STRIDE * len(GEMM_TILES) and _cfg_parts(cfg)[1] < len(GEMM_LOOPS)):
+            continue
         _TUNED[tuple(k)] = tuple(v)
-    return len(_TUNED)
+        n += 1
+    return n
 
 
 LAST_CFG = 0

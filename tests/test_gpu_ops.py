@@ -469,6 +469,41 @@ def test_qkv_gemm_and_attention(hip, prec, B, H, L, d):
         assert rel_err(planes_to_float(out), ref) < 2 * TOL[prec] + PL
 
 
+@pytest.mark.parametrize("prec", [4, 3, 1])
+@pytest.mark.parametrize("B,H,L,Lk,d", [(8, 8, 1024, 0, 40), (8, 8, 1024, 1000, 40), (16, 8, 640, 0, 32), (8, 8, 1024, 999, 4), (8, 8, 1024, 0, 80)])
+def test_attention_phased_equals_single_tile(hip, prec, B, H, L, Lk, d):
+    """Long sequences run two query tiles per wavefront; for head dims <= 48 (the UNet's 40-channel heads at 32^2 and 64^2 latents) in
+    PHASES -- S(q0) | S(q1) || softmax(q0) | PV(q0) || softmax(q1) | PV(q1), all K fragments of a key tile read up front -- with the
+    per-accumulator MFMA order of the one-tile kernel: the outputs must be BIT-IDENTICAL to it (MVD_ATTN_QT1=1 forces the one-tile
+    kernel), including the ragged last key tile (Lk keys < L rows) and the head dims without a full 32-channel step (d = 4)."""
+    import os
+    C = H * d
+    x = torch.randn(B * L, C, generator=g(140)) * 1.3
+    w = torch.randn(3 * C, C, generator=g(141)) / math.sqrt(C) * 1.5
+    Wp = hip.pack_linear(w.cuda())
+    planes = hip.alloc_attn_planes(B, H, L, d, "cuda")
+    ws = torch.empty(16 * 1024 * 1024, device="cuda")
+    hip.gemm(hip.split_planes(x.cuda()), Wp, None, prec=4, epi=hip.EPI_QKV, qkv=dict(planes=planes, heads=H, dhead=d, L=L), workspace=ws)
+    outs = []
+    for force in (False, True):
+        if force:
+            os.environ["MVD_ATTN_QT1"] = "1"
+        try:
+            out = hip.planes_like(B * L, C, "cuda")
+            out.zero_()
+            hip.attention(planes, out, B, H, L, d, prec=prec, Lkeys=Lk)
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        finally:
+            os.environ.pop("MVD_ATTN_QT1", None)
+    assert torch.equal(outs[0], outs[1])
+    q, k, v = (F.linear(x, w[i * C:(i + 1) * C]).view(B, L, H, d).permute(0, 2, 1, 3) for i in range(3))
+    kk = Lk or L
+    sim = torch.einsum("bhid,bhjd->bhij", q, k[:, :, :kk]) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v[:, :, :kk]).permute(0, 2, 1, 3).reshape(B * L, C)
+    assert rel_err(planes_to_float(outs[0]), ref) < 2 * TOL[prec] + PL
+
+
 @pytest.mark.parametrize("pcfg,psplit", [(0, 1), (_hip.make_cfg(2, 1), 1), (_hip.make_cfg(1, 0), 1), (_hip.make_cfg(3, 4), 1), (0, 3)])
 @pytest.mark.parametrize("B,L,H,d,offs", [(2, 256, 8, 40, 0.0), (1, 64, 8, 160, 3.0), (3, 32, 4, 24, -1.5)])
 def test_gemm_layernorm_fold(hip, pcfg, psplit, B, L, H, d, offs):
