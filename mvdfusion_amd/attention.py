@@ -195,7 +195,7 @@ class SpatialTransformer(nn.Module):
         n = ctx.ws.planes("tf.n", M, C)
         ctx.groupnorm(x, n, self.norm, B, L, C, silu=False)
         t = ctx.ws.get("tf.t", (M, C))
-        fold = ctx.ln_fold
+        fold = ctx.ln_fold_enabled()
         tp, rs1, rs2 = (ctx.ws.planes("tf.tp", M, C), ctx.row_stats("tf.rs1", M, C), ctx.row_stats("tf.rs2", M, C)) if fold else (None,) * 3
         ctx.gemm(n, w_in, t, out_planes=tp, row_stats=rs1, kind="proj")
         o = tb.self_attn(ctx, t, B, L, "tf", t_planes=tp, t_stats=rs1)
@@ -261,7 +261,7 @@ class ViewAlignedFeatureTransformer(nn.Module):
         n = ctx.ws.planes("tf.n", M, C)
         ctx.groupnorm(x, n, self.aligned_attn_norm, B, L, C, silu=False)
         t = ctx.ws.get("tf.t", (M, C))
-        fold = ctx.ln_fold
+        fold = ctx.ln_fold_enabled()
         tp, rs1, rs2 = (ctx.ws.planes("tf.tp", M, C), ctx.row_stats("tf.rs1", M, C), ctx.row_stats("tf.rs2", M, C)) if fold else (None,) * 3
         ctx.gemm(n, w_in, t, out_planes=tp, row_stats=rs1, kind="proj")
         t2b = ctx.ws.get("tf.t2b", (M, C))

@@ -24,7 +24,10 @@ UNET_PARAMS = dict(image_size=32, in_channels=10, out_channels=5, model_channels
                    use_view_aligned_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=True,
                    legacy=False)
 
-DEFAULT_PRECISION = "f16x4"
+# fp16 hi + lo operand split, three partial products (lo*lo dropped: a 2^-22 relative term, below the fp32 accumulation noise).  The
+# per-layer-class sweep of round 4 (tools/prec_sweep.py) puts every x3 / x4 assignment inside the run-to-run
+# spread of the chaotic 50-step trajectory (0.8 - 3.6e-4 latent RMSE vs the float64 evaluation, tolerance 1e-3) at -7 % time.
+DEFAULT_PRECISION = "f16x3"
 
 
 def model_config(mc=320, D=1, S=32, precision=None, **overrides):

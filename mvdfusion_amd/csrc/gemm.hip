@@ -253,27 +253,45 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       bv = *(const float4*)(d.bias + col);
       bg = *(const float4*)(d.bias + half + col);
     }
-#pragma unroll 1
-    for (int ps = 0; ps < WTM / 16; ++ps) {
-      const int row = ps * 16 + (lane >> 2);
-      const int m = wm0 + row;
-      if (m >= d.M) continue;
-      float4 v = *(const float4*)(sC + row * LDW + q);
-      float4 g = *(const float4*)(sC + row * LDW + 16 + q);
-      v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
-      g.x *= d.acc_scale; g.y *= d.acc_scale; g.z *= d.acc_scale; g.w *= d.acc_scale;
-      if (lnf) {
-        const float mean = sR[row * 2], rstd = sR[row * 2 + 1];
-        v.x = (v.x - mean * sv.x) * rstd; v.y = (v.y - mean * sv.y) * rstd; v.z = (v.z - mean * sv.z) * rstd; v.w = (v.w - mean * sv.w) * rstd;
-        g.x = (g.x - mean * sg.x) * rstd; g.y = (g.y - mean * sg.y) * rstd; g.z = (g.z - mean * sg.z) * rstd; g.w = (g.w - mean * sg.w) * rstd;
-      }
-      if (d.bias) {
+    // Two passes like MVD_EPI_STORE below: every chunk's value first (LDS reads + arithmetic, no global access), then all the stores.
+    // As one rolled load - compute - store loop the compiler put `s_waitcnt vmcnt(0)` at the loop head (the bias / column-sum loads merge
+    // with the loop's stores on the back edge), i.e. every chunk waited for the ACKNOWLEDGEMENT of the previous chunk's stores -- ~1 300
+    // cycles when all CUs store at once, four times per 64-row wave tile, about half of this epilogue (round 4, ISA inspection).
+    // No run-time branch inside the chunk loop: the LayerNorm fold is a compile-time flag of the lambda and an absent bias adds the zero
+    // vector (exact) -- with `if (lnf)` / `if (d.bias)` per chunk every chunk was a chain of small basic blocks, each waiting for its
+    // own LDS reads.
+    constexpr int NCH = WTM / 16;
+    float4 gv[NCH];
+    const float scale = d.acc_scale;
+    auto geglu_values = [&](auto lnf_c) {
+      constexpr bool LNF = decltype(lnf_c)::value;
+#pragma unroll
+      for (int ps = 0; ps < NCH; ++ps) {
+        const int row = ps * 16 + (lane >> 2);
+        float4 v = *(const float4*)(sC + row * LDW + q);
+        float4 g = *(const float4*)(sC + row * LDW + 16 + q);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
+        if (LNF) {
+          const float mean = sR[row * 2], rstd = sR[row * 2 + 1];
+          v.x = (v.x - mean * sv.x) * rstd; v.y = (v.y - mean * sv.y) * rstd; v.z = (v.z - mean * sv.z) * rstd; v.w = (v.w - mean * sv.w) * rstd;
+          g.x = (g.x - mean * sg.x) * rstd; g.y = (g.y - mean * sg.y) * rstd; g.z = (g.z - mean * sg.z) * rstd; g.w = (g.w - mean * sg.w) * rstd;
+        }
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
+        v.x *= gelu_erf(g.x); v.y *= gelu_erf(g.y); v.z *= gelu_erf(g.z); v.w *= gelu_erf(g.w);
+        gv[ps] = v;
       }
-      v.x *= gelu_erf(g.x); v.y *= gelu_erf(g.y); v.z *= gelu_erf(g.z); v.w *= gelu_erf(g.w);
-      if (d.out) *(float4*)(d.out + (size_t)m * d.ldo + col) = v;
-      if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, col, v.x, v.y, v.z, v.w);
+    };
+    if (lnf) geglu_values(std::integral_constant<bool, true>{});
+    else geglu_values(std::integral_constant<bool, false>{});
+#pragma unroll
+    for (int ps = 0; ps < NCH; ++ps) {
+      const int m = wm0 + ps * 16 + (lane >> 2);
+      if (m < d.M) {
+        if (d.out) *(float4*)(d.out + (size_t)m * d.ldo + col) = gv[ps];
+        if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, col, gv[ps].x, gv[ps].y, gv[ps].z, gv[ps].w);
+      }
     }
     MVD_STAMP_AT(d, wave, 9);
     MVD_STAMP_AT(d, wave, 6);
@@ -294,20 +312,34 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), cs = bb;
       if (d.bias) bb = *(const float4*)(d.bias + n);        // in_proj bias (nn.MultiheadAttention, timm qkv_bias); SD attention has none
       if (lnf) cs = *(const float4*)(d.ln_colsum + n);
-#pragma unroll 1
-      for (int ps = 0; ps < WTM / 8; ++ps) {
-        const int row = ps * 8 + (lane >> 3);
-        const int m = wm0 + row;
-        if (m >= d.M) continue;
-        float4 v = *(const float4*)(sC + row * LDW + col);
-        const int b = m / d.L, tok = m - b * d.L;
-        const size_t idx = ((size_t)(b * d.heads + head) * d.Lpad + tok) * dq + dd;
-        v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
-        if (lnf) {
-          const float mean = sR[row * 2], rstd = sR[row * 2 + 1];
-          v.x = (v.x - mean * cs.x) * rstd; v.y = (v.y - mean * cs.y) * rstd; v.z = (v.z - mean * cs.z) * rstd; v.w = (v.w - mean * cs.w) * rstd;
+      // (values of every chunk first, then all the stores: see the GEGLU epilogue above)
+      constexpr int NCQ = WTM / 8;
+      float4 qv[NCQ];
+      const float scale = d.acc_scale;
+      auto qk_values = [&](auto lnf_c) {
+        constexpr bool LNF = decltype(lnf_c)::value;
+#pragma unroll
+        for (int ps = 0; ps < NCQ; ++ps) {
+          const int row = ps * 8 + (lane >> 3);
+          float4 v = *(const float4*)(sC + row * LDW + col);
+          v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+          if (LNF) {
+            const float mean = sR[row * 2], rstd = sR[row * 2 + 1];
+            v.x = (v.x - mean * cs.x) * rstd; v.y = (v.y - mean * cs.y) * rstd; v.z = (v.z - mean * cs.z) * rstd; v.w = (v.w - mean * cs.w) * rstd;
+          }
+          qv[ps] = make_float4((v.x + bb.x) * qs, (v.y + bb.y) * qs, (v.z + bb.z) * qs, (v.w + bb.w) * qs);
         }
-        store_planes4(ph, pl, idx, (v.x + bb.x) * qs, (v.y + bb.y) * qs, (v.z + bb.z) * qs, (v.w + bb.w) * qs);
+      };
+      if (lnf) qk_values(std::integral_constant<bool, true>{});
+      else qk_values(std::integral_constant<bool, false>{});
+#pragma unroll
+      for (int ps = 0; ps < NCQ; ++ps) {
+        const int m = wm0 + ps * 8 + (lane >> 3);
+        if (m < d.M) {
+          const int b = m / d.L, tok = m - b * d.L;
+          const size_t idx = ((size_t)(b * d.heads + head) * d.Lpad + tok) * dq + dd;
+          store_planes4(ph, pl, idx, qv[ps].x, qv[ps].y, qv[ps].z, qv[ps].w);
+        }
       }
     } else {                      // V^T: each lane takes 4 consecutive tokens of one channel (8-byte stores, keys contiguous)
       const int dv = (d.dhead + 15) & ~15;
@@ -316,21 +348,34 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       const int head = cc / d.dhead, dd = cc - head * d.dhead;
       const float bv = d.bias ? d.bias[wn0 + col] : 0.f;
       const float csv = lnf ? d.ln_colsum[wn0 + col] : 0.f;
-#pragma unroll 1
-      for (int ps = 0; ps < WTM / 8; ++ps) {
-        const int row = (ps * 2 + rsel) * 4;
-        const int m = wm0 + row;
-        if (m >= d.M) continue;
-        const int b = m / d.L, tok = m - b * d.L;
-        const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
-        float t4[4];
+      constexpr int NCV = WTM / 8;
+      float4 vv[NCV];
+      const float scale = d.acc_scale;
+      auto vt_values = [&](auto lnf_c) {
+        constexpr bool LNF = decltype(lnf_c)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          t4[i] = sC[(row + i) * LDW + col] * d.acc_scale;
-          if (lnf) t4[i] = (t4[i] - sR[(row + i) * 2] * csv) * sR[(row + i) * 2 + 1];
-          t4[i] += bv;
+        for (int ps = 0; ps < NCV; ++ps) {
+          const int row = (ps * 2 + rsel) * 4;
+          float t4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            t4[i] = sC[(row + i) * LDW + col] * scale;
+            if (LNF) t4[i] = (t4[i] - sR[(row + i) * 2] * csv) * sR[(row + i) * 2 + 1];
+            t4[i] += bv;
+          }
+          vv[ps] = make_float4(t4[0], t4[1], t4[2], t4[3]);
         }
-        store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, t4[0], t4[1], t4[2], t4[3]);
+      };
+      if (lnf) vt_values(std::integral_constant<bool, true>{});
+      else vt_values(std::integral_constant<bool, false>{});
+#pragma unroll
+      for (int ps = 0; ps < NCV; ++ps) {
+        const int m = wm0 + (ps * 2 + rsel) * 4;
+        if (m < d.M) {
+          const int b = m / d.L, tok = m - b * d.L;
+          const size_t idx = ((size_t)(b * d.heads + head) * dv + dd) * d.Lpad + tok;
+          store_planes4((u16*)d.vt_hi, (u16*)d.vt_lo, idx, vv[ps].x, vv[ps].y, vv[ps].z, vv[ps].w);
+        }
       }
     }
     return;
@@ -593,8 +638,9 @@ __device__ __forceinline__ void sched_reads_early() {
   }
 }
 
+// (second launch bound: the register-staged 8-wave tile must leave room for two workgroups per CU = 4 wavefronts per SIMD)
 template <int BM, int BN, int WM, int WN, int NS, int AMODE, int STAGES>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && STAGES == 8) ? 4 : 1) void gemm_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -607,9 +653,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
   constexpr int LDW = WTN + 4;                        // fp32 pitch of the epilogue staging tile
   constexpr int C4 = WTN / 4;                         // float4 columns of a wave tile row
   constexpr int EPI_BYTES = NW * WTM * LDW * 4;
-  constexpr bool RING = STAGES >= 6;                   // 6 / 7 = register-pipelined loop over a DEEP ring of LDS buffers (<= 4 / <= 8)
+  constexpr bool RING = STAGES == 6 || STAGES == 7;    // 6 / 7 = register-pipelined loop over a DEEP ring of LDS buffers (<= 4 / <= 8)
   constexpr bool PIPE = STAGES == 3 || RING;           // 3 = register-pipelined loop (two LDS buffers)
   constexpr bool STAG = STAGES == 4 || STAGES == 5;    // 4 / 5 = staggered wave groups with three / four LDS buffers
+  constexpr bool RSTG = STAGES == 8;                    // 8 = REGISTER-staged delivery: global_load_dwordx4 -> VGPR -> ds_write_b128, two LDS buffers
   constexpr int TAB_BYTES = AMODE != MVD_A_DENSE ? BM * 9 * 4 : 0;
   constexpr int LNR_BYTES = AMODE == MVD_A_DENSE ? BM * 8 : 0;      // {mean, rstd} of the tile's rows (LayerNorm fold: dense problems)
   constexpr int RING_FIT = (160 * 1024 - TAB_BYTES - LNR_BYTES) / STAGE;   // a workgroup may own the whole 160 KiB of its CU
@@ -946,6 +993,74 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
       if (it + J < nkt) step(integral_constant<int, J & 1>{}, integral_constant<bool, false>{}, it + J);
     });
     __syncthreads();   // the epilogue reuses the stage buffers
+  } else if (RSTG) {
+    // ---- register-staged loop (round 4).  The LDS-DMA instruction that the other loops issue per 1 KiB granule costs 60 - 185 issue
+    //      cycles on the wave that issues it; a 64x64 tile gives a wave only 16 MFMAs (256 cycles) per k-tile against 4 such granules, so
+    //      the small-tile kernels are DMA-ISSUE bound (12 - 13 % of the matrix pipe, profiles/r03_pmc_mfma.json).  Here every wave loads
+    //      its granules with ordinary 16-byte global loads two k-tiles ahead (two register stages of LPS x 4 VGPRs), and writes a k-tile
+    //      into the other LDS buffer with ds_write_b128 (same lane-linear 1 KiB image the DMA would have produced) while the current one
+    //      is multiplied: ~20 issue cycles per granule instead of ~100.  Small LDS footprint (2 buffers), so several workgroups share
+    //      a CU and hide each other's barriers.  Same k / MFMA order as every other loop => bit-identical results.
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    u32x4 regs[2][LPS];
+    auto fetch = [&](auto rs_c) {                // issue the loads of the next k-tile into register stage RS (consecutive calls walk kt0, kt0 + 1, ...)
+      constexpr int RS = decltype(rs_c)::value;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const u16* src;
+        if (AMODE == MVD_A_DENSE) {
+          src = a_cur[i];
+          a_cur[i] += a_step[i];
+        } else {
+          src = a_off[i] >= 0 ? (const u16*)d.A + (unsigned)(a_off[i] + c_cb * 64 + a_chunk[i]) : zero;
+        }
+        regs[RS][i] = *(const u32x4*)src;
+      }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        regs[RS][AI + i] = *(const u32x4*)b_cur[i];
+        b_cur[i] += b_step[i];
+      }
+      advance_tap();
+    };
+    auto put = [&](auto rs_c, int buf) {
+      constexpr int RS = decltype(rs_c)::value;
+      unsigned char* sbase = smem + buf * STAGE + lane * 16;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) *(u32x4*)(sbase + (wave + i * NW) * 1024) = regs[RS][i];
+#pragma unroll
+      for (int i = 0; i < BI; ++i) *(u32x4*)(sbase + (A_GRAN + wave + i * NW) * 1024) = regs[RS][AI + i];
+    };
+    using std::integral_constant;
+    fetch(integral_constant<int, 0>{});                              // k-tile 0 -> stage 0
+    if (nkt > 1) fetch(integral_constant<int, 1>{});                 // k-tile 1 -> stage 1
+    ln_gather_rows();
+    MVD_STAMP_AT(d, wave, 1);
+    if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    put(integral_constant<int, 0>{}, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    MVD_STAMP_AT(d, wave, 2);
+    // iteration it (k-tile it sits in LDS buffer it & 1; register stage j & 1 holds k-tile j): read the fragments, refill the stage k-tile it
+    // left with k-tile it + 2, multiply, then move k-tile it + 1 (loaded a whole iteration ago) into the other buffer -- its last readers
+    // passed the previous barrier
+    auto body = [&](auto par_c, int it) {
+      constexpr int P = decltype(par_c)::value;
+      op16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      read_frags(P, ah, al, bh, bl);
+      if (it + 2 < nkt) fetch(integral_constant<int, P>{});
+      mfma_tile(ah, al, bh, bl);
+      if (it + 1 < nkt) {
+        if (it + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPS) : "memory");      // k-tile it + 1 landed; it + 2 stays in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        put(integral_constant<int, P ^ 1>{}, P ^ 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int it = 0; it < nkt; it += 2) {
+      body(integral_constant<int, 0>{}, it);
+      if (it + 1 < nkt) body(integral_constant<int, 1>{}, it + 1);
+    }
   } else {
     // ---- plain two-buffer loop: DMA of k-tile t+1 in flight while tile t is read and multiplied
     stage(0);
@@ -1312,9 +1427,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
       constexpr int NM = TM * TN * NS, NR = (TM + TN) * (NS >= 3 ? 2 : 1);
       sched_reads_early<0, NR, NM>();
     }
-#if defined(MVD_WS_VARIANT) && (MVD_WS_VARIANT & 1)
-    // (probe build, tools/probes/ws_variants.sh: keep every MFMA of a k-tile in front of the next k-tile's barrier -- without it the
-    //  scheduler sinks about half of them behind it, so the barriers of a pair of k-tiles sit 20 and 60 MFMAs apart)
+#if !defined(MVD_WS_VARIANT) || !(MVD_WS_VARIANT & 1)
+    // Keep every MFMA of a k-tile in front of the next k-tile's barrier: without this scheduling barrier the compiler sinks about half of
+    // them behind it, so the two barriers of an unrolled pair of k-tiles sit 20 and 60 MFMAs apart and the loaders get 320 cycles for
+    // one k-tile and 960 for the next.  Same-box A/B of the step: +1.0 % (profiles/r04_ws_variants.json; -DMVD_WS_VARIANT=1 builds without it).
     __builtin_amdgcn_sched_barrier(0);
 #endif
     br = br + 1 == NBUF ? 0 : br + 1;
@@ -1708,7 +1824,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmParams p) 
 //   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop, 2 = staggered wave groups, 3 LDS buffers (8-wave tiles 1 and
 //          4 only), 3 = staggered, 4 LDS buffers (tile 1 only: 128 KiB), 4 = register-pipelined loop over a ring of <= 4 LDS buffers,
 //          5 = over a ring of <= 8 (4-wave tiles 0, 2, 3 only: the 8-wave tiles fit 4), 6 = conv_patch_kernel (stride-1 3x3 convolutions, tiles 1, 2, 4),
-//          7 = gemm_ws_kernel (consumer / loader wavefronts, LDS-DMA delivery), 8 = gemm_ws_kernel with register-staged delivery (LM = 1)
+//          7 = gemm_ws_kernel (consumer / loader wavefronts, LDS-DMA delivery), 8 = gemm_ws_kernel with register-staged delivery (LM = 1),
+//          9 = gemm_kernel with register-staged delivery (global_load -> VGPR -> ds_write_b128, two LDS buffers; tiles 0 - 3)
 //   order : 0 = n-fastest tile order, 1 = m-fastest
 // The 80-column family serves MVD_EPI_STORE only (GEGLU / QKV epilogues address 32-column wave tiles).
 struct TileInfo {
@@ -1811,6 +1928,7 @@ static bool cfg_supported(const mvd_gemm_desc& d, int cfg) {
   if (loop == 5 && waves != 4) return false;
   if (loop == 6) return (tile == 1 || tile == 2 || tile == 4) && patch_shares(d, kTiles[tile]) > 0;
   if (loop == 7 || loop == 8) return (tile == 1 || tile == 2 || tile == 4) && d.epi == MVD_EPI_STORE;
+  if (loop == 9) return tile <= 3;
   return true;
 }
 
@@ -1952,6 +2070,10 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     case 23: launch_ws<128, 128, 2, 2>(p, s); break;
     case 39: launch_ws<128, 80, 4, 1>(p, s); break;
     case 71: launch_ws<128, 160, 2, 2>(p, s); break;
+    case 9: launch_cfg<64, 64, 2, 2, 8>(p, s); break;
+    case 41: launch_cfg<128, 80, 4, 1, 8>(p, s); break;
+    case 57: launch_cfg<64, 80, 4, 1, 8>(p, s); break;
+    case 25: launch_cfg<128, 128, 2, 4, 8>(p, s); break;
     case 24: launch_ws<128, 128, 2, 2, 1>(p, s); break;
     case 40: launch_ws<128, 80, 4, 1, 1>(p, s); break;
     case 72: launch_ws<128, 160, 2, 2, 1>(p, s); break;

@@ -121,6 +121,13 @@ class Ctx:
     def prec_of(self, kind):
         return self.policy.get(kind, self.prec)
 
+    def ln_fold_enabled(self):
+        """LayerNorm folded into the QKV / GEGLU GEMMs (hip.LnFold): the epilogue's `rstd (x.W' - mean colsum)` cancels exactly only as
+        far as the MFMA operands carry W' and x -- 2^-22 with fp16 hi + lo, but 2^-12 / 2^-9 with one product and 2^-17 with bf16 hi + lo,
+        amplified by |mean| / std of the row.  Those modes run the LayerNorm kernels instead."""
+        return (self.ln_fold and hip.OPERAND_FORMAT == "f16" and self.prec_of("qkv") >= hip.PREC_X3 and
+                self.prec_of("geglu") >= hip.PREC_X3 and self.prec_of("proj") >= hip.PREC_X3)
+
     def gemm(self, A, W, out, gn=None, kind=None, **kw):
         """gn=(B, HW): `out` feeds a GroupNorm over (B, HW, N) -- the GEMM emits its statistics (see gn_slot).
         kind: the layer class of the precision policy (hip.PREC_KINDS)."""

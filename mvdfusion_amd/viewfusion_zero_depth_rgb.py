@@ -220,7 +220,7 @@ class ViewFusion(nn.Module):
                  clip_path="", unet_cc_path="", z_scale_factor=0.18215, vae_max_batch=8, objective="noise",
                  loss_type="l2", embed_camera_pose=True, finetune_projection=False, finetune_unet=False,
                  finetune_cross_attn=True, finetune_view_attn=True, feed_prev_depth=False, drop_conditions=False,
-                 vae=None, clip_image_encoder=None, precision="f16x4", reference_eval_dropout=False, **kwargs):
+                 vae=None, clip_image_encoder=None, precision=None, reference_eval_dropout=False, **kwargs):
         super().__init__()
         assert embed_camera_pose, "this build implements the embed_camera_pose=True configuration of configs/*.yaml"
         self.finetune_projection, self.finetune_unet, self.z_scale_factor = finetune_projection, finetune_unet, z_scale_factor
@@ -237,6 +237,8 @@ class ViewFusion(nn.Module):
         # bound), "f16x3" (drops lo*lo, ~2^-22), "bf16x3" (~2^-16), "f16" / "bf16" (one product, hi only).  The operand type selects the library
         # flavour and is fixed per process.
         # A policy string "f16x4:conv=3,geglu=3" sets the products per layer class (hip.PREC_KINDS).
+        from .configs import DEFAULT_PRECISION
+        precision = precision or DEFAULT_PRECISION
         fmt, self.precision, self.precision_policy = hip.parse_precision(precision)
         hip.set_operand_format(fmt)
         self.precision_name = precision

@@ -146,3 +146,32 @@ def test_rccl_one_rank_ddp_training_step():
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         json.dump({"backend": "nccl", "world": 1, "records": recs}, open(os.path.join(out, "dist_ddp_rccl_1rank.json"), "w"))
+
+
+def test_bench_two_ranks_json_contract():
+    """`python bench.py --gpus 2` end to end on this box's single GPU (MVD_DIST_SHARE_GPU=1: functional only): bench.py spawns the two
+    ranks itself under torch.distributed.run, the ranks shard BASELINE configs[2]'s 8 views, exchange latent rows once per step, and
+    rank 0 prints ONE JSON line with the multi-GPU contract the driver reads at N > 1 (n_gpus, scaling, rccl_ranks / backend,
+    config.parallelism, view_parallel.speedup_over_single_gpu).  RCCL when it accepts two ranks on one device, else gloo."""
+    bench = os.path.join(ROOT, "bench.py")
+    used, line, r = None, None, None
+    for backend in ("nccl", "gloo"):
+        env = dict(os.environ, MVD_DIST_SHARE_GPU="1", MVD_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and len(lines) == 1:
+            used, line = backend, lines[0]
+            break
+        print(f"bench.py --gpus 2 over {backend} did not run here:\n" + r.stderr[-1200:])
+    assert line is not None, r.stderr[-3000:]
+    j = json.loads(line)
+    assert j["metric"] == "denoising-steps/sec" and j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong"
+    assert j["rccl_ranks"] == (2 if used == "nccl" else 0)
+    assert j["config"]["views"] == 8 and "view-parallel: 8 views over 2 GPUs" in j["config"]["parallelism"]
+    vp = j["view_parallel"]
+    assert vp["views"] == 8 and vp["single_gpu_same_workload_steps_per_s"] > 0 and vp["speedup_over_single_gpu"] > 0
+    assert j["value"] > 1.0 and j["vs_baseline"] is None and j["data"] == "synthetic"
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"backend": used, "line": j}, open(os.path.join(out, "bench_2rank_one_gpu.json"), "w"))

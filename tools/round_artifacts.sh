@@ -2,7 +2,7 @@
 # Round artefacts on the GPU box -> gpurun_out/<tag>/ (copied into profiles/ by hand afterwards):
 #   bench lines (V=4 default with cpu_baseline; V=8; V=8 x 64^2), rocprofv3 kernel-trace stats of the default command,
 #   PMC traffic / MFMA passes per workload, shard emulation, step trace summary.
-tag=${1:-r03}
+tag=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -14,7 +14,7 @@ python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --tune-ca
 python bench.py --views 8 --steps 10 --warmup 3 --no-cpu-baseline --tune-cache $T8 > /dev/null 2>&1
 python bench.py --views 8 --latent 64 --steps 5 --warmup 2 --no-cpu-baseline --tune-cache $T864 > /dev/null 2>&1
 python bench.py --steps 100 --warmup 5 --tune-cache $T4 > $O/bench_n1.json 2> $O/bench_n1.log
-python bench.py --views 8 --steps 50 --warmup 3 --no-cpu-baseline --shard-emulate 0/8 --tune-cache $T8 > $O/bench_v8_s32.json 2> $O/bench_v8_s32.log
+python bench.py --views 8 --steps 50 --warmup 3 --no-cpu-baseline --shard-emulate 0/8,7/8 --tune-cache $T8 > $O/bench_v8_s32.json 2> $O/bench_v8_s32.log
 python bench.py --views 8 --latent 64 --steps 20 --warmup 3 --no-cpu-baseline --tune-cache $T864 > $O/bench_v8_s64.json 2> $O/bench_v8_s64.log
 cd /tmp && export TMPDIR=/tmp
 out=$O/prof
