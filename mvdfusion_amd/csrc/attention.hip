@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, (DQ <= 64 ? 2 : 1)) void attn_kernel(const u16
     const int kv0 = t * KV_TILE, buf = NBUF == 2 ? (t & 1) : 0;
     if (t + 1 < ntiles) load_tile(kv0 + KV_TILE);      // in flight under the MFMAs below
 
-    if constexpr (QT == 2 && DQ <= 48) {
+    if constexpr (QT == 2 && DQ <= 48 && NS >= 3) {      // (the one-product debugging mode keeps the un-phased body)
       // ---- two query tiles per wavefront, PHASED (round 4): the softmax of one query tile is VALU work (max / exp2 / sum / hi+lo split:
       //      ~140 instructions) and the products of the other one are MFMA work, so the k-tile runs as
       //        A: S(q0) = K Q0^T                       (MFMA)

@@ -558,7 +558,11 @@ def _autotune(d, A=None, reps=4, trials=3, W_data=None):
     e0, e1 = Event(), Event()
     stats_ptr, d.gn_stats = d.gn_stats, None          # the statistics atomics must run exactly once: only in the real launch
     # split-K: the library's model (0 = auto) or none (1); the timed region includes the reduce kernel of a split GEMM
-    skip = {int(t) for t in os.environ.get("MVD_TUNE_EXCLUDE_LOOPS", "").split(",") if t}      # (A/B measurements: e.g. "7" = no role-split kernel)
+    # Loops the tuner does not time unless asked (MVD_TUNE_INCLUDE_LOOPS=8,9): the two register-staged delivery paths of round 4 were
+    # candidates for a whole session and were selected for NO shape of any workload (profiles/r04_ws_variants.json);
+    # they stay built, tested (test_gemm_configurations_agree) and selectable by cfg.  MVD_TUNE_EXCLUDE_LOOPS: A/B measurements.
+    skip = {WSR_LOOP, REG_LOOP} - {int(t) for t in os.environ.get("MVD_TUNE_INCLUDE_LOOPS", "").split(",") if t}
+    skip |= {int(t) for t in os.environ.get("MVD_TUNE_EXCLUDE_LOOPS", "").split(",") if t}      # (e.g. "7" = no role-split kernel)
     cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode, conv=d.a_mode == A_CONV3X3) if cfg_supported(d, c) and _cfg_parts(c)[1] not in skip
              for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]
     # three cold copies of the packed weight, launched back to back between one pair of events: the eager launch latency (a few us

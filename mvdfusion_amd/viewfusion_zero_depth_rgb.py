@@ -289,10 +289,16 @@ class ViewFusion(nn.Module):
         assert self.finetune_view_attn is True, "must finetune new view attention layers"
 
     # ------------------------------------------------------------------------------------------------
-    def invalidate_packed(self):
-        """Drop every packed weight image, captured graph and engine: they are rebuilt from the live fp32 parameters."""
+    def invalidate_packed(self, keep_engines=False):
+        """Drop every packed weight image, captured graph and engine: they are rebuilt from the live fp32 parameters.
+        keep_engines: the parameters changed IN PLACE (an optimizer step): the engines' static arenas (activations, split-K slabs,
+        statistics slots -- GBs of buffers) stay, only the packed images and the graphs that captured their addresses go."""
         hip.drop_packed_caches(self)
-        self._engines.clear()
+        if keep_engines:
+            for e in self._engines.values():
+                e.graphs.clear()
+        else:
+            self._engines.clear()
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         """nn.Module.load_state_dict, then drop every derived packed weight / engine / graph (demo.py:165, train.py:144-153)."""
@@ -311,9 +317,11 @@ class ViewFusion(nn.Module):
 
     def engine(self, V, S, D, cfg, q0=0, Vq=None):
         sig = hip.params_signature(self)
-        if sig != self._packed_sig:      # load_state_dict / optimizer step / .cuda() since the weights were packed
-            if self._packed_sig is not None:
-                self.invalidate_packed()
+        if sig != self._packed_sig:      # an in-place update (optimizer step, fill_) since the weights were packed; load_state_dict /
+            if self._packed_sig is not None:      # .cuda() invalidate fully themselves (the device may have changed)
+                dev_now = self._device.device
+                same_dev = all(e.ctx.device == dev_now for e in self._engines.values())
+                self.invalidate_packed(keep_engines=same_dev)
             self._packed_sig = sig
         if Vq is not None and Vq <= 0:
             raise ValueError(f"engine(V={V}, q0={q0}, Vq={Vq}): a rank must own at least one query view")

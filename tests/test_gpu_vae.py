@@ -147,9 +147,12 @@ def test_prepare_batch_vs_reference_golden(name, random_views, with_depths):
         assert mine.shape == ref.shape and float((mine.cpu() - ref).abs().max()) < 1e-5
 
 
-def test_sample_then_decode_end_to_end():
-    """The demo.py flow (demo.py:85-94) on the HIP path end to end at reduced width: batch -> prepare_batch (HIP VAE encode, stub
-    CLIP) -> 50-step DDIM sample with classifier-free guidance (one hipGraph per step) -> decode of the 4 latent channels."""
+@pytest.mark.parametrize("V", [4, 15])
+def test_sample_then_decode_end_to_end(V):
+    """The demo.py flow (demo.py:80-94) on the HIP path end to end at reduced width: batch -> prepare_batch (HIP VAE encode, stub
+    CLIP) -> 50-step DDIM sample with classifier-free guidance (one hipGraph per step) -> the three decodes demo.py makes (prediction,
+    input view, ground truth).  V = 15 is the inference view count configs/mvd_gso.yaml:97 ships (1 input + 15 targets of the 16-view
+    rig): the fused GridAttn kernel runs with 16 view slots, one of them padding."""
     from conftest import model_config
     from mvdfusion_amd import synthetic as syn
     from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
@@ -164,15 +167,18 @@ def test_sample_then_decode_end_to_end():
     rig = syn.gso_rig()
     batch = dict(images=torch.rand(16, 3, 256, 256, generator=torch.Generator().manual_seed(3)).cuda(), R=rig.R, T=rig.T,
                  f=rig.focal_length, c=rig.principal_point)
-    tc = dict(input_batch_size=1, train_batch_size=4, random_views=False)
+    tc = dict(input_batch_size=1, train_batch_size=V, random_views=False, cfg_scale=2.5)      # the yaml's `inference:` block
     torch.manual_seed(0)
-    x, batch_latents, input_latents, batch_cameras, inter = m.sample(batch, tc, cfg_scale=2.5, return_input=True, depth=True,
-                                                                     verbose=False)
-    assert x.shape == (4, 5, 32, 32) and batch_latents.shape == (4, 5, 32, 32) and input_latents.shape == (1, 5, 32, 32)
-    assert len(inter) == 50 and len(batch_cameras) == 4 and bool(torch.isfinite(x).all())
-    img = m.decode(x[:, :4])
-    assert img.shape == (4, 3, 256, 256) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
-    assert bool(torch.isfinite(img).all())
+    model_outputs = m.sample(batch, tc, cfg_scale=tc["cfg_scale"], return_input=True, depth=True, verbose=False)
+    assert len(model_outputs) == 5
+    x, batch_latents, input_latents, batch_cameras, inter = model_outputs
+    assert x.shape == (V, 5, 32, 32) and batch_latents.shape == (V, 5, 32, 32) and input_latents.shape == (1, 5, 32, 32)
+    assert len(inter) == 50 and len(batch_cameras) == V and bool(torch.isfinite(x).all())
+    assert m.view_attn.fused_supported(V, V * V * 1024)
+    pred_rgb, input_rgb, gt_rgb = m.decode(x[:, :4]), m.decode(input_latents[:, :4]), m.decode(batch_latents[:, :4])
+    assert pred_rgb.shape == (V, 3, 256, 256) and input_rgb.shape == (1, 3, 256, 256) and gt_rgb.shape == (V, 3, 256, 256)
+    for img in (pred_rgb, input_rgb, gt_rgb):
+        assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0 and bool(torch.isfinite(img).all())
 
 
 def _training_setup(gd, mc=32, V=4, **overrides):

@@ -16,6 +16,12 @@ python bench.py --views 8 --latent 64 --steps 5 --warmup 2 --no-cpu-baseline --t
 python bench.py --steps 100 --warmup 5 --tune-cache $T4 > $O/bench_n1.json 2> $O/bench_n1.log
 python bench.py --views 8 --steps 50 --warmup 3 --no-cpu-baseline --shard-emulate 0/8,7/8 --tune-cache $T8 > $O/bench_v8_s32.json 2> $O/bench_v8_s32.log
 python bench.py --views 8 --latent 64 --steps 20 --warmup 3 --no-cpu-baseline --tune-cache $T864 > $O/bench_v8_s64.json 2> $O/bench_v8_s64.log
+# the as-shipped inference view count (configs/mvd_gso.yaml:97), the D = 3 geometry, the training step, the VAE, the 2-rank bench contract
+python bench.py --views 15 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_v15_s32.json 2> $O/bench_v15_s32.log
+python bench.py --views 8 --depth-samples 3 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_v8_s32_d3.json 2> $O/bench_v8_s32_d3.log
+python tools/bench_train.py --steps 5 > $O/train_step.json 2> $O/train_step.log
+python tools/bench_vae.py --steps 20 > $O/decode_n1.json 2> $O/decode_n1.log
+python tools/bench_vae.py --steps 20 --encode > $O/encode_n1.json 2> $O/encode_n1.log
 cd /tmp && export TMPDIR=/tmp
 out=$O/prof
 rm -rf $out
