@@ -32,9 +32,13 @@ __device__ __forceinline__ void mfma_valu_pattern() {
   }
 }
 
-// (second launch bound = wavefronts per SIMD the register allocation must leave room for: the head dims <= 64 run two workgroups per CU)
+#ifdef MVD_ATTN_PHASED
+#define MVD_ATTN_MIN_WAVES(DQ) ((DQ) <= 64 ? 2 : 1)      // the phased body needs the 256-register cap to keep two workgroups per CU
+#else
+#define MVD_ATTN_MIN_WAVES(DQ) 1
+#endif
 template <int DQ, int DV, int NS, int QT, int NBUF>
-__global__ __launch_bounds__(256, (DQ <= 64 ? 2 : 1)) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
+__global__ __launch_bounds__(256, MVD_ATTN_MIN_WAVES(DQ)) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
                                                    const u16* __restrict__ k_hi, const u16* __restrict__ k_lo,
                                                    const u16* __restrict__ vt_hi, const u16* __restrict__ vt_lo,
                                                    u16* __restrict__ out_sp, int ldo, int H, int L, int Lk, int Lpad, int dhead) {
@@ -145,7 +149,17 @@ __global__ __launch_bounds__(256, (DQ <= 64 ? 2 : 1)) void attn_kernel(const u16
     const int kv0 = t * KV_TILE, buf = NBUF == 2 ? (t & 1) : 0;
     if (t + 1 < ntiles) load_tile(kv0 + KV_TILE);      // in flight under the MFMAs below
 
-    if constexpr (QT == 2 && DQ <= 48 && NS >= 3) {      // (the one-product debugging mode keeps the un-phased body)
+#ifdef MVD_ATTN_PHASED
+    constexpr bool PHASED = QT == 2 && DQ <= 48 && NS >= 3;
+#else
+    // Round 4 measured the phased body SLOWER than the un-phased one: attn_kernel<48,48,3,2,2> 72.4 us vs 64.3 us per launch at
+    // L = 1024 (graph-replayed step, profiles/r04_step_trace_v4.txt vs r03), 19.0 vs 16.4 ms of attention per step at L = 4096 -- two
+    // co-resident workgroups already overlap one's softmax with the other's MFMAs, and the phased form pays for its K-fragment
+    // prefetch with a second round of V^T fragment reads and a register allocation at the 256 limit.  Kept behind -DMVD_ATTN_PHASED
+    // (bit-identical, tests/test_gpu_ops.py::test_attention_phased_equals_single_tile covers whichever body is built).
+    constexpr bool PHASED = false;
+#endif
+    if constexpr (PHASED) {
       // ---- two query tiles per wavefront, PHASED (round 4): the softmax of one query tile is VALU work (max / exp2 / sum / hi+lo split:
       //      ~140 instructions) and the products of the other one are MFMA work, so the k-tile runs as
       //        A: S(q0) = K Q0^T                       (MFMA)
