@@ -170,7 +170,11 @@ typedef struct mvd_gemm_desc {
   /* Row statistics of the OUTPUT for a LayerNorm that is folded into the CONSUMER GEMM (MVD_EPI_STORE, n_store == N): rs_out =
    * [M][rs_ld] pairs of floats {sum, sum of squares} of the stored values of row m over one column slot (a wave tile of the kernel
    * that ran, or a 256-column span of the split-K reduce); the number of slots written per row goes to rs_count[0] (device int).
-   * rs_ld >= N / 32 (the narrowest wave tile).  No atomics: the consumer adds the slots in order.  NULL = off. */
+   * rs_ld >= N / 32 (the narrowest wave tile).  No atomics: the consumer adds the slots in order.  NULL = off.
+   * Precision: a slot is a plain fp32 {sum x, sum x^2} over <= 256 columns and the consumer forms var = E[x^2] - mean^2 in double, so the
+   * relative error of the variance is ~1e-7 mean^2 / var: validated for rows with |mean| / std <= 3 (tests/test_gpu_ops.py::
+   * test_gemm_layernorm_fold, 2e-6); residual streams with outlier channels (|mean| / std in the hundreds) should use mvd_layernorm
+   * (two-pass) -- the host mirror's switch is Ctx.ln_fold. */
   float* rs_out;
   int* rs_count;
   int rs_ld;
@@ -178,7 +182,9 @@ typedef struct mvd_gemm_desc {
    * weight is W' = W * diag(gamma), and the epilogue forms  rstd_m (x_m . W'_n - mean_m ln_colsum[n]) + bias[n]  with
    * ln_colsum[n] = sum_k W'[n][k] (logical column order, like bias), bias[n] = sum_k beta[k] W[n][k] (+ the layer's own bias),
    * mean / rstd of row m over its ln_dim real columns from the producer's ln_stats = rs_out, ln_count = rs_count, ln_ld = rs_ld,
-   * eps = ln_eps.  Exact algebra: LayerNorm is affine per row.  Runs without split-K.  NULL = off. */
+   * eps = ln_eps.  Exact algebra: LayerNorm is affine per row -- exact in arithmetic only as far as the MFMA operands carry W' and x:
+   * use it with the fp16 hi + lo modes (MVD_PREC_X3 / X4 of the f16 library); with one product or bf16 operands the uncancelled
+   * mean * sum(W~' - W') term grows with |mean| / std (the host mirror runs mvd_layernorm there).  Runs without split-K.  NULL = off. */
   const float* ln_stats;
   const int* ln_count;
   const float* ln_colsum;
