@@ -209,7 +209,9 @@ class SpatialTransformer(nn.Module):
             ctx.gemv_rows(a2.to_v.weight, None, ctx.context, v1)
             vec = ctx.ws.get("tf.vec", (B, C))
             ctx.gemv_rows(a2.to_out[0].weight, a2.to_out[0].bias, v1, vec)
-        t2 = ctx.ws.get("tf.t2", (M, C))
+        # (with the LayerNorm fold the fp32 copy of t2 has no reader: the GEGLU GEMM takes t2's planes + row statistics, the merged
+        #  ff-out / proj_out GEMM takes the planes from cat5 -- one (M, C) fp32 write less per transformer)
+        t2 = None if fold else ctx.ws.get("tf.t2", (M, C))
         cat5 = tb.cat5(ctx, M, "tf")
         ctx.gemm(o, tb.attn1.packed("out"), t2, res=t, bias_b=vec, rows_per_batch=L, out_planes=cat5, out_planes_col=4 * C, row_stats=rs2, kind="out")
         if out is None:
@@ -264,7 +266,7 @@ class ViewAlignedFeatureTransformer(nn.Module):
         fold = ctx.ln_fold_enabled()
         tp, rs1, rs2 = (ctx.ws.planes("tf.tp", M, C), ctx.row_stats("tf.rs1", M, C), ctx.row_stats("tf.rs2", M, C)) if fold else (None,) * 3
         ctx.gemm(n, w_in, t, out_planes=tp, row_stats=rs1, kind="proj")
-        t2b = ctx.ws.get("tf.t2b", (M, C))
+        t2b = None if fold else ctx.ws.get("tf.t2b", (M, C))
         cat5 = tb.cat5(ctx, M, "tf")
         if D == 1:
             assert vol_col == C and vol.shape[-1] == 2 * (C + 768), (vol_col, C, vol.shape)
