@@ -78,7 +78,7 @@ def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True,
     dys = dy * sc                                                             # exact (power of two)
     dx = None
     if need_dx:
-        wt = hip.pack_linear(weight.detach().t().contiguous())                # (K, N): dX = dY W
+        wt = hip.pack_linear(weight.detach().t().contiguous(), like=weight)   # (K, N): dX = dY W  (same elements: the registered max|w| serves)
         dx_full = torch.empty(M, wt.N, dtype=torch.float32, device=dev)
         hip.gemm(_planes_padded(dys, N), wt, dx_full, prec=prec, bias=False, workspace=workspace)
         dx_full *= isc
@@ -109,7 +109,7 @@ def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, nee
     dx = None
     if need_dx:
         # dX = conv3x3(dY, W') with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]  (full correlation with the rotated filter)
-        wr = hip.pack_conv3x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous())
+        wr = hip.pack_conv3x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous(), like=weight)
         dx_full = torch.empty(M, wr.N, dtype=torch.float32, device=dev)
         hip.gemm(_planes_padded(dys, Cout), wr, dx_full, prec=prec, bias=False, workspace=workspace,
                  conv=dict(B=B, Hin=H, Win=W, Cin=_pad32(Cout), Hout=H, Wout=W, stride=1, upsample=0))

@@ -230,23 +230,69 @@ class PlanesOperand:
         self.n_real, self.bias, self.geglu, self.conv_cin, self.acc_scale = self.N, bias, False, 0, acc_scale
 
 
-def _pack_scale(w):
+# max|w| of the model's parameters, measured by ONE batched reduction and ONE host read (register_param_maxima): storage pointer ->
+# (weakref to the parameter, numel, max|w|).  Reading max|w| per packed weight is a host synchronisation each -- ~900 per training step
+# (every weight is re-packed after an optimizer step, forward and transposed for the dgrad): 0.15 s of the 0.42 s step (cProfile, round 4).
+_PARAM_MAX = {}
+
+
+def register_param_maxima(params):
+    """Measure max|w| of every fp32 GPU parameter in `params` with one reduction pass and one host read; pack_* calls on those
+    parameters (or on tensors derived from them with the same maximum: transposes, flips -- `like=`) then need no synchronisation.
+    The owner re-registers after every in-place update (ViewFusion.engine)."""
+    import weakref
+    ps = [p for p in params if p.is_cuda and p.dtype == torch.float32 and p.numel() > 0]
+    _PARAM_MAX.clear()
+    if not ps:
+        return 0
+    with torch.no_grad():
+        try:
+            norms = torch._foreach_norm([p.detach().reshape(-1) for p in ps], float("inf"))
+        except Exception:
+            norms = [torch.linalg.vector_norm(p.detach().reshape(-1), ord=float("inf")) for p in ps]
+        vals = torch.stack([n.reshape(()) for n in norms]).tolist()
+    for p, v in zip(ps, vals):
+        _PARAM_MAX[p.data_ptr()] = (weakref.ref(p), p.numel(), float(v))
+    return len(ps)
+
+
+def _known_max(t):
+    """max|t| from the registry if `t` is (a view of the whole of) a registered, still-alive parameter; else None."""
+    ent = _PARAM_MAX.get(t.data_ptr())
+    if ent is None:
+        return None
+    ref, numel, mx = ent
+    p = ref()
+    if p is None or p.data_ptr() != t.data_ptr() or numel != t.numel():
+        return None
+    return mx
+
+
+def _pack_scale(w, like=None):
     """Power of two that brings max|w| to [1024, 2048): the low half of the fp16 split then stays a normal number for
-    every weight within 2^-13 of the largest one (exact to undo: the GEMM multiplies its accumulator by 1/scale)."""
+    every weight within 2^-13 of the largest one (exact to undo: the GEMM multiplies its accumulator by 1/scale).
+    like: parameter(s) whose elements are exactly those of `w` (a transpose / flip / concatenation of them): their registered maxima
+    are used instead of reducing `w` (no host synchronisation)."""
     import math
-    mx = float(torch.linalg.vector_norm(w.reshape(-1), ord=float("inf")))      # max|w| in ONE reduction (abs().max() is two kernels and a temporary)
+    mx = None
+    srcs = [w] if like is None else (list(like) if isinstance(like, (list, tuple)) else [like])
+    known = [_known_max(s.detach()) for s in srcs]
+    if all(k is not None for k in known):
+        mx = max(known)
+    if mx is None:
+        mx = float(torch.linalg.vector_norm(w.reshape(-1), ord=float("inf")))      # max|w| in ONE reduction (abs().max() is two kernels and a temporary)
     if not (mx > 0.0) or not math.isfinite(mx):
         return 1.0
     return 2.0 ** (10 - math.floor(math.log2(mx)))
 
 
-def pack_linear(weight, bias=None, geglu=False):
-    """weight (N, K) fp32 on the GPU (nn.Linear / 1x1 nn.Conv2d weight)."""
+def pack_linear(weight, bias=None, geglu=False, like=None):
+    """weight (N, K) fp32 on the GPU (nn.Linear / 1x1 nn.Conv2d weight).  like: see _pack_scale."""
     w = weight.detach().reshape(weight.shape[0], -1).contiguous().float()
     N, K = w.shape
     Np, Kp = (N + 15) // 16 * 16, (K + 31) // 32 * 32
     data = torch.empty(lib().mvd_packed_weight_bytes(N, K), dtype=torch.uint8, device=w.device)
-    scale = _pack_scale(w)
+    scale = _pack_scale(w, like if like is not None else weight)
     check(lib().mvd_pack_linear_weight(ptr(w), N, K, K, int(geglu), scale, ptr(data), stream()))
     b = None
     if bias is not None:
@@ -259,16 +305,16 @@ def pack_linear(weight, bias=None, geglu=False):
 
 def pack_linear_cat(weights):
     """Row-concatenate several (N_i, K) weights (e.g. to_q/to_k/to_v -> one QKV GEMM)."""
-    return pack_linear(torch.cat([w.detach().float() for w in weights], dim=0))
+    return pack_linear(torch.cat([w.detach().float() for w in weights], dim=0), like=list(weights))
 
 
-def pack_conv3x3(weight, bias=None):
+def pack_conv3x3(weight, bias=None, like=None):
     w = weight.detach().contiguous().float()
     Cout, Cin = w.shape[0], w.shape[1]
     cin_pad = (Cin + 31) // 32 * 32
     Np = (Cout + 15) // 16 * 16
     data = torch.empty(Np * 9 * cin_pad * 4, dtype=torch.uint8, device=w.device)
-    scale = _pack_scale(w)
+    scale = _pack_scale(w, like if like is not None else weight)
     check(lib().mvd_pack_conv3x3_weight(ptr(w), Cout, Cin, cin_pad, scale, ptr(data), stream()))
     b = None
     if bias is not None:
@@ -417,7 +463,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
            out_planes is not None, splitk, d.b_mode, row_stats is not None, ln is not None)
     if cfg is None:
         tuned = _TUNED.get(key)
-        if tuned is None and AUTOTUNE:
+        if tuned is None and AUTOTUNE and 2.0 * d.M * d.N * d.K >= AUTOTUNE_MIN_FLOPS:
             tuned = _autotune(d, A if A.is_contiguous() else None, W_data=W.data if not isinstance(W, PlanesOperand) else None)
             _TUNED[key] = tuned
         if tuned is not None:
@@ -524,6 +570,7 @@ def load_tuned(path):
 
 LAST_CFG = 0
 AUTOTUNE = False          # set by the step engine around its eager warm-up step (never during graph capture)
+AUTOTUNE_MIN_FLOPS = 0.0  # problems below this many FLOPs keep the library's heuristic (the training step tunes its big GEMMs only)
 _TUNED = {}
 
 

@@ -289,6 +289,8 @@ class ViewFusion(nn.Module):
         assert self.finetune_view_attn is True, "must finetune new view attention layers"
 
     # ------------------------------------------------------------------------------------------------
+    train_autotune_min_flops = 2.0e9      # training step: GEMMs at least this large are autotuned on first sight (None: heuristic tiles only)
+
     def invalidate_packed(self, keep_engines=False):
         """Drop every packed weight image, captured graph and engine: they are rebuilt from the live fp32 parameters.
         keep_engines: the parameters changed IN PLACE (an optimizer step): the engines' static arenas (activations, split-K slabs,
@@ -323,6 +325,7 @@ class ViewFusion(nn.Module):
                 same_dev = all(e.ctx.device == dev_now for e in self._engines.values())
                 self.invalidate_packed(keep_engines=same_dev)
             self._packed_sig = sig
+            hip.register_param_maxima(self.parameters())      # one reduction + one host read instead of one per packed weight
         if Vq is not None and Vq <= 0:
             raise ValueError(f"engine(V={V}, q0={q0}, Vq={Vq}): a rank must own at least one query view")
         key = (V, S, D, bool(cfg), q0, Vq)
@@ -530,6 +533,19 @@ class ViewFusion(nn.Module):
         (mvdfusion_amd/backward_gridattn.py: final layer, softmax-over-V pooling, 3 DiT blocks, pre layer, grid_sample backward,
         z-embedding) and ViewFusion.time_embed.  Returns (loss, {state_dict key: gradient}) for every parameter the loss depends on;
         with only_trainable the weight gradients of frozen parameters (requires_grad False) are skipped (None) -- their dgrad still runs."""
+        from . import backward_blocks as bb
+        from . import backward_gridattn as bg
+        tune = self.train_autotune_min_flops is not None and not hip.AUTOTUNE
+        if tune:          # the forward of the training step runs eagerly (condition dropout): its GEMMs and the backward's are tuned here,
+            hip.AUTOTUNE, hip.AUTOTUNE_MIN_FLOPS = True, float(self.train_autotune_min_flops)      # once per shape (cached), big ones only
+        try:
+            return self._gradients(batch, trainer_config, noise_source, only_trainable)
+        finally:
+            if tune:
+                hip.AUTOTUNE, hip.AUTOTUNE_MIN_FLOPS = False, 0.0
+                hip.release_tuning_buffers()
+
+    def _gradients(self, batch, trainer_config, noise_source, only_trainable):
         from . import backward_blocks as bb
         from . import backward_gridattn as bg
         loss, grads, dvol = self.unet_gradients(batch, trainer_config, noise_source=noise_source, only_trainable=only_trainable)
