@@ -55,12 +55,23 @@ def main():
         times.append(time.perf_counter() - t0)
         losses.append(float(loss.detach()))
     dt = sum(times[1:]) / a.steps
-    print(json.dumps({"metric": "training-steps/sec (fwd + bwd + AdamW, one scene)", "value": 1.0 / dt, "s_per_step": dt, "first_step_s": times[0],
+    # algorithmic work of one step (SURVEY.md section 8(d), 2 FLOP per MAC): forward = V UNet passes (cfg 1: no null twin) + GridAttn; the
+    # backward is a dgrad and a wgrad per contraction (2 x forward) and re-runs every block's forward once (activation checkpointing at block
+    # granularity, like the reference's use_checkpoint=True) => 4 x forward
+    f_unet = {1: 225.09e9, 3: 235.81e9}.get(D, 225.09e9) * (a.width / 320.0) ** 2
+    T = V * V * S * S * D
+    f_fwd = V * f_unet + T * (3516416 + 3072 * V) + V * S * S * D * 393216 + (V + 1) * S * S * 2560
+    flops = 4.0 * f_fwd
+    print(json.dumps({"metric": "training-steps/sec (fwd + bwd + AdamW, one scene)", "value": 1.0 / dt, "unit": "steps/s", "s_per_step": dt, "first_step_s": times[0],
+                      "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / dt / 2.5e15,
+                                   "traffic": None, "algorithmic_tflop_per_step": flops / 1e12,
+                                   "note": "whole step (fwd + recompute + dgrad + wgrad) against the dense 16-bit MFMA peak; the step is "
+                                           "host- and glue-bound (DESIGN.md section 6c), not a kernel roofline"},
                       "views": V, "depth_samples": D, "latent": S, "model_channels": a.width, "trainable_parameters": n_train,
                       "finetune_unet": not a.frozen_unet,
                       "losses": losses, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
-                      "note": "backward = recompute-per-block + dgrad/wgrad on the split-operand MFMA GEMM, fp32 VALU attention "
-                              "backward; a functional training path, not yet tuned (no graph capture, fresh allocations)"}))
+                      "note": "backward = recompute-per-block + dgrad/wgrad on the split-operand MFMA GEMM (big shapes autotuned on first sight), "
+                              "fp32 VALU attention backward; one batched max|w| read per step; no graph capture, fresh allocations"}))
 
 
 if __name__ == "__main__":
