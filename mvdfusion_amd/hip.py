@@ -241,7 +241,7 @@ def register_param_maxima(params):
     parameters (or on tensors derived from them with the same maximum: transposes, flips -- `like=`) then need no synchronisation.
     The owner re-registers after every in-place update (ViewFusion.engine)."""
     import weakref
-    ps = [p for p in params if p.is_cuda and p.dtype == torch.float32 and p.numel() > 0]
+    ps = [p for p in params if p.dtype == torch.float32 and p.numel() > 0]
     _PARAM_MAX.clear()
     if not ps:
         return 0
@@ -254,6 +254,11 @@ def register_param_maxima(params):
     for p, v in zip(ps, vals):
         _PARAM_MAX[p.data_ptr()] = (weakref.ref(p), p.numel(), float(v))
     return len(ps)
+
+
+def forget_param_maxima():
+    """Drop the registry (the owner calls this when parameters may have been replaced wholesale: load_state_dict, .cuda())."""
+    _PARAM_MAX.clear()
 
 
 def _known_max(t):

@@ -296,6 +296,7 @@ class ViewFusion(nn.Module):
         keep_engines: the parameters changed IN PLACE (an optimizer step): the engines' static arenas (activations, split-K slabs,
         statistics slots -- GBs of buffers) stay, only the packed images and the graphs that captured their addresses go."""
         hip.drop_packed_caches(self)
+        hip.forget_param_maxima()          # (engine() measures them again before anything is packed for a step)
         if keep_engines:
             for e in self._engines.values():
                 e.graphs.clear()

@@ -370,6 +370,41 @@ def test_precision_policy_parsing():
     assert m.precision == 4 and m.precision_policy == {"conv": 3}
 
 
+def test_param_maxima_registry_replaces_per_pack_synchronisation():
+    """hip.register_param_maxima / _pack_scale(like=): max|w| of every parameter from one batched reduction; a packed image of a
+    parameter -- or of a transpose / flip / concatenation of parameters (`like=`) -- takes its power-of-two scale from the registry; tensors
+    the registry does not know, parameters that died, and same-address tensors of another size fall back to reducing the tensor itself."""
+    import gc
+    import math
+    from mvdfusion_amd import hip
+    lin, conv = torch.nn.Linear(24, 40), torch.nn.Conv2d(8, 16, 3)
+    with torch.no_grad():
+        lin.weight.mul_(37.0)
+        conv.weight.mul_(0.01)
+    try:
+        n = hip.register_param_maxima(list(lin.parameters()) + list(conv.parameters()))
+        assert n == 4
+        want = lambda t: 2.0 ** (10 - math.floor(math.log2(float(t.detach().abs().max()))))
+        assert hip._known_max(lin.weight.detach()) == pytest.approx(float(lin.weight.detach().abs().max()))
+        assert hip._pack_scale(lin.weight) == want(lin.weight) and hip._pack_scale(conv.weight) == want(conv.weight)
+        wt = lin.weight.detach().t().contiguous()                      # a derived image: not registered itself ...
+        assert hip._known_max(wt) is None and hip._pack_scale(wt) == want(lin.weight)      # ... (falls back to its own reduction)
+        big = lin.weight.detach() * 100.0
+        assert hip._pack_scale(big, like=lin.weight) == want(lin.weight)                   # `like` decides, not the tensor's own values
+        assert hip._pack_scale(torch.cat([lin.weight.detach().reshape(-1), conv.weight.detach().reshape(-1)]),
+                               like=[lin.weight, conv.weight]) == want(lin.weight)
+        assert hip._pack_scale(big, like=[lin.weight, big]) == want(big)                   # one unknown source: reduce the tensor itself
+        assert hip._known_max(lin.weight.detach()[:10]) is None                            # same address, other size
+        ptr = lin.weight.data_ptr()
+        del lin
+        gc.collect()
+        assert hip._PARAM_MAX[ptr][0]() is None                                            # the parameter died: its entry no longer answers
+        hip.forget_param_maxima()
+        assert not hip._PARAM_MAX
+    finally:
+        hip.forget_param_maxima()
+
+
 def test_fused_gridattn_serves_every_shipped_view_count():
     """configs/mvd_gso.yaml:97 (15 views), mvd_train.yaml:90,97 (5, 7): the fused kernel pads the views of a point to a power of two."""
     from mvdfusion_amd.view_attn_efficient2 import GridAttn
