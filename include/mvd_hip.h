@@ -141,7 +141,7 @@ typedef struct mvd_gemm_desc {
   /* kernel configuration: 0 = built-in heuristic; otherwise cfg = 1 + MVD_GEMM_CFG_STRIDE * tile + 2 * loop + order with
    *   tile : 0 = 64x64 (4 waves)  1 = 128x128 (8 waves)  2 = 128x80 (4 waves)  3 = 64x80 (4 waves)  4 = 128x160 (8 waves);
    *          tiles >= 2 (the 80-column family for N = 320 * k: no N padding, 256 workgroups at M = 8192, N = 320) serve
-   *          MVD_EPI_STORE only
+   *          MVD_EPI_STORE only (the GEGLU / QKV epilogues walk a wave tile in 32-column blocks)
    *   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop (two k-tiles in LDS, MFMA fragments double-buffered in
    *          registers), 2 = staggered (8-wave tiles only: three k-tiles in LDS, the two wavefronts of a SIMD half an
    *          iteration apart, so one issues LDS-DMA / fragment reads while the other runs MFMAs), 3 = staggered with four
@@ -150,7 +150,7 @@ typedef struct mvd_gemm_desc {
    *          of the low-resolution levels whose k-loop is otherwise one DMA round trip per k-tile, 6 = the input-patch kernel for
    *          stride-1 padded 3x3 convolutions (tiles 1, 2, 4): the tile's pixels + halo are staged once per 32-channel block and the
    *          nine taps read shifted slots of that patch (4-6x less A traffic into LDS), 7 = the wave-specialised kernel (tiles 1, 2,
-   *          4; MVD_EPI_STORE): four consumer wavefronts (fragment reads + MFMAs) and four loader wavefronts (all LDS-DMAs) per
+   *          4; tile 1 with every epilogue, 2 and 4 MVD_EPI_STORE): four consumer wavefronts (fragment reads + MFMAs) and four loader wavefronts (all LDS-DMAs) per
    *          workgroup, 8 = the same kernel with REGISTER-staged operand delivery (the loader wavefronts issue ordinary 16-byte global
    *          loads, hold NBUF - 2 k-tiles of their share in VGPRs and ds_write_b128 each k-tile into its LDS slot one iteration before it
    *          is read -- same LDS image and MFMA order as 7: bit-identical), 9 = register-staged delivery in the plain kernel (tiles 0 - 3: every
@@ -312,6 +312,8 @@ int mvd_gridattn_tokens(const float* x, const float* depth_noise, const float* s
  * Linear 256->768 is a plain mvd_gemm).  1 <= V <= 16: a wavefront owns 16 token rows = 16 / Vp points, Vp = the next power of
  * two >= V; the Vp - V padding slots of a point are masked as attention keys and in the pooling (the reference ships V = 15, 7, 5:
  * configs/mvd_gso.yaml:97, mvd_train.yaml:90,97); Vq*S*S*D*Vp must be a multiple of 64.  V > 16: the unfused kernels above / below.
+ *   prec    : MVD_PREC_X4 = all four partial products of the operand split, MVD_PREC_X3 = without lo*lo (every MFMA of the kernel:
+ *             the five Linear layers per block and Q K^T)
  *   wstream : the aggregation weights as fp16 (bf16) hi + lo in the kernel's consumption order, mvd_gridattn_fused_slots()
  *             slots of 32 KiB (layout: csrc/gridattn_fused.hip header; packer: mvdfusion_amd/view_attn_efficient2.py)
  *   vecs    : mvd_gridattn_fused_vec_floats() floats -- per DiT block [adaLN modulation of this step 1536 | b_qkv 768 |
@@ -323,7 +325,8 @@ size_t mvd_gridattn_fused_vec_floats(void);
 int mvd_gridattn_fused(const float* x, const float* depth_noise, const float* steps, const int* iter, const float* grid_lin,
                        const float* feat, const float* in_feat, const float* cams, const float* in_cam, const void* wstream,
                        const float* vecs, void* pooled_sp, int V, int q0, int Vq, int S, int D, float depth_scale,
-                       float depth_shift, mvd_stream_t stream);
+                       float depth_shift, int prec /* MVD_PREC_X3 | MVD_PREC_X4: partial products per MAC, as mvd_gemm_desc.prec */,
+                       mvd_stream_t stream);
 /* timm Attention core over the V reference views (:52): qkv (Nseq*V, 3*heads*dhead) -> out (Nseq*V, heads*dhead) */
 int mvd_view_mha(const float* qkv, void* out_sp, int Nseq, int V, int heads, int dhead,
                  mvd_stream_t stream); /* output: split planes */

@@ -238,8 +238,17 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
     return;
   }
-  if constexpr (WTN == 32) {      // GEGLU / QKV epilogues address 32-column blocks (one value|gate block, head-aligned q/k/v)
-  if (d.epi == MVD_EPI_GEGLU) {   // wave tile = 16 value columns | 16 gate columns
+  if constexpr (WTN % 32 == 0) {  // GEGLU / QKV epilogues address 32-column blocks (one value|gate block, head-aligned q/k/v)
+  if (d.epi == MVD_EPI_GEGLU || d.epi == MVD_EPI_QKV) {
+  const int wn0_tile = wn0;
+  float* const sC_tile = sC;
+  // a wave tile is WTN / 32 such blocks (gemm_kernel: one; gemm_ws_kernel<128, 128, 2, 2>: two), each handled on its own
+#pragma unroll 1
+  for (int jb = 0; jb < WTN / 32; ++jb) {
+  const int wn0 = wn0_tile + jb * 32;
+  float* const sC = sC_tile + jb * 32;
+  if (wn0 >= d.N) break;
+  if (d.epi == MVD_EPI_GEGLU) {   // block = 16 value columns | 16 gate columns
     const int ocol0 = (wn0 >> 5) * 16;
     const int half = d.N >> 1;
     // (rolled chunk loops, column operands loaded once: see MVD_EPI_STORE below)
@@ -293,12 +302,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         if (d.out_sp) store_sp4((u16*)d.out_sp, (size_t)m, d.ldp, col, gv[ps].x, gv[ps].y, gv[ps].z, gv[ps].w);
       }
     }
-    MVD_STAMP_AT(d, wave, 9);
-    MVD_STAMP_AT(d, wave, 6);
-    MVD_STAMP_AT(d, wave, 7);
-    return;
+    continue;
   }
-  if (d.epi == MVD_EPI_QKV) {     // a 32-column aligned wave tile lies inside one of q / k / v
+  {                               // MVD_EPI_QKV: a 32-column aligned block lies inside one of q / k / v
     const int C = d.heads * d.dhead;
     const int which = wn0 / C;
     if (which < 2) {
@@ -378,7 +384,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
       }
     }
-    return;
+  }
+  }   // 32-column blocks
+  MVD_STAMP_AT(d, wave, 9);
+  MVD_STAMP_AT(d, wave, 6);
+  MVD_STAMP_AT(d, wave, 7);
+  return;
   }
   }
   // MVD_EPI_STORE, in two passes over the wave tile.  A 64-lane chunk is RPC = 64 / C4 whole rows of C4 16-byte columns (80-column wave
@@ -1827,7 +1838,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmParams p) 
 //          7 = gemm_ws_kernel (consumer / loader wavefronts, LDS-DMA delivery), 8 = gemm_ws_kernel with register-staged delivery (LM = 1),
 //          9 = gemm_kernel with register-staged delivery (global_load -> VGPR -> ds_write_b128, two LDS buffers; tiles 0 - 3)
 //   order : 0 = n-fastest tile order, 1 = m-fastest
-// The 80-column family serves MVD_EPI_STORE only (GEGLU / QKV epilogues address 32-column wave tiles).
+// The 80-column family serves MVD_EPI_STORE only (the GEGLU / QKV epilogues walk a wave tile in 32-column blocks).
 struct TileInfo {
   int bm, bn, waves;
   int cores_plain, cores_pipe;   // workgroups that fit one CU (LDS / registers), per loop variant
@@ -1927,7 +1938,7 @@ static bool cfg_supported(const mvd_gemm_desc& d, int cfg) {
   if (loop == 3 && tile != 1) return false;
   if (loop == 5 && waves != 4) return false;
   if (loop == 6) return (tile == 1 || tile == 2 || tile == 4) && patch_shares(d, kTiles[tile]) > 0;
-  if (loop == 7 || loop == 8) return (tile == 1 || tile == 2 || tile == 4) && d.epi == MVD_EPI_STORE;
+  if (loop == 7 || loop == 8) return tile == 1 || ((tile == 2 || tile == 4) && d.epi == MVD_EPI_STORE);   // (64x64 wave tiles: every epilogue)
   if (loop == 9) return tile <= 3;
   return true;
 }

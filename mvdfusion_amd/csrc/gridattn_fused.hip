@@ -172,6 +172,7 @@ __device__ __forceinline__ void g4_wait_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory");
 }
 
+template <int NS>      // partial products per MAC: 4 = all of hi/lo x hi/lo, 3 = without lo*lo (the GEMMs' f16x3)
 __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[G4_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) w[q] = read_w(sl, gq * 4 + q);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mma_lolo(acc[gq * 4 + q], w[q], xf);
+      for (int q = 0; q < 4; ++q)
+        if constexpr (NS == 4) mma_lolo(acc[gq * 4 + q], w[q], xf);
 #pragma unroll
       for (int q = 0; q < 4; ++q) mma_lohi(acc[gq * 4 + q], w[q], xf);
 #pragma unroll
@@ -427,12 +429,12 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
               const int mt = 16 * sl3 + 4 * gq + q;
               const int ks = mt / 6, t6 = mt - ks * 6;
               if (t6 < 4) {
-                if (term == 0) mma_lolo(qkv[t6], w[q], xf[ks]);
+                if (NS == 4 && term == 0) mma_lolo(qkv[t6], w[q], xf[ks]);
                 if (term == 1) mma_lohi(qkv[t6], w[q], xf[ks]);
                 if (term == 2) mma_hilo(qkv[t6], w[q], xf[ks]);
                 if (term == 3) mma_hihi(qkv[t6], w[q], xf[ks]);
               } else {
-                if (term == 0) mmu_lolo(qkv[t6], w[q], xf[ks]);
+                if (NS == 4 && term == 0) mmu_lolo(qkv[t6], w[q], xf[ks]);
                 if (term == 1) mmu_lohi(qkv[t6], w[q], xf[ks]);
                 if (term == 2) mmu_hilo(qkv[t6], w[q], xf[ks]);
                 if (term == 3) mmu_hihi(qkv[t6], w[q], xf[ks]);
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
       // S^T[key][query] = sum_d K[key][d] Q[query][d]   (one 16x16x32 MFMA per partial product)
       const Frag kf = make_frag(qkv[2], qkv[3]), qf = make_frag(qkv[0], qkv[1]);
       f32x4 st = {0.f, 0.f, 0.f, 0.f};
-      st = MVD_MFMA_16x16x32(kf.lo, qf.lo, st, 0, 0, 0);
+      if constexpr (NS == 4) st = MVD_MFMA_16x16x32(kf.lo, qf.lo, st, 0, 0, 0);
       st = MVD_MFMA_16x16x32(kf.lo, qf.hi, st, 0, 0, 0);
       st = MVD_MFMA_16x16x32(kf.hi, qf.lo, st, 0, 0, 0);
       st = MVD_MFMA_16x16x32(kf.hi, qf.hi, st, 0, 0, 0);
@@ -525,7 +527,8 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
           for (int q = 0; q < 4; ++q) w[q] = read_w(sl, gq * 4 + q);
           const int ks = 4 * sl2 + gq;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) mma_lolo(f1[q], w[q], xf[ks]);
+          for (int q = 0; q < 4; ++q)
+            if constexpr (NS == 4) mma_lolo(f1[q], w[q], xf[ks]);
 #pragma unroll
           for (int q = 0; q < 4; ++q) mma_lohi(f1[q], w[q], xf[ks]);
 #pragma unroll
@@ -592,7 +595,7 @@ extern "C" size_t mvd_gridattn_fused_vec_floats(void) { return (size_t)G4_VEC_GR
 extern "C" int mvd_gridattn_fused(const float* x, const float* depth_noise, const float* steps, const int* iter,
                                   const float* grid_lin, const float* feat, const float* in_feat, const float* cams,
                                   const float* in_cam, const void* wstream, const float* vecs, void* pooled_sp, int V, int q0,
-                                  int Vq, int S, int D, float depth_scale, float depth_shift, mvd_stream_t stream) {
+                                  int Vq, int S, int D, float depth_scale, float depth_shift, int prec, mvd_stream_t stream) {
   MVD_CHECK_ARG(x && depth_noise && steps && iter && grid_lin && feat && in_feat && cams && in_cam && wstream && vecs && pooled_sp,
                 "mvd_gridattn_fused: null pointer");
   MVD_CHECK_ARG(V >= 1 && V <= 16, "mvd_gridattn_fused: V=%d outside [1, 16] (use the unfused path)", V);
@@ -600,6 +603,7 @@ extern "C" int mvd_gridattn_fused(const float* x, const float* depth_noise, cons
   while ((1 << lv) < V) ++lv;
   const int Vp = 1 << lv;
   MVD_CHECK_ARG(q0 >= 0 && Vq > 0 && q0 + Vq <= V && S > 1 && D > 0, "mvd_gridattn_fused: bad shape");
+  MVD_CHECK_ARG(prec == MVD_PREC_X3 || prec == MVD_PREC_X4, "mvd_gridattn_fused: prec %d (MVD_PREC_X3 or MVD_PREC_X4)", prec);
   MVD_CHECK_ARG(((uintptr_t)wstream & 15) == 0 && ((uintptr_t)vecs & 15) == 0 && ((uintptr_t)pooled_sp & 127) == 0,
                 "mvd_gridattn_fused: wstream / vecs must be 16-byte, pooled_sp 128-byte aligned");
   const size_t T = (size_t)Vq * S * S * D * Vp;           // token rows incl. the padding slots
@@ -609,7 +613,8 @@ extern "C" int mvd_gridattn_fused(const float* x, const float* depth_noise, cons
   p.in_feat = in_feat; p.cams = cams; p.in_cam = in_cam; p.wstream = (const unsigned char*)wstream; p.vecs = vecs;
   p.pooled_sp = (u16*)pooled_sp; p.V = V; p.Vp = Vp; p.lv = lv; p.q0 = q0; p.Vq = Vq; p.S = S; p.D = D; p.nslots = 23 + 3 * 64;
   p.depth_scale = depth_scale; p.depth_shift = depth_shift;
-  hipLaunchKernelGGL(g4_fused_kernel, dim3((unsigned)(T / 64)), dim3(256), 0, (hipStream_t)stream, p);
+  if (prec == MVD_PREC_X3) hipLaunchKernelGGL(g4_fused_kernel<3>, dim3((unsigned)(T / 64)), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(g4_fused_kernel<4>, dim3((unsigned)(T / 64)), dim3(256), 0, (hipStream_t)stream, p);
   MVD_CHECK_LAUNCH("mvd_gridattn_fused");
   return 0;
 }

@@ -109,7 +109,7 @@ SIGNATURES = {
     "mvd_gridattn_fused_slots": (_i, []),
     "mvd_gridattn_fused_stream_bytes": (_sz, []),
     "mvd_gridattn_fused_vec_floats": (_sz, []),
-    "mvd_gridattn_fused": (_i, [_vp] * 12 + [_i, _i, _i, _i, _i, _f, _f, _vp]),
+    "mvd_gridattn_fused": (_i, [_vp] * 12 + [_i, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "mvd_view_mha": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_view_pool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mvd_cfg_ddim_update": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
@@ -482,7 +482,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
 
 # mvd_gemm_desc.cfg = 1 + CFG_STRIDE * tile + 2 * loop + order (include/mvd_hip.h: MVD_GEMM_CFG_STRIDE)
 CFG_STRIDE = 32
-TUNE_CACHE_VERSION = 5             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
+TUNE_CACHE_VERSION = 6             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
 GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch", "ws", "ws-reg", 8)  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
                                  # (3 / 4 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
@@ -509,7 +509,7 @@ def _cfg_valid(cfg, epi, b_mode=0):
     waves = wm * wn
     return (loop not in (2, 3) or waves == 8) and (loop != 3 or tile == 1) and (loop != 5 or waves == 4) and \
         (loop != PATCH_LOOP or tile in (1, 2, 4)) and (tile < 2 or epi == EPI_STORE) and \
-        (loop not in (WS_LOOP, WSR_LOOP) or (tile in (1, 2, 4) and epi == EPI_STORE)) and (loop != REG_LOOP or tile <= 3)
+        (loop not in (WS_LOOP, WSR_LOOP) or tile == 1 or (tile in (2, 4) and epi == EPI_STORE)) and (loop != REG_LOOP or tile <= 3)
 
 
 _ALL_CONFIGS = tuple(c for c in range(1, CFG_STRIDE * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))

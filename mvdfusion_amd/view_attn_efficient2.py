@@ -258,7 +258,7 @@ class GridAttn(nn.Module):
             hip.check(L.mvd_gridattn_fused(hip.ptr(dsrc), hip.ptr(depth_noise), hip.ptr(dsteps), hip.ptr(it), hip.ptr(grid_lin),
                                            hip.ptr(feat), hip.ptr(in_feat), hip.ptr(cams_rec), hip.ptr(in_cam_rec), hip.ptr(stream),
                                            hip.ptr(vecs), hip.ptr(pool), V, q0, Vq, S, D, float(self.depth_scale),
-                                           float(self.depth_shift), hip.stream()))
+                                           float(self.depth_shift), 3 if ctx.prec_of("ga") == 3 else 4, hip.stream()))
             ctx.gemm(pool, w_fin, vol_out, M=nseq, out_planes=vol_planes, out_planes_col=vol_planes_col, kind="ga")
             return vol_out
         tokens = ctx.ws.planes("ga.tokens", T, hip.TOKEN_LD)

@@ -233,8 +233,8 @@ class ViewFusion(nn.Module):
         # reference's eval-mode behaviour bit for bit in distribution (validation curves comparable 1:1).
         self.reference_eval_dropout = bool(reference_eval_dropout)
         # precision = MFMA operand type x number of partial products of the (hi+lo)(hi+lo) operand split:
-        # "f16x4" (default: fp16, all 4 products -- fp32-class; +4 % time over x3 because the GEMMs are operand-delivery
-        # bound), "f16x3" (drops lo*lo, ~2^-22), "bf16x3" (~2^-16), "f16" / "bf16" (one product, hi only).  The operand type selects the library
+        # "f16x3" (default, configs.DEFAULT_PRECISION: fp16 hi + lo, lo*lo dropped, ~2^-22), "f16x4" (all 4 products; +5 - 7 % time, no
+        # measurable accuracy difference: DESIGN.md section 4), "bf16x3" (~2^-16), "f16" / "bf16" (one product, hi only).  The operand type selects the library
         # flavour and is fixed per process.
         # A policy string "f16x4:conv=3,geglu=3" sets the products per layer class (hip.PREC_KINDS).
         from .configs import DEFAULT_PRECISION

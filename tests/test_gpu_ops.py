@@ -220,7 +220,7 @@ def test_gemm_geglu(hip, splitk):
     op = hip.planes_like(M, 4 * C, "cuda")
     hip.gemm(Ap, Wp, None, epi=hip.EPI_GEGLU, workspace=ws, splitk=splitk, out_planes=op)
     assert rel_err(planes_to_float(op), ref) < TOL[3] + PL
-    # every kernel configuration that serves the GEGLU epilogue (incl. the wave-specialised kernel with 128 x 32 consumer tiles)
+    # every kernel configuration that serves the GEGLU epilogue (incl. the wave-specialised kernel: 64 x 64 consumer tiles = two 32-column blocks)
     base = None
     for cfg in hip.gemm_configs(hip.EPI_GEGLU)[::2]:
         out.fill_(float("nan"))
@@ -547,10 +547,14 @@ def test_gemm_layernorm_fold(hip, pcfg, psplit, B, L, H, d, offs):
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).permute(0, 2, 1, 3).reshape(M, C)
     fold = hip.LnFold(torch.cat([wq, wk, wv], 0).cuda(), None, normc)
     planes = hip.alloc_attn_planes(B, H, L, d, "cuda")
-    hip.gemm(tp, fold.w, None, epi=hip.EPI_QKV, qkv=dict(planes=planes, heads=H, dhead=d, L=L), workspace=ws, ln=(rs, fold))
     out = hip.planes_like(M, C, "cuda")
-    hip.attention(planes, out, B, H, L, d)
-    assert rel_err(planes_to_float(out), ref) < 4 * TOL[4] + PL
+    for ccfg in (None, hip.make_cfg(1, hip.WS_LOOP)):      # built-in choice; the wave-specialised kernel (two 32-column blocks per consumer tile)
+        for t_ in planes:
+            t_.zero_()
+        hip.gemm(tp, fold.w, None, epi=hip.EPI_QKV, qkv=dict(planes=planes, heads=H, dhead=d, L=L), workspace=ws, ln=(rs, fold), cfg=ccfg,
+                 splitk=1 if ccfg else 0)
+        hip.attention(planes, out, B, H, L, d)
+        assert rel_err(planes_to_float(out), ref) < 4 * TOL[4] + PL, ccfg
     # consumer 2: GEGLU, reading the rows as a column block of a wider operand buffer and writing its first columns
     Wg = torch.randn(8 * C, C, generator=g(90)) / math.sqrt(C)
     bg = torch.randn(8 * C, generator=g(91))
@@ -559,10 +563,13 @@ def test_gemm_layernorm_fold(hip, pcfg, psplit, B, L, H, d, offs):
     foldg = hip.LnFold(Wg.cuda(), bg.cuda(), normc, geglu=True)
     cat5 = hip.planes_like(M, 5 * C, "cuda")
     cat5[:, 2 * 4 * C:] = tp
-    hip.gemm(cat5[:, 2 * 4 * C:], foldg.w, None, M=M, lda=5 * C, epi=hip.EPI_GEGLU, out_planes=cat5, workspace=ws, ln=(rs, foldg))
-    gotg = planes_to_float(cat5)
-    assert rel_err(gotg[:, :4 * C], refg) < 4 * TOL[4] + PL
-    assert torch.equal(cat5[:, 2 * 4 * C:].cpu(), tp.cpu())
+    for ccfg in (None, hip.make_cfg(1, hip.WS_LOOP)):
+        cat5[:, :2 * 4 * C].zero_()
+        hip.gemm(cat5[:, 2 * 4 * C:], foldg.w, None, M=M, lda=5 * C, epi=hip.EPI_GEGLU, out_planes=cat5, workspace=ws, ln=(rs, foldg), cfg=ccfg,
+                 splitk=1 if ccfg else 0)
+        gotg = planes_to_float(cat5)
+        assert rel_err(gotg[:, :4 * C], refg) < 4 * TOL[4] + PL, ccfg
+        assert torch.equal(cat5[:, 2 * 4 * C:].cpu(), tp.cpu())
 
 
 def test_attention_forced_rescale(hip):
