@@ -270,6 +270,7 @@ def main():
                     "that the default N=1 run times in the same process")
     ap.add_argument("--gn-two-pass", action="store_true", help="A/B: GroupNorm statistics by their own kernels instead of the producers")
     ap.add_argument("--ln-kernels", action="store_true", help="A/B: LayerNorm kernels instead of the fold into the QKV / GEGLU GEMMs")
+    ap.add_argument("--gn-apply-kernels", action="store_true", help="A/B: GroupNorm apply always as its own launch (not inside the split-K reduce)")
     ap.add_argument("--train-step", action="store_true",
                     help="instead of the denoising metric: time the TRAINING step (BASELINE configs[4] per GPU: fwd + bwd + AdamW on one "
                          "scene of --views views, --depth-samples samples; tools/bench_train.py) and print its JSON line")
@@ -330,6 +331,9 @@ def main():
     if a.ln_kernels:
         from mvdfusion_amd import engine as _engine
         _engine.Ctx.ln_fold = False
+    if a.gn_apply_kernels:
+        from mvdfusion_amd import engine as _engine
+        _engine.Ctx.gn_fuse = False
 
     def sync():
         torch.cuda.synchronize()

@@ -190,7 +190,22 @@ typedef struct mvd_gemm_desc {
   const float* ln_colsum;
   int ln_ld, ln_dim;
   float ln_eps;
+  /* GroupNorm APPLY of the output behind the GEMM (openaimodel.py:201-204: GroupNorm32 -> SiLU -> conv of the next layer; needs gn_stats /
+   * gn_hw / gn_groups, MVD_EPI_STORE, out != NULL): after the call gna_out_sp (M, N split planes) holds act(GroupNorm(out) * gamma + beta),
+   * gna_flags bit 0 = SiLU, bit 1 = round the normalised value to fp16 first (as mvd_groupnorm_from_stats' `silu`), bit 2 = `out` itself
+   * has no other reader: the fused path may leave it unwritten.  How: a split-K GEMM whose (image, group) slab of gn_hw x N / gn_groups
+   * values fits 64 KB of LDS runs ONE reduce kernel -- a workgroup per (image, group) sums the slabs, applies the epilogue, keeps the values
+   * in LDS, forms mean / rstd and writes the normalised planes: the separate reduce and apply launches and the fp32 round trip between them
+   * disappear; otherwise the library launches mvd_groupnorm_from_stats behind the GEMM / the reduce.  NULL = off. */
+  void* gna_out_sp;
+  const float* gna_gamma;
+  const float* gna_beta;
+  float gna_eps;
+  int gna_flags;
 } mvd_gemm_desc;
+#define MVD_GNA_SILU 1
+#define MVD_GNA_ROUND_F16 2
+#define MVD_GNA_OUT_UNUSED 4
 
 int mvd_gemm(const mvd_gemm_desc* d, mvd_stream_t stream);
 /* 1 if kernel configuration `cfg` (see mvd_gemm_desc.cfg) serves the problem `d` describes (tile family vs epilogue, loop variant vs

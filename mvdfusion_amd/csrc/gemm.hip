@@ -1828,6 +1828,183 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmParams p) 
   gn_stats_add(d.gn_stats, m0 / d.gn_hw, g, d.gn_groups, ss, qq);
 }
 
+// Split-K reduce + GroupNorm APPLY in one launch (mvd_gemm_desc.gna_out_sp): a workgroup per (image, group).  It sums the split-K slabs
+// of its gn_hw x (N / groups) values, applies the STORE epilogue (scale, bias, per-image bias, residual), keeps the values in LDS, forms
+// the group's mean / rstd (fp32 partial sums per thread in a fixed order, combined in double: deterministic) and writes the normalised,
+// activated values as split planes -- what splitk_reduce_stats_kernel + gn_apply_stats(_cols)_kernel did in two launches with the fp32
+// tensor making a round trip through memory in between (57 such pairs per configs[1] step).  The fp32 output is written unless the
+// caller marks it unused; the statistics slot of the output still receives the sums (another consumer may normalise the same tensor).
+// Mapping: two channels per thread (a group is N / 32 = 10, 20, 40 ... channels wide: 8-byte accesses); the 8 XCDs take runs of
+// groups / 8 neighbouring groups each, so a 128-byte line of a slab row (3.2 groups of 10 channels) is pulled into one or two L2s.
+#define MVD_GNK_THREADS 1024
+__global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p) {
+  // Latency, not bandwidth, is what this kernel has to manage: a workgroup owns a few thousand values spread over gn_hw rows, so every
+  // thread takes U elements at a time and has ALL their operands -- up to ZC slabs, the residual, both biases -- in flight before it
+  // touches one (a first version that walked its elements one by one was a chain of ~10 memory round trips per workgroup and slower than
+  // the two kernels it replaces).  1024 threads: the largest group of a step (1024 x 10 channels) is five elements per thread.
+  constexpr int NT = MVD_GNK_THREADS, NWV = NT / 64, U = 3, ZC = 4;
+  extern __shared__ float s_val[];                 // [gn_hw][cg] values of the group
+  __shared__ double s_red[2][NWV];
+  __shared__ float s_coef[2][128];
+  const mvd_gemm_desc& d = p.d;
+  const int G = d.gn_groups, HW = d.gn_hw;
+  const int cg = d.N / G, cg2 = cg >> 1;
+  int g, b;
+  {
+    const int bid = blockIdx.x;
+    if ((G & 7) == 0) {
+      const int gpx = G >> 3, x = bid & 7, r = bid >> 3;
+      g = x * gpx + r % gpx;
+      b = r / gpx;
+    } else {
+      g = bid % G;
+      b = bid / G;
+    }
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = g * cg, m0 = b * HW;
+  const size_t MN = (size_t)d.M * d.N;
+  const int total = HW * cg2;
+  const bool put_out = d.out != nullptr && !(d.gna_flags & MVD_GNA_OUT_UNUSED);
+  // element e = (row e / cg2, channel pair e % cg2); a thread walks e = tid, tid + NT, ...: (r, j) advance without a division
+  const int dq = NT / cg2, dj = NT - dq * cg2;
+  const int rs = tid / cg2, js = tid - rs * cg2;                 // the thread's first element ...
+  const int r0 = tid < total ? rs : 0, j0 = tid < total ? js : 0; // ... which is also its safe address for the unconditional loads
+  const float* const zero2 = (const float*)g_zero_page;
+  const bool has_bias = d.bias != nullptr, has_bb = d.bias_b != nullptr, has_res = d.res != nullptr;
+  float s = 0.f, q = 0.f;
+  {
+    int r = rs, j = js;
+    for (int e0 = tid; e0 < total; e0 += NT * U) {
+      int rr[U], jj[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ok[u] = e0 + u * NT < total;
+        rr[u] = ok[u] ? r : r0;                    // (elements past the end re-read the thread's first one: every load is unconditional)
+        jj[u] = ok[u] ? j : j0;
+        r += dq;
+        j += dj;
+        if (j >= cg2) {
+          j -= cg2;
+          ++r;
+        }
+      }
+      float2 acc[U], tb[U], tbb[U], tr[U];
+      float2 t[ZC][U];
+      const int nz0 = p.splits < ZC ? p.splits : ZC;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int m = m0 + rr[u], n = c0 + 2 * jj[u];
+        tb[u] = *(const float2*)(has_bias ? d.bias + n : zero2);
+        tbb[u] = *(const float2*)(has_bb ? d.bias_b + (size_t)(m / d.rows_per_batch) * d.ldbb + n : zero2);
+        tr[u] = *(const float2*)(has_res ? d.res + (size_t)m * d.ldr + n : zero2);
+#pragma unroll
+        for (int z = 0; z < ZC; ++z) {
+          const float* w = d.workspace + (size_t)(z < nz0 ? z : 0) * MN + (size_t)m * d.N + n;
+          t[z][u] = *(const float2*)w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        acc[u] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int z = 0; z < ZC; ++z)
+          if (z < nz0) {
+            acc[u].x += t[z][u].x;
+            acc[u].y += t[z][u].y;
+          }
+      }
+      for (int zb = ZC; zb < p.splits; zb += ZC) {               // more than ZC slabs: further rounds of ZC x U loads
+        const int nz = p.splits - zb < ZC ? p.splits - zb : ZC;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int m = m0 + rr[u], n = c0 + 2 * jj[u];
+#pragma unroll
+          for (int z = 0; z < ZC; ++z) t[z][u] = *(const float2*)(d.workspace + (size_t)(zb + (z < nz ? z : 0)) * MN + (size_t)m * d.N + n);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int z = 0; z < ZC; ++z)
+            if (z < nz) {
+              acc[u].x += t[z][u].x;
+              acc[u].y += t[z][u].y;
+            }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float2 v = acc[u];
+        v.x = v.x * d.acc_scale + tb[u].x + tbb[u].x + tr[u].x;
+        v.y = v.y * d.acc_scale + tb[u].y + tbb[u].y + tr[u].y;
+        if (ok[u]) {
+          const int m = m0 + rr[u], n = c0 + 2 * jj[u];
+          if (put_out) *(float2*)(d.out + (size_t)m * d.ldo + n) = v;
+          *(float2*)(s_val + 2 * (e0 + u * NT)) = v;
+          s += v.x + v.y;
+          q += v.x * v.x + v.y * v.y;
+        }
+      }
+    }
+  }
+  {
+    const double sd = wave_sum_d((double)s), qd = wave_sum_d((double)q);
+    if (lane == 0) {
+      s_red[0][wave] = sd;
+      s_red[1][wave] = qd;
+    }
+  }
+  __syncthreads();
+  double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) {
+    S1 += s_red[0][w];
+    S2 += s_red[1][w];
+  }
+  const double cnt = (double)HW * cg;
+  const double mean = S1 / cnt;
+  double var = S2 / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)d.gna_eps));
+  if (tid < cg) {
+    const float a = rstd * d.gna_gamma[c0 + tid];
+    s_coef[0][tid] = a;
+    s_coef[1][tid] = d.gna_beta[c0 + tid] - (float)mean * a;
+  }
+  if (tid == 0 && d.gn_stats) gn_stats_add(d.gn_stats, b, g, G, (float)S1, (float)S2);
+  __syncthreads();
+  u16* const ysp = (u16*)d.gna_out_sp;
+  const int fl = d.gna_flags;
+  {
+    int r = rs, j = js;
+    for (int e = tid; e < total; e += NT) {
+      float2 v = *(const float2*)(s_val + 2 * e);
+      v.x = v.x * s_coef[0][2 * j] + s_coef[1][2 * j];
+      v.y = v.y * s_coef[0][2 * j + 1] + s_coef[1][2 * j + 1];
+      if (fl & MVD_GNA_ROUND_F16) {
+        v.x = (float)(_Float16)v.x;
+        v.y = (float)(_Float16)v.y;
+      }
+      if (fl & MVD_GNA_SILU) {
+        v.x = silu_f(v.x);
+        v.y = silu_f(v.y);
+      }
+      u16 h0, l0, h1, l1;
+      split_op16(v.x, h0, l0);
+      split_op16(v.y, h1, l1);
+      u16* pp = ysp + sp_index((size_t)(m0 + r), d.N, c0 + 2 * j);
+      *(uint32_t*)pp = (uint32_t)h0 | ((uint32_t)h1 << 16);
+      *(uint32_t*)(pp + 32) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+      r += dq;
+      j += dj;
+      if (j >= cg2) {
+        j -= cg2;
+        ++r;
+      }
+    }
+  }
+}
+
 // Tile configurations (mvd_gemm_desc.cfg = 1 + MVD_GEMM_CFG_STRIDE * tile + 2 * loop + order; 0 = built-in heuristic).
 //   tile : 0 = 64x64 (2x2 waves)  1 = 128x128 (2x4)  2 = 128x80 (4x1)  3 = 64x80 (4x1)  4 = 128x160 (4x2)
 //          (a 256x128 tile -- 128x32 wave tiles, 64 MFMAs per k-tile and wave against 20 fragment reads and 6 DMAs -- was built and
@@ -2006,6 +2183,10 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
                       d.N % d.gn_groups == 0,
                   "mvd_gemm: gn_stats needs MVD_EPI_STORE, n_store == N, M %% 16 == 0, gn_hw %% 16 == 0, N %% gn_groups == 0 (N=%d M=%d hw=%d)",
                   d.N, d.M, d.gn_hw);
+  if (d.gna_out_sp)
+    MVD_CHECK_ARG(d.gn_stats && d.out && d.ldo == d.N && d.gna_gamma && d.gna_beta && d.N % 32 == 0 && d.M % d.gn_hw == 0 &&
+                      ((uintptr_t)d.gna_out_sp & 127) == 0,
+                  "mvd_gemm: gna_out_sp (GroupNorm apply behind the GEMM) needs gn_stats, out with ldo == N, gamma / beta, N %% 32 == 0, M %% gn_hw == 0");
   if (d.b_mode == MVD_B_PLANES)
     MVD_CHECK_ARG(d.ldb >= d.K && d.ldb % 32 == 0, "mvd_gemm: B planes need ldb=%d >= K=%d, a multiple of 32", d.ldb, d.K);
   else
@@ -2091,6 +2272,17 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     default: MVD_CHECK_ARG(false, "mvd_gemm: no kernel for tile %d loop %d", tile, loop);
   }
   MVD_CHECK_LAUNCH("mvd_gemm");
+  // GroupNorm apply behind the GEMM (gna_out_sp): one reduce + apply kernel when the (image, group) slab of a split GEMM fits the LDS,
+  // else the ordinary producer statistics followed by the apply kernel
+  const int gna_cg = d.gna_out_sp ? d.N / d.gn_groups : 0;
+  const bool gna_fused = d.gna_out_sp && p.splits > 1 && !d.rs_out && !d.out_sp && !d.colscale && d.act == MVD_ACT_NONE && (gna_cg & 1) == 0 &&
+                         gna_cg <= 128 && (size_t)d.gn_hw * gna_cg * 4 <= 64 * 1024 && d.ldo % 2 == 0 && (!d.res || d.ldr % 2 == 0) &&
+                         (!d.bias_b || d.ldbb % 2 == 0);
+  if (gna_fused) {
+    hipLaunchKernelGGL(splitk_gn_kernel, dim3((d.M / d.gn_hw) * d.gn_groups), dim3(MVD_GNK_THREADS), (size_t)d.gn_hw * gna_cg * 4, s, p);
+    MVD_CHECK_LAUNCH("mvd_gemm/splitk_gn");
+    return 0;
+  }
   if (p.splits > 1) {
     if (d.rs_out) {
       hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(cdiv(d.M, 4), cdiv(d.N, 256)), dim3(256), 0, s, p);
@@ -2108,6 +2300,9 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     }
     MVD_CHECK_LAUNCH("mvd_gemm/splitk_reduce");
   }
+  if (d.gna_out_sp)
+    return mvd_groupnorm_from_stats(d.out, d.gna_out_sp, d.gna_gamma, d.gna_beta, d.gn_stats, d.M / d.gn_hw, d.gn_hw, d.N, d.gn_groups,
+                                    d.gna_eps, d.gna_flags & (MVD_GNA_SILU | MVD_GNA_ROUND_F16), stream);
   return 0;
 }
 

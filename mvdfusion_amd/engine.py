@@ -60,6 +60,7 @@ class Ctx:
     """Per-model execution context handed down the module tree."""
     gn_from_producer = True         # False: every GroupNorm runs its own statistics kernel (A/B measurement, bench.py --gn-two-pass)
     ln_fold = True                  # False: LayerNorm kernels instead of the fold into the QKV / GEGLU GEMMs (A/B: bench.py --ln-kernels)
+    gn_fuse = True                  # False: GroupNorm apply always as its own launch (A/B: bench.py --gn-apply-kernels)
 
     def __init__(self, device, prec=hip.PREC_X4, policy=None):
         self.device = torch.device(device)
@@ -80,12 +81,18 @@ class Ctx:
         self._gn_next = 0
         self._gn = {}               # data_ptr of a produced tensor -> (stats slot, B, HW, C)
         self._rs = {}               # (tag, rows, width) -> hip.RowStats (static: part of the captured graph)
+        # GroupNorm of the NEXT layer, applied by the GEMM that produces this layer's output (TimestepEmbedSequential sets the hint:
+        # (norm module, name of the consumer's planes buffer, silu)); _gn_done: (tensor, norm) -> planes already holding the result
+        self.next_gn = None
+        self._gn_done = {}
 
     def begin_step(self):
         """Reset the rotation of the layer-output buffers: the eager warm-up step and the captured step then walk the
         SAME act{i} slots in the same order (capture never meets a slot the warm-up did not allocate)."""
         self._rot.clear()
         self._gn.clear()
+        self._gn_done.clear()
+        self.next_gn = None
         self._gn_next = 0
         if self.gn_from_producer:          # (one launch of the library's own fill kernel: the step contains no framework kernels)
             hip.check(hip.lib().mvd_fill_zero(hip.ptr(self.gn_arena), self.gn_arena.numel() * 2, hip.stream()))
@@ -128,20 +135,43 @@ class Ctx:
         return (self.ln_fold and hip.OPERAND_FORMAT == "f16" and self.prec_of("qkv") >= hip.PREC_X3 and
                 self.prec_of("geglu") >= hip.PREC_X3 and self.prec_of("proj") >= hip.PREC_X3)
 
-    def gemm(self, A, W, out, gn=None, kind=None, **kw):
+    def gemm(self, A, W, out, gn=None, kind=None, gn_apply=None, **kw):
         """gn=(B, HW): `out` feeds a GroupNorm over (B, HW, N) -- the GEMM emits its statistics (see gn_slot).
+        gn_apply=(norm, planes, silu, out_unused): that GroupNorm (+ SiLU) is applied right behind the GEMM into `planes` -- inside the
+        split-K reduce when the GEMM splits (mvd_gemm_desc.gna_out_sp), else by the apply kernel; out_unused: nothing else reads `out`.
         kind: the layer class of the precision policy (hip.PREC_KINDS)."""
         kw.setdefault("prec", self.prec_of(kind))
         kw.setdefault("workspace", self.gemm_ws)
+        applied = False
         if out is not None:
             self._gn.pop(out.data_ptr(), None)          # whatever statistics the buffer had are stale now
             if gn is not None and self.gn_from_producer and gn[1] % 16 == 0 and out.shape[-1] % 32 == 0:
                 st = self.gn_slot(out, gn[0], gn[1], out.shape[-1])
                 if st is not None:
                     kw.update(gn_stats=st, gn_hw=gn[1], gn_groups=32)
-        return hip.gemm(A, W, out, **kw)
+                    if gn_apply is not None and self.gn_fuse and gn_apply[0].num_groups == 32 and out.is_contiguous():
+                        norm, planes, silu, unused = gn_apply
+                        kw["gn_apply"] = (norm.weight, norm.bias, norm.eps, (hip.GNA_SILU if silu else 0) | (hip.GNA_OUT_UNUSED if unused else 0),
+                                          planes)
+                        applied = True
+                    elif gn_apply is None and self.next_gn is not None and self.gn_fuse and out.is_contiguous():
+                        # the layer's output GEMM: the next layer's GroupNorm rides along (ctx.groupnorm finds the planes in _gn_done)
+                        norm, pname, silu = self.next_gn
+                        if norm.num_groups == 32 and norm.num_channels == out.shape[-1] and out.shape[0] == gn[0] * gn[1]:
+                            planes = self.ws.planes(pname, out.shape[0], out.shape[-1])
+                            kw["gn_apply"] = (norm.weight, norm.bias, norm.eps, hip.GNA_SILU if silu else 0, planes)
+                            self._gn_done[(out.data_ptr(), id(norm))] = (planes, bool(silu))
+        if gn is not None:
+            self.next_gn = None         # (a hint is for the first output-producing GEMM after it was set)
+        r = hip.gemm(A, W, out, **kw)
+        if gn_apply is not None and not applied:
+            self.groupnorm(out, gn_apply[1], gn_apply[0], gn[0], gn[1], out.shape[-1], gn_apply[2])
+        return r
 
     def groupnorm(self, x, y, norm, B, HW, C, silu):
+        done = self._gn_done.pop((x.data_ptr(), id(norm)), None)
+        if done is not None and done[0].data_ptr() == y.data_ptr() and done[0].shape == y.shape and done[1] == bool(silu) and silu in (True, False):
+            return y                    # applied behind the GEMM that produced x
         ent = self._gn.get(x.data_ptr())
         if ent is not None and ent[1:] == (B, HW, C) and norm.num_groups == 32:
             return hip.groupnorm_from_stats(x, y, norm.weight, norm.bias, ent[0], B, HW, C, norm.eps, silu)

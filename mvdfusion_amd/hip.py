@@ -63,6 +63,7 @@ class GemmDesc(C.Structure):
         ("gn_stats", _vp), ("gn_hw", _i), ("gn_groups", _i),
         ("rs_out", _vp), ("rs_count", _vp), ("rs_ld", _i),
         ("ln_stats", _vp), ("ln_count", _vp), ("ln_colsum", _vp), ("ln_ld", _i), ("ln_dim", _i), ("ln_eps", _f),
+        ("gna_out_sp", _vp), ("gna_gamma", _vp), ("gna_beta", _vp), ("gna_eps", _f), ("gna_flags", _i),
     ]
 
 
@@ -392,7 +393,7 @@ def split_planes(x, out=None, ldp=None):
 
 def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
          bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
-         out_planes=None, out_planes_col=0, cfg=None, gn_stats=None, gn_hw=0, gn_groups=32, row_stats=None, ln=None):
+         out_planes=None, out_planes_col=0, cfg=None, gn_stats=None, gn_hw=0, gn_groups=32, row_stats=None, ln=None, gn_apply=None):
     """out = epilogue(A @ W^T).  A: split planes (M, 2*K) int16 (dense) or the NHWC image rows (B*H*W, 2*C) with
     conv=dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
     out: fp32 tensor or None; out_planes: split-planes tensor or None (feeds the next GEMM); out_planes_col: first column
@@ -402,6 +403,8 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     groupnorm_from_stats instead of a statistics kernel).
     row_stats = RowStats: the GEMM also emits per-row {sum, sum of squares} slots of its output (for a LayerNorm folded into the
     consumer); ln = (RowStats of the producer of A, LnFold of this weight): LayerNorm(A rows) folded into this QKV / GEGLU GEMM.
+    gn_apply = (gamma, beta, eps, flags, planes): the GroupNorm consuming `out` is applied behind the GEMM (needs gn_stats): `planes`
+    receives act(GroupNorm(out)) -- fused with the split-K reduce when the GEMM splits (mvd_gemm_desc.gna_out_sp; flags GNA_*).
     """
     assert A.dtype == torch.int16, "A must be in split-planes format (see hip.split_planes)"
     d = GemmDesc()
@@ -452,6 +455,10 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.qscale = float(qkv["dhead"]) ** -0.5 * 1.4426950408889634      # * log2(e): mvd_attention works in base 2
     if gn_stats is not None:
         d.gn_stats, d.gn_hw, d.gn_groups = gn_stats.data_ptr(), int(gn_hw), int(gn_groups)
+    if gn_apply is not None:
+        gamma, beta, eps, flags, planes = gn_apply
+        assert gn_stats is not None and out is not None and planes.dtype == torch.int16 and planes.shape[-1] == 2 * d.N
+        d.gna_gamma, d.gna_beta, d.gna_eps, d.gna_flags, d.gna_out_sp = gamma.data_ptr(), beta.data_ptr(), float(eps), int(flags), planes.data_ptr()
     if row_stats is not None:
         assert row_stats.slots.shape[0] >= d.M and row_stats.ld >= (d.N + 31) // 32
         d.rs_out, d.rs_count, d.rs_ld = row_stats.slots.data_ptr(), row_stats.count.data_ptr(), row_stats.ld
@@ -465,7 +472,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.workspace = workspace.data_ptr()
         d.workspace_elems = workspace.numel()
     key = (d.M, d.N, d.K, d.a_mode, d.Cin, d.stride, d.upsample, d.no_pad_tl, d.epi, d.prec, res is not None, out is not None,
-           out_planes is not None, splitk, d.b_mode, row_stats is not None, ln is not None)
+           out_planes is not None, splitk, d.b_mode, row_stats is not None, ln is not None, gn_apply is not None)
     if cfg is None:
         tuned = _TUNED.get(key)
         if tuned is None and AUTOTUNE and 2.0 * d.M * d.N * d.K >= AUTOTUNE_MIN_FLOPS:
@@ -482,7 +489,8 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
 
 # mvd_gemm_desc.cfg = 1 + CFG_STRIDE * tile + 2 * loop + order (include/mvd_hip.h: MVD_GEMM_CFG_STRIDE)
 CFG_STRIDE = 32
-TUNE_CACHE_VERSION = 6             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
+GNA_SILU, GNA_ROUND_F16, GNA_OUT_UNUSED = 1, 2, 4      # mvd_gemm_desc.gna_flags
+TUNE_CACHE_VERSION = 7             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
 GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch", "ws", "ws-reg", 8)  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
                                  # (3 / 4 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
@@ -598,6 +606,9 @@ def release_tuning_buffers():
     _TRASH = None
 
 
+_TUNE_STATS = {}
+
+
 def _autotune(d, A=None, reps=4, trials=3, W_data=None):
     """Time the kernel configurations (tile x loop variant x tile order; split-K follows from the library's model)
     on the actual operands -- the op is idempotent -- and return the fastest.
@@ -609,6 +620,12 @@ def _autotune(d, A=None, reps=4, trials=3, W_data=None):
     best, best_ms = (0, d.splitk), float("inf")
     e0, e1 = Event(), Event()
     stats_ptr, d.gn_stats = d.gn_stats, None          # the statistics atomics must run exactly once: only in the real launch
+    if d.gna_out_sp:                                   # GroupNorm apply behind the GEMM: needs statistics -- a scratch slot while timing (the
+        n = (d.M // d.gn_hw) * d.gn_groups * 2         # planes it writes are rewritten by the real launch)
+        scratch = _TUNE_STATS.get(n)
+        if scratch is None:
+            scratch = _TUNE_STATS[n] = torch.zeros(n, dtype=torch.int64, device="cuda")
+        d.gn_stats = scratch.data_ptr()
     # split-K: the library's model (0 = auto) or none (1); the timed region includes the reduce kernel of a split GEMM
     # Loops the tuner does not time unless asked (MVD_TUNE_INCLUDE_LOOPS=8,9): the two register-staged delivery paths of round 4 were
     # candidates for a whole session and were selected for NO shape of any workload (profiles/r04_ws_variants.json);

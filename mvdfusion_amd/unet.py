@@ -105,9 +105,10 @@ class ResBlock(TimestepBlock):
         ctx.groupnorm(x, a, self.in_layers[0], B, H * W, Ci, silu=True)
         h = ctx.ws.get("res.h", (M, Co))
         # conv bias + Linear(SiLU(emb)) are folded into one per-step bias vector (UNetModel._time_biases)
-        ctx.gemm(a, w1, h, conv=dict(Cin=Ci, **geo), bias=False, bias_b=ctx.emb_bias[self], rows_per_batch=M, gn=(B, H * W), kind="conv")
         a2 = ctx.ws.planes("res.a2", M, Co)
-        ctx.groupnorm(h, a2, self.out_layers[0], B, H * W, Co, silu=True)
+        # GroupNorm + SiLU of h right behind the convolution (inside its split-K reduce when it splits); h itself has no other reader
+        ctx.gemm(a, w1, h, conv=dict(Cin=Ci, **geo), bias=False, bias_b=ctx.emb_bias[self], rows_per_batch=M, gn=(B, H * W), kind="conv",
+                 gn_apply=(self.out_layers[0], a2, True, True))
         skip = x
         if wsk is not None:
             if x_planes is None:
@@ -120,19 +121,37 @@ class ResBlock(TimestepBlock):
         return out
 
 
+def gn_hint(layer):
+    """(GroupNorm module, name of its planes buffer, silu) of the GroupNorm a layer starts with -- what the PREVIOUS layer's output GEMM
+    needs to apply it on the way out (Ctx.next_gn); None for layers that do not start with one."""
+    from .attention import SpatialTransformer, ViewAlignedFeatureTransformer
+    if isinstance(layer, tuple):                      # an explicit hint (the UNet head's GroupNorm)
+        return layer
+    if isinstance(layer, ResBlock):
+        return layer.in_layers[0], "res.a", True
+    if isinstance(layer, SpatialTransformer):
+        return layer.norm, "tf.n", False
+    if isinstance(layer, ViewAlignedFeatureTransformer):
+        return layer.aligned_attn_norm, "tf.n", False
+    return None
+
+
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
-    def run(self, ctx, x, H, W, out=None, x_planes=None):
+    def run(self, ctx, x, H, W, out=None, x_planes=None, next_layer=None):
         """Run the layers in order; `out` (optional) is the buffer the LAST layer must write (skip tensors);
-        `x_planes`: split-bf16 planes of x when the caller has them (the concat kernel writes both)."""
+        `x_planes`: split-bf16 planes of x when the caller has them (the concat kernel writes both); next_layer: the layer that
+        consumes this block's output directly (its leading GroupNorm is applied by the last layer's output GEMM)."""
         n = len(self)
         for i, layer in enumerate(self):
             dst = out if i == n - 1 else None
+            ctx.next_gn = gn_hint(self[i + 1] if i + 1 < n else next_layer)
             if isinstance(layer, (Upsample, Downsample)):
                 x, H, W = layer.run(ctx, x, H, W, out=dst)
             elif isinstance(layer, ResBlock):
                 x = layer.run(ctx, x, H, W, out=dst, x_planes=x_planes if i == 0 else None)
             else:
                 x = layer.run(ctx, x, H, W, out=dst)
+            ctx.next_gn = None
         return x, H, W
 
 
@@ -289,17 +308,20 @@ class UNetModel(nn.Module):
                 rec.append((blk, h.clone(), H, W, 0))
             if bi == 0:
                 o = ctx.ws.get("hs0", (B * H * W, self.model_channels))
+                ctx.next_gn = gn_hint(self.input_blocks[1][0])
                 h = blk[0].run(ctx, h, H, W, o)
+                ctx.next_gn = None
             else:
                 last = blk[-1]
                 Ho, Wo = (H // 2, W // 2) if isinstance(last, Downsample) else (H, W)
                 co = last.out_channels if isinstance(last, (ResBlock, Downsample)) else last.in_channels
                 o = ctx.ws.get(f"hs{bi}", (B * Ho * Wo, co))      # skip tensors get their own static buffers
-                h, H, W = blk.run(ctx, h, H, W, out=o)
+                nxt = self.input_blocks[bi + 1][0] if bi + 1 < len(self.input_blocks) else self.middle_block[0]
+                h, H, W = blk.run(ctx, h, H, W, out=o, next_layer=nxt)
             hs.append((h, H, W))
         if rec is not None:
             rec.append((self.middle_block, h.clone(), H, W, 0))
-        h, H, W = self.middle_block.run(ctx, h, H, W)
+        h, H, W = self.middle_block.run(ctx, h, H, W)       # (its output goes into the first concat: no direct GroupNorm consumer)
         for blk in self.output_blocks:
             sk, _, _ = hs.pop()
             M = B * H * W
@@ -309,7 +331,9 @@ class UNetModel(nn.Module):
             ctx.concat(h, ca, sk, cb, cat, catp, B, H * W)
             if rec is not None:
                 rec.append((blk, cat.clone(), H, W, ca))
-            h, H, W = blk.run(ctx, cat, H, W, x_planes=catp)
+            # (a decoder block's output goes into the next concat; the last one feeds the head's GroupNorm + SiLU)
+            h, H, W = blk.run(ctx, cat, H, W, x_planes=catp,
+                              next_layer=(self.out[0], "res.a", True) if blk is self.output_blocks[-1] else None)
         if self._head is None:
             self._head = hip.pack_conv3x3(self.out[2].weight, self.out[2].bias)
         M = B * H * W

@@ -358,6 +358,64 @@ def test_gemm_groupnorm_statistics(hip, cfg, splitk):
         assert rel_err(planes_to_float(y).view(B, HW, N), ref) < PL + 3e-6, (B, HW, N, K)
 
 
+@pytest.mark.parametrize("splitk", [0, 1, 2, 5])
+@pytest.mark.parametrize("flags", [1, 0, 3, 5])
+def test_gemm_groupnorm_apply_behind_the_gemm(hip, splitk, flags):
+    """mvd_gemm_desc.gna_out_sp: GroupNorm (+ SiLU) of the output applied behind the GEMM -- ONE reduce + apply kernel per (image, group)
+    when the GEMM splits K and the group's slab fits the LDS (splitk_gn_kernel), otherwise producer statistics + the apply kernel launched
+    by the library.  Every path must reproduce F.group_norm of the reference output, leave the fp32 output and the statistics slot of
+    the output valid (another consumer may normalise it), and be repeatable bit for bit.  Shapes: a 3x3 convolution with a per-image
+    bias (ResBlock conv1 + time embedding, openaimodel.py:262-270), dense GEMMs with a residual, groups of 10 / 20 / 40 / 2 channels,
+    one slab (4096 x 10 floats = 160 KB) that does not fit -> fallback."""
+    ws = torch.empty(32 * 1024 * 1024, device="cuda")
+    cases = [("conv", 2, 16, 64, 320), ("conv", 3, 64, 96, 640), ("dense", 2, 256, 320, 1280), ("dense", 1, 1024, 96, 64), ("dense", 1, 4096, 64, 320),
+             ("dense", 4, 16, 160, 64)]
+    for kind, B, HW, K, N in cases:
+        M = B * HW
+        gm, bt = torch.randn(N, generator=g(64)) + 1.0, torch.randn(N, generator=g(65))
+        bb = torch.randn(N, generator=g(66))
+        if kind == "conv":
+            H = int(math.isqrt(HW))
+            x = torch.randn(B, K, H, H, generator=g(60)) + 0.2
+            w = torch.randn(N, K, 3, 3, generator=g(61)) / math.sqrt(9 * K)
+            ref = F.conv2d(x, w, None, padding=1).permute(0, 2, 3, 1).reshape(M, N) + bb
+            Wp = hip.pack_conv3x3(w.cuda(), None)
+            ap = hip.split_planes(x.permute(0, 2, 3, 1).reshape(M, K).contiguous().cuda())
+            kw = dict(conv=dict(B=B, Hin=H, Win=H, Cin=K, Hout=H, Wout=H, stride=1, upsample=0), bias=False, bias_b=bb.cuda(), rows_per_batch=M)
+        else:
+            a = torch.randn(M, K, generator=g(60)) + 0.1
+            w = torch.randn(N, K, generator=g(61)) / math.sqrt(K)
+            b = torch.randn(N, generator=g(62))
+            r = torch.randn(M, N, generator=g(63))
+            ref = a @ w.t() + b + r
+            Wp = hip.pack_linear(w.cuda(), b.cuda())
+            ap = hip.split_planes(a.cuda())
+            kw = dict(res=r.cuda())
+        want = F.group_norm(ref.view(B, HW, N).permute(0, 2, 1), 32, gm, bt, eps=1e-5).permute(0, 2, 1).reshape(M, N)
+        if flags & 2:
+            want = want.half().float()
+        if flags & 1:
+            want = F.silu(want)
+        gc, bc = gm.cuda(), bt.cuda()
+        runs = []
+        for rep in range(2):
+            out = torch.full((M, N), float("nan"), device="cuda")
+            y = hip.planes_like(M, N, "cuda")
+            y.fill_(0x7e00)
+            st = torch.zeros(B, 32, 2, dtype=torch.int64, device="cuda")
+            hip.gemm(ap, Wp, out, prec=4, workspace=ws, splitk=splitk, gn_stats=st, gn_hw=HW, gn_apply=(gc, bc, 1e-5, flags, y), **kw)
+            runs.append((planes_to_float(y).cpu(), st.cpu(), out.cpu()))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        tol = (2e-3 if flags & 2 else 0.0) + PL + 4e-6        # (fp16 rounding of the normalised value: a value next to a rounding boundary may flip)
+        assert rel_err(runs[0][0], want) < tol, (kind, B, HW, K, N)
+        if not flags & 4:                                      # the fp32 output is part of the contract unless marked unused
+            assert rel_err(runs[0][2], ref) < TOL[4], (kind, B, HW, K, N)
+            # ... and its statistics slot serves any other GroupNorm over the same tensor
+            y2 = hip.planes_like(M, N, "cuda")
+            hip.groupnorm_from_stats(out, y2, gc, bc, st, B, HW, N, 1e-5, flags & 3)
+            assert rel_err(planes_to_float(y2).cpu(), want) < tol, (kind, B, HW, K, N)
+
+
 def test_concat_groupnorm_statistics(hip):
     for B, HW, ca, cb in [(2, 64, 1280, 1280), (4, 1024, 320, 320), (3, 16, 64, 32)]:
         M = B * HW
