@@ -282,6 +282,15 @@ int mvd_unet_input(const float* x, const float* input_latents, void* out_sp, int
 /* out[r, 0:Ca] = a[r], out[r, Ca:Ca+Cb] = b[r]  (torch.cat([h, hs.pop()], dim=1), unet.py:550) */
 int mvd_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, void* out_sp, int rows, long long* gn_stats,
                         int gn_hw, int gn_groups, mvd_stream_t stream);
+/* concat + the GroupNorm (+ SiLU) that consumes it, in one launch (unet.py:550 -> openaimodel.py:201-204): y_sp (B*hw, Ca+Cb planes) =
+ * act(GroupNorm([a | b]) * gamma + beta), raw_sp (optional) = planes of [a | b] itself (the ResBlock's 1x1 skip convolution reads them),
+ * out (optional) = the fp32 concatenation, gn_stats (optional) = the {sum, sum of squares} slot of the result as mvd_concat_channels
+ * writes it.  `silu`: bit 0 SiLU, bit 1 fp16 rounding first.  A workgroup per (image, group) holds its hw x (C / groups) values in LDS:
+ * mvd_concat_groupnorm_fits() tells whether a shape is served (even Ca, Cb and group width, <= 128 KiB per group); otherwise use
+ * mvd_concat_channels + mvd_groupnorm_from_stats. */
+int mvd_concat_groupnorm_fits(int Ca, int Cb, int hw, int groups);
+int mvd_concat_groupnorm(const float* a, int Ca, const float* b, int Cb, float* out, void* raw_sp, void* y_sp, const float* gamma,
+                         const float* beta, long long* gn_stats, int B, int hw, int groups, float eps, int silu, mvd_stream_t stream);
 /* out_sp optional: split planes for the 1x1 skip conv; gn_stats optional: GroupNorm statistics of `out` (as mvd_gemm_desc.gn_stats;
  * rows % 16 == 0, gn_hw % 16 == 0, (Ca + Cb) % gn_groups == 0, Ca + Cb <= 2560) */
 /* area pooling by `factor` of vol (B, S, S, D, C) -> (B, S/f, S/f, D, C)  (unet.py:198-209).  Output: split planes with

@@ -144,6 +144,142 @@ __global__ __launch_bounds__(256) void concat_stats_kernel(const float4* __restr
   gn_stats_add(stats, (int)(m0 / hw), g, groups, ss, qq);
 }
 
+// concat + GroupNorm (+ SiLU) of the result in ONE launch (unet.py:550 torch.cat([h, hs.pop()]) -> ResBlock in_layers, openaimodel.py:201-204):
+// a workgroup per (image, group) gathers its hw x (C / groups) values from the two sources into LDS, forms mean / rstd (fp32 partials per
+// thread in a fixed order, combined in double) and writes the normalised planes, the RAW planes (the ResBlock's 1x1 skip convolution
+// reads those) and, on request, the fp32 concatenation -- what concat_stats_kernel + gn_apply_stats(_cols)_kernel did in two launches.
+// Same structure as splitk_gn_kernel (gemm.hip): two channels per thread, U elements' loads in flight at a time.
+#define MVD_CGN_THREADS 1024
+__global__ __launch_bounds__(MVD_CGN_THREADS) void concat_gn_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb,
+                                                                    float* __restrict__ out, u16* __restrict__ raw_sp, u16* __restrict__ y_sp,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    long long* __restrict__ stats, int hw, int groups, float eps, int flags) {
+  constexpr int NT = MVD_CGN_THREADS, NWV = NT / 64, U = 4;
+  extern __shared__ float s_val[];
+  __shared__ double s_red[2][NWV];
+  __shared__ float s_coef[2][128];
+  const int C = ca + cb, cg = C / groups, cg2 = cg >> 1;
+  int g, img;
+  {
+    const int bid = blockIdx.x;
+    if ((groups & 7) == 0) {
+      const int gpx = groups >> 3, x = bid & 7, r = bid >> 3;
+      g = x * gpx + r % gpx;
+      img = r / gpx;
+    } else {
+      g = bid % groups;
+      img = bid / groups;
+    }
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = g * cg;
+  const size_t m0 = (size_t)img * hw;
+  const int total = hw * cg2;
+  const int dq = NT / cg2, dj = NT - dq * cg2;
+  const int rs = tid / cg2, js = tid - rs * cg2;
+  const int r0 = tid < total ? rs : 0, j0 = tid < total ? js : 0;
+  float s = 0.f, q = 0.f;
+  {
+    int r = rs, j = js;
+    for (int e0 = tid; e0 < total; e0 += NT * U) {
+      float2 v[U];
+      int rr[U], jj[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ok[u] = e0 + u * NT < total;
+        rr[u] = ok[u] ? r : r0;
+        jj[u] = ok[u] ? j : j0;
+        r += dq;
+        j += dj;
+        if (j >= cg2) {
+          j -= cg2;
+          ++r;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t m = m0 + rr[u];
+        const int n = c0 + 2 * jj[u];
+        v[u] = *(const float2*)(n < ca ? a + m * ca + n : b + m * cb + (n - ca));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ok[u]) {
+          const size_t m = m0 + rr[u];
+          const int n = c0 + 2 * jj[u];
+          if (out) *(float2*)(out + m * C + n) = v[u];
+          if (raw_sp) {
+            u16 h0, l0, h1, l1;
+            split_op16(v[u].x, h0, l0);
+            split_op16(v[u].y, h1, l1);
+            u16* pp = raw_sp + sp_index(m, C, n);
+            *(uint32_t*)pp = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            *(uint32_t*)(pp + 32) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+          }
+          *(float2*)(s_val + 2 * (e0 + u * NT)) = v[u];
+          s += v[u].x + v[u].y;
+          q += v[u].x * v[u].x + v[u].y * v[u].y;
+        }
+      }
+    }
+  }
+  {
+    const double sd = wave_sum_d((double)s), qd = wave_sum_d((double)q);
+    if (lane == 0) {
+      s_red[0][wave] = sd;
+      s_red[1][wave] = qd;
+    }
+  }
+  __syncthreads();
+  double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) {
+    S1 += s_red[0][w];
+    S2 += s_red[1][w];
+  }
+  const double cnt = (double)hw * cg;
+  const double mean = S1 / cnt;
+  double var = S2 / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (tid < cg) {
+    const float aa = rstd * gamma[c0 + tid];
+    s_coef[0][tid] = aa;
+    s_coef[1][tid] = beta[c0 + tid] - (float)mean * aa;
+  }
+  if (tid == 0 && stats) gn_stats_add(stats, img, g, groups, (float)S1, (float)S2);
+  __syncthreads();
+  {
+    int r = rs, j = js;
+    for (int e = tid; e < total; e += NT) {
+      float2 v = *(const float2*)(s_val + 2 * e);
+      v.x = v.x * s_coef[0][2 * j] + s_coef[1][2 * j];
+      v.y = v.y * s_coef[0][2 * j + 1] + s_coef[1][2 * j + 1];
+      if (flags & 2) {
+        v.x = (float)(_Float16)v.x;
+        v.y = (float)(_Float16)v.y;
+      }
+      if (flags & 1) {
+        v.x = silu_f(v.x);
+        v.y = silu_f(v.y);
+      }
+      u16 h0, l0, h1, l1;
+      split_op16(v.x, h0, l0);
+      split_op16(v.y, h1, l1);
+      u16* pp = y_sp + sp_index(m0 + r, C, c0 + 2 * j);
+      *(uint32_t*)pp = (uint32_t)h0 | ((uint32_t)h1 << 16);
+      *(uint32_t*)(pp + 32) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+      r += dq;
+      j += dj;
+      if (j >= cg2) {
+        j -= cg2;
+        ++r;
+      }
+    }
+  }
+}
+
 // vol (B,S,S,D,C) -> out (B,S/f,S/f,D,C), mean over f x f windows (F.interpolate(mode='area') with integer ratio)
 __global__ __launch_bounds__(256) void area_pool_kernel(const float4* __restrict__ vol, u16* __restrict__ out_sp, int B, int S,
                                                         int D, int C4, int f, int ldp) {
@@ -277,6 +413,35 @@ extern "C" int mvd_concat_channels(const float* a, int Ca, const float* b, int C
   hipLaunchKernelGGL(concat_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, Ca / 4,
                      (const float4*)b, Cb / 4, (float4*)out, (u16*)out_sp, (size_t)rows);
   MVD_CHECK_LAUNCH("mvd_concat_channels");
+  return 0;
+}
+
+extern "C" int mvd_concat_groupnorm_fits(int Ca, int Cb, int hw, int groups) {
+  const int C = Ca + Cb;
+  if (groups <= 0 || C % groups || (Ca & 1) || (Cb & 1)) return 0;
+  const int cg = C / groups;
+  return (cg & 1) == 0 && cg <= 128 && (size_t)hw * cg * 4 <= 128 * 1024 ? 1 : 0;
+}
+
+extern "C" int mvd_concat_groupnorm(const float* a, int Ca, const float* b, int Cb, float* out, void* raw_sp, void* y_sp, const float* gamma,
+                                    const float* beta, long long* gn_stats, int B, int hw, int groups, float eps, int silu,
+                                    mvd_stream_t stream) {
+  MVD_CHECK_ARG(a && b && y_sp && gamma && beta && B > 0 && hw > 0, "mvd_concat_groupnorm: null pointer / bad shape");
+  MVD_CHECK_ARG((Ca + Cb) % 32 == 0 && mvd_concat_groupnorm_fits(Ca, Cb, hw, groups),
+                "mvd_concat_groupnorm: needs (Ca+Cb) %% 32 == 0, even Ca / Cb / group width <= 128 and hw * (C / groups) * 4 <= 128 KiB of LDS "
+                "(Ca=%d Cb=%d hw=%d groups=%d): use mvd_concat_channels + mvd_groupnorm_from_stats", Ca, Cb, hw, groups);
+  MVD_CHECK_ARG(((uintptr_t)a & 7) == 0 && ((uintptr_t)b & 7) == 0 && ((uintptr_t)out & 7) == 0 && ((uintptr_t)y_sp & 127) == 0 &&
+                    ((uintptr_t)raw_sp & 127) == 0, "mvd_concat_groupnorm: alignment");
+  const size_t lds = (size_t)hw * ((Ca + Cb) / groups) * 4;
+  static bool raised = false;
+  if (!raised) {      // (more than the default 64 KiB of dynamic LDS: the largest groups of a step are 1024 rows x 30 channels)
+    const hipError_t e = hipFuncSetAttribute((const void*)concat_gn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    MVD_CHECK_ARG(e == hipSuccess, "mvd_concat_groupnorm: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
+    raised = true;
+  }
+  hipLaunchKernelGGL(concat_gn_kernel, dim3(B * groups), dim3(MVD_CGN_THREADS), lds, (hipStream_t)stream, a, Ca, b, Cb, out, (u16*)raw_sp,
+                     (u16*)y_sp, gamma, beta, gn_stats, hw, groups, eps, silu);
+  MVD_CHECK_LAUNCH("mvd_concat_groupnorm");
   return 0;
 }
 

@@ -85,6 +85,7 @@ class Ctx:
         # (norm module, name of the consumer's planes buffer, silu)); _gn_done: (tensor, norm) -> planes already holding the result
         self.next_gn = None
         self._gn_done = {}
+        self._unwritten = set()     # data_ptr of fp32 tensors a fused producer did NOT write (their normalised planes exist instead)
 
     def begin_step(self):
         """Reset the rotation of the layer-output buffers: the eager warm-up step and the captured step then walk the
@@ -92,6 +93,7 @@ class Ctx:
         self._rot.clear()
         self._gn.clear()
         self._gn_done.clear()
+        self._unwritten.clear()
         self.next_gn = None
         self._gn_next = 0
         if self.gn_from_producer:          # (one launch of the library's own fill kernel: the step contains no framework kernels)
@@ -172,6 +174,8 @@ class Ctx:
         done = self._gn_done.pop((x.data_ptr(), id(norm)), None)
         if done is not None and done[0].data_ptr() == y.data_ptr() and done[0].shape == y.shape and done[1] == bool(silu) and silu in (True, False):
             return y                    # applied behind the GEMM that produced x
+        if x.data_ptr() in self._unwritten:
+            raise RuntimeError("GroupNorm of a tensor whose fused producer left the fp32 data unwritten (Ctx.concat(need_out=False))")
         ent = self._gn.get(x.data_ptr())
         if ent is not None and ent[1:] == (B, HW, C) and norm.num_groups == 32:
             return hip.groupnorm_from_stats(x, y, norm.weight, norm.bias, ent[0], B, HW, C, norm.eps, silu)
@@ -179,10 +183,28 @@ class Ctx:
         ws = self.ws.get("gn_ws", (B * hip.lib().mvd_groupnorm_chunks(HW) * 32 * 2,), torch.float64)
         return hip.groupnorm(x, y, norm.weight, norm.bias, B, HW, C, norm.eps, silu, ws)
 
-    def concat(self, a, ca, b, cb, out, out_planes, B, HW):
-        """out = [a | b] along the channels (+ its split planes), with the GroupNorm statistics of the result."""
+    def concat(self, a, ca, b, cb, out, out_planes, B, HW, gn_apply=None, need_out=True):
+        """out = [a | b] along the channels (+ its split planes), with the GroupNorm statistics of the result.
+        gn_apply = (norm, planes buffer name, silu): the GroupNorm that consumes the result is applied in the same launch
+        (mvd_concat_groupnorm) when a group fits the LDS; need_out=False: nobody reads the fp32 concatenation itself."""
         self._gn.pop(out.data_ptr(), None)
+        self._unwritten.discard(out.data_ptr())
         st = None
+        if gn_apply is not None and self.gn_fuse and self.gn_from_producer and HW % 16 == 0 and (ca + cb) % 32 == 0 and \
+                gn_apply[0].num_groups == 32 and gn_apply[0].num_channels == ca + cb and \
+                hip.lib().mvd_concat_groupnorm_fits(ca, cb, HW, 32):
+            norm, pname, silu = gn_apply
+            st = self.gn_slot(out, B, HW, ca + cb)
+            planes = self.ws.planes(pname, B * HW, ca + cb)
+            hip.check(hip.lib().mvd_concat_groupnorm(hip.ptr(a), ca, hip.ptr(b), cb, hip.ptr(out) if need_out else None, hip.ptr(out_planes),
+                                                     hip.ptr(planes), hip.ptr(norm.weight), hip.ptr(norm.bias),
+                                                     hip.ptr(st) if st is not None else None, B, HW, 32, norm.eps, 1 if silu else 0,
+                                                     hip.stream()))
+            if not need_out:
+                self._gn.pop(out.data_ptr(), None)      # (no fp32 data behind the statistics slot: nobody may normalise `out` again)
+                self._unwritten.add(out.data_ptr())
+            self._gn_done[(out.data_ptr(), id(norm))] = (planes, bool(silu))
+            return out
         if self.gn_from_producer and HW % 16 == 0 and (ca + cb) % 32 == 0:
             st = self.gn_slot(out, B, HW, ca + cb)
         hip.check(hip.lib().mvd_concat_channels(hip.ptr(a), ca, hip.ptr(b), cb, hip.ptr(out), hip.ptr(out_planes), B * HW,

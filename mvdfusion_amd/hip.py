@@ -90,6 +90,8 @@ SIGNATURES = {
     "mvd_pixel_cross_attn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_unet_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvd_concat_channels": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "mvd_concat_groupnorm_fits": (_i, [_i, _i, _i, _i]),
+    "mvd_concat_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "mvd_transpose_planes": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "mvd_im2col3x3_t_planes": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "mvd_col_sum_workspace_doubles": (_sz, [_i, _i]),

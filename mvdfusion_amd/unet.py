@@ -328,7 +328,11 @@ class UNetModel(nn.Module):
             ca, cb = h.shape[-1], sk.shape[-1]
             cat = ctx.ws.get("cat", (M, ca + cb))
             catp = ctx.ws.planes("catp", M, ca + cb)          # planes for the ResBlock's 1x1 skip conv
-            ctx.concat(h, ca, sk, cb, cat, catp, B, H * W)
+            # concat + the block's leading GroupNorm / SiLU in one launch; the fp32 concatenation itself is only read by a ResBlock
+            # without a skip convolution (none in this decoder) and by the training recorder
+            first = blk[0]
+            need_cat = rec is not None or not isinstance(first, ResBlock) or isinstance(first.skip_connection, nn.Identity)
+            ctx.concat(h, ca, sk, cb, cat, catp, B, H * W, gn_apply=gn_hint(first), need_out=need_cat)
             if rec is not None:
                 rec.append((blk, cat.clone(), H, W, ca))
             # (a decoder block's output goes into the next concat; the last one feeds the head's GroupNorm + SiLU)

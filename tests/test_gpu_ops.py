@@ -416,6 +416,45 @@ def test_gemm_groupnorm_apply_behind_the_gemm(hip, splitk, flags):
             assert rel_err(planes_to_float(y2).cpu(), want) < tol, (kind, B, HW, K, N)
 
 
+@pytest.mark.parametrize("silu", [1, 0])
+def test_concat_groupnorm_one_launch(hip, silu):
+    """mvd_concat_groupnorm: torch.cat([h, skip], 1) -> GroupNorm32 -> SiLU (unet.py:550, openaimodel.py:201-204) in one launch: normalised
+    planes, raw planes (the 1x1 skip convolution's operand), optional fp32 concatenation and statistics slot; groups of 80 / 60 / 30 / 20
+    channels that straddle the boundary between the two sources (640 | 320 with 30-channel groups), the largest slab of a step
+    (1024 rows x 30 channels = 120 KB of LDS), and a shape the kernel does not serve (odd group width)."""
+    L = hip.lib()
+    assert not L.mvd_concat_groupnorm_fits(64, 32, 16, 32) and not L.mvd_concat_groupnorm_fits(320, 320, 4096, 32)
+    for B, HW, ca, cb in [(2, 64, 1280, 1280), (2, 256, 1280, 640), (4, 1024, 640, 320), (3, 1024, 320, 320), (1, 16, 1280, 1280), (2, 256, 640, 640)]:
+        assert L.mvd_concat_groupnorm_fits(ca, cb, HW, 32)
+        M, C = B * HW, ca + cb
+        a, b = torch.randn(M, ca, generator=g(56)) * 2, torch.randn(M, cb, generator=g(57)) + 0.5
+        gm, bt = torch.randn(C, generator=g(58)), torch.randn(C, generator=g(59))
+        ad, bd, gc, bc = a.cuda(), b.cuda(), gm.cuda(), bt.cuda()
+        cat = torch.cat([a, b], 1)
+        ref = F.group_norm(cat.view(B, HW, C).permute(0, 2, 1), 32, gm, bt, eps=1e-5).permute(0, 2, 1).reshape(M, C)
+        if silu:
+            ref = F.silu(ref)
+        outs = []
+        for rep, with_out in enumerate((True, False, True)):
+            out = torch.full((M, C), float("nan"), device="cuda")
+            raw, y = hip.planes_like(M, C, "cuda"), hip.planes_like(M, C, "cuda")
+            st = torch.zeros(B, 32, 2, dtype=torch.int64, device="cuda")
+            hip.check(L.mvd_concat_groupnorm(hip.ptr(ad), ca, hip.ptr(bd), cb, hip.ptr(out) if with_out else None, hip.ptr(raw), hip.ptr(y),
+                                             hip.ptr(gc), hip.ptr(bc), hip.ptr(st), B, HW, 32, 1e-5, silu, hip.stream()))
+            outs.append((planes_to_float(y).cpu(), planes_to_float(raw).cpu(), st.cpu()))
+            if with_out:
+                assert torch.equal(out.cpu(), cat)
+            else:
+                assert bool(torch.isnan(out).all())
+        assert all(torch.equal(outs[0][i], outs[2][i]) and torch.equal(outs[0][i], outs[1][i]) for i in range(3))
+        assert rel_err(outs[0][0], ref) < PL + 4e-6, (B, HW, ca, cb)
+        assert rel_err(outs[0][1], cat) < PL
+        # the statistics slot serves mvd_groupnorm_from_stats on the fp32 concatenation
+        y2 = hip.planes_like(M, C, "cuda")
+        hip.groupnorm_from_stats(cat.cuda(), y2, gc, bc, outs[0][2].cuda(), B, HW, C, 1e-5, silu)
+        assert rel_err(planes_to_float(y2).cpu(), ref) < PL + 4e-6
+
+
 def test_concat_groupnorm_statistics(hip):
     for B, HW, ca, cb in [(2, 64, 1280, 1280), (4, 1024, 320, 320), (3, 16, 64, 32)]:
         M = B * HW
