@@ -202,6 +202,14 @@ typedef struct mvd_gemm_desc {
   const float* gna_beta;
   float gna_eps;
   int gna_flags;
+  /* ... over a CONCATENATION (unet.py:550: h = torch.cat([h, hs.pop()], 1) feeding the next ResBlock): with cat_b = the (M, cat_cb) fp32
+   * skip tensor the GroupNorm of gna_* runs over [out | cat_b] (N + cat_cb channels; gn_stats / gna_out_sp / gamma / beta refer to the
+   * concatenation), and cat_raw_sp (optional) receives the split planes of [out | cat_b] itself (operand of the ResBlock's 1x1 skip
+   * convolution).  Split GEMM: the one reduce kernel reads the skip tensor next to the slabs; else mvd_concat_groupnorm runs behind the
+   * GEMM.  Shapes: mvd_concat_groupnorm_fits(N, cat_cb, gn_hw, gn_groups).  NULL = off. */
+  const float* cat_b;
+  int cat_cb;
+  void* cat_raw_sp;
 } mvd_gemm_desc;
 #define MVD_GNA_SILU 1
 #define MVD_GNA_ROUND_F16 2

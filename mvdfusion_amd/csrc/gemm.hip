@@ -1848,7 +1848,9 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
   __shared__ float s_coef[2][128];
   const mvd_gemm_desc& d = p.d;
   const int G = d.gn_groups, HW = d.gn_hw;
-  const int cg = d.N / G, cg2 = cg >> 1;
+  // (concat mode, mvd_gemm_desc.cat_b: the GroupNorm runs over [out | cat_b], CT = N + cat_cb channels; channels >= N come from cat_b)
+  const int CT = d.N + (d.cat_b ? d.cat_cb : 0);
+  const int cg = CT / G, cg2 = cg >> 1;
   int g, b;
   {
     const int bid = blockIdx.x;
@@ -1893,12 +1895,17 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
       float2 acc[U], tb[U], tbb[U], tr[U];
       float2 t[ZC][U];
       const int nz0 = p.splits < ZC ? p.splits : ZC;
+      bool own[U];                                  // the element is a column of THIS GEMM (else: of cat_b)
+      float2 tc[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int m = m0 + rr[u], n = c0 + 2 * jj[u];
+        const int m = m0 + rr[u], nn = c0 + 2 * jj[u];
+        own[u] = nn < d.N;
+        const int n = own[u] ? nn : 0;              // (a cat_b element reads column 0 of the slabs and drops it: loads stay unconditional)
         tb[u] = *(const float2*)(has_bias ? d.bias + n : zero2);
         tbb[u] = *(const float2*)(has_bb ? d.bias_b + (size_t)(m / d.rows_per_batch) * d.ldbb + n : zero2);
         tr[u] = *(const float2*)(has_res ? d.res + (size_t)m * d.ldr + n : zero2);
+        tc[u] = *(const float2*)(own[u] ? zero2 : d.cat_b + (size_t)m * d.cat_cb + (nn - d.N));
 #pragma unroll
         for (int z = 0; z < ZC; ++z) {
           const float* w = d.workspace + (size_t)(z < nz0 ? z : 0) * MN + (size_t)m * d.N + n;
@@ -1919,7 +1926,7 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
         const int nz = p.splits - zb < ZC ? p.splits - zb : ZC;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int m = m0 + rr[u], n = c0 + 2 * jj[u];
+          const int m = m0 + rr[u], n = own[u] ? c0 + 2 * jj[u] : 0;
 #pragma unroll
           for (int z = 0; z < ZC; ++z) t[z][u] = *(const float2*)(d.workspace + (size_t)(zb + (z < nz ? z : 0)) * MN + (size_t)m * d.N + n);
         }
@@ -1937,9 +1944,18 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
         float2 v = acc[u];
         v.x = v.x * d.acc_scale + tb[u].x + tbb[u].x + tr[u].x;
         v.y = v.y * d.acc_scale + tb[u].y + tbb[u].y + tr[u].y;
+        if (!own[u]) v = tc[u];
         if (ok[u]) {
           const int m = m0 + rr[u], n = c0 + 2 * jj[u];
-          if (put_out) *(float2*)(d.out + (size_t)m * d.ldo + n) = v;
+          if (put_out && own[u]) *(float2*)(d.out + (size_t)m * d.ldo + n) = v;
+          if (d.cat_raw_sp) {                      // raw planes of [out | cat_b] (the next ResBlock's 1x1 skip convolution reads them)
+            u16 h0, l0, h1, l1;
+            split_op16(v.x, h0, l0);
+            split_op16(v.y, h1, l1);
+            u16* pp = (u16*)d.cat_raw_sp + sp_index((size_t)m, CT, n);
+            *(uint32_t*)pp = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            *(uint32_t*)(pp + 32) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+          }
           *(float2*)(s_val + 2 * (e0 + u * NT)) = v;
           s += v.x + v.y;
           q += v.x * v.x + v.y * v.y;
@@ -1992,7 +2008,7 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
       u16 h0, l0, h1, l1;
       split_op16(v.x, h0, l0);
       split_op16(v.y, h1, l1);
-      u16* pp = ysp + sp_index((size_t)(m0 + r), d.N, c0 + 2 * j);
+      u16* pp = ysp + sp_index((size_t)(m0 + r), CT, c0 + 2 * j);
       *(uint32_t*)pp = (uint32_t)h0 | ((uint32_t)h1 << 16);
       *(uint32_t*)(pp + 32) = (uint32_t)l0 | ((uint32_t)l1 << 16);
       r += dq;
@@ -2187,6 +2203,14 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     MVD_CHECK_ARG(d.gn_stats && d.out && d.ldo == d.N && d.gna_gamma && d.gna_beta && d.N % 32 == 0 && d.M % d.gn_hw == 0 &&
                       ((uintptr_t)d.gna_out_sp & 127) == 0,
                   "mvd_gemm: gna_out_sp (GroupNorm apply behind the GEMM) needs gn_stats, out with ldo == N, gamma / beta, N %% 32 == 0, M %% gn_hw == 0");
+  if (d.cat_b)
+    MVD_CHECK_ARG(d.gna_out_sp && d.cat_cb > 0 && d.cat_cb % 2 == 0 && (d.N + d.cat_cb) % 32 == 0 && (d.N + d.cat_cb) % d.gn_groups == 0 &&
+                      ((uintptr_t)d.cat_b & 7) == 0 && ((uintptr_t)d.cat_raw_sp & 127) == 0 &&
+                      mvd_concat_groupnorm_fits(d.N, d.cat_cb, d.gn_hw, d.gn_groups),
+                  "mvd_gemm: cat_b (GroupNorm over [out | cat_b]) needs gna_out_sp, an even cat_cb, (N + cat_cb) %% 32 == 0 and a shape "
+                  "mvd_concat_groupnorm_fits() accepts (N=%d cat_cb=%d hw=%d)", d.N, d.cat_cb, d.gn_hw);
+  long long* const gna_stats = d.gn_stats;       // the statistics slot of the tensor the GroupNorm normalises ...
+  if (d.cat_b) d.gn_stats = nullptr;             // ... which in concat mode is [out | cat_b]: the GEMM's own epilogue / reduce must not touch it
   if (d.b_mode == MVD_B_PLANES)
     MVD_CHECK_ARG(d.ldb >= d.K && d.ldb % 32 == 0, "mvd_gemm: B planes need ldb=%d >= K=%d, a multiple of 32", d.ldb, d.K);
   else
@@ -2274,12 +2298,21 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   MVD_CHECK_LAUNCH("mvd_gemm");
   // GroupNorm apply behind the GEMM (gna_out_sp): one reduce + apply kernel when the (image, group) slab of a split GEMM fits the LDS,
   // else the ordinary producer statistics followed by the apply kernel
-  const int gna_cg = d.gna_out_sp ? d.N / d.gn_groups : 0;
+  const int gna_ct = d.N + (d.cat_b ? d.cat_cb : 0);
+  const int gna_cg = d.gna_out_sp ? gna_ct / d.gn_groups : 0;
+  const size_t gna_lds = (size_t)d.gn_hw * gna_cg * 4;
   const bool gna_fused = d.gna_out_sp && p.splits > 1 && !d.rs_out && !d.out_sp && !d.colscale && d.act == MVD_ACT_NONE && (gna_cg & 1) == 0 &&
-                         gna_cg <= 128 && (size_t)d.gn_hw * gna_cg * 4 <= 64 * 1024 && d.ldo % 2 == 0 && (!d.res || d.ldr % 2 == 0) &&
-                         (!d.bias_b || d.ldbb % 2 == 0);
+                         gna_cg <= 128 && gna_lds <= 128 * 1024 && d.ldo % 2 == 0 && (!d.res || d.ldr % 2 == 0) && (!d.bias_b || d.ldbb % 2 == 0) &&
+                         d.N % 2 == 0;
   if (gna_fused) {
-    hipLaunchKernelGGL(splitk_gn_kernel, dim3((d.M / d.gn_hw) * d.gn_groups), dim3(MVD_GNK_THREADS), (size_t)d.gn_hw * gna_cg * 4, s, p);
+    static bool raised = false;
+    if (!raised) {     // (more than the default 64 KiB of dynamic LDS: 1024 rows x 30 channels of a concatenation)
+      const hipError_t e = hipFuncSetAttribute((const void*)splitk_gn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      MVD_CHECK_ARG(e == hipSuccess, "mvd_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
+      raised = true;
+    }
+    p.d.gn_stats = gna_stats;      // (the slot of the normalised tensor -- of the concatenation in concat mode)
+    hipLaunchKernelGGL(splitk_gn_kernel, dim3((d.M / d.gn_hw) * d.gn_groups), dim3(MVD_GNK_THREADS), gna_lds, s, p);
     MVD_CHECK_LAUNCH("mvd_gemm/splitk_gn");
     return 0;
   }
@@ -2300,6 +2333,9 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     }
     MVD_CHECK_LAUNCH("mvd_gemm/splitk_reduce");
   }
+  if (d.gna_out_sp && d.cat_b)     // concat mode without the fused reduce: the output just written + cat_b -> one concat-and-normalise launch
+    return mvd_concat_groupnorm(d.out, d.N, d.cat_b, d.cat_cb, nullptr, d.cat_raw_sp, d.gna_out_sp, d.gna_gamma, d.gna_beta, gna_stats,
+                                d.M / d.gn_hw, d.gn_hw, d.gn_groups, d.gna_eps, d.gna_flags & (MVD_GNA_SILU | MVD_GNA_ROUND_F16), stream);
   if (d.gna_out_sp)
     return mvd_groupnorm_from_stats(d.out, d.gna_out_sp, d.gna_gamma, d.gna_beta, d.gn_stats, d.M / d.gn_hw, d.gn_hw, d.N, d.gn_groups,
                                     d.gna_eps, d.gna_flags & (MVD_GNA_SILU | MVD_GNA_ROUND_F16), stream);

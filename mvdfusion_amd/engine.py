@@ -7,6 +7,8 @@ captured in a single hipGraph and replayed 50 times with no host work in between
 layers of the same shape (keeps the working set inside the 256 MB Infinity Cache); 288 GB of HBM makes the arena size
 a non-issue.
 """
+import os
+
 import torch
 
 from . import hip
@@ -86,6 +88,10 @@ class Ctx:
         self.next_gn = None
         self._gn_done = {}
         self._unwritten = set()     # data_ptr of fp32 tensors a fused producer did NOT write (their normalised planes exist instead)
+        # the decoder's concat + GroupNorm, done by the GEMM that produces the block output (UNetModel.run sets the hint for a block's last
+        # layer): (skip tensor, cat buffer, raw planes buffer, norm module, planes buffer name, silu); _cat_done: cat buffers so produced
+        self.next_cat = None
+        self._cat_done = set()
 
     def begin_step(self):
         """Reset the rotation of the layer-output buffers: the eager warm-up step and the captured step then walk the
@@ -94,7 +100,9 @@ class Ctx:
         self._gn.clear()
         self._gn_done.clear()
         self._unwritten.clear()
+        self._cat_done.clear()
         self.next_gn = None
+        self.next_cat = None
         self._gn_next = 0
         if self.gn_from_producer:          # (one launch of the library's own fill kernel: the step contains no framework kernels)
             hip.check(hip.lib().mvd_fill_zero(hip.ptr(self.gn_arena), self.gn_arena.numel() * 2, hip.stream()))
@@ -147,7 +155,28 @@ class Ctx:
         applied = False
         if out is not None:
             self._gn.pop(out.data_ptr(), None)          # whatever statistics the buffer had are stale now
-            if gn is not None and self.gn_from_producer and gn[1] % 16 == 0 and out.shape[-1] % 32 == 0:
+            self._unwritten.discard(out.data_ptr())
+            handled = False
+            if gn is not None and gn_apply is None and self.next_cat is not None and self.gn_fuse and self.gn_from_producer and \
+                    gn[1] % 16 == 0 and out.is_contiguous():
+                # the block output goes straight into torch.cat([h, skip]) -> GroupNorm -> SiLU of the next decoder block: this GEMM's
+                # reduce (or one launch behind it) writes the normalised planes and the raw planes of the concatenation
+                sk, cat, catp, norm, pname, silu = self.next_cat
+                N, cb = out.shape[-1], sk.shape[-1]
+                if norm.num_groups == 32 and norm.num_channels == N + cb and sk.shape[0] == out.shape[0] == gn[0] * gn[1] and \
+                        sk.is_contiguous() and hip.lib().mvd_concat_groupnorm_fits(N, cb, gn[1], 32):
+                    st = self.gn_slot(cat, gn[0], gn[1], N + cb)
+                    if st is not None:
+                        planes = self.ws.planes(pname, out.shape[0], N + cb)
+                        kw.update(gn_stats=st, gn_hw=gn[1], gn_groups=32, cat=(sk, catp),
+                                  gn_apply=(norm.weight, norm.bias, norm.eps, (hip.GNA_SILU if silu else 0) | hip.GNA_OUT_UNUSED, planes))
+                        self._gn.pop(cat.data_ptr(), None)          # (the fp32 concatenation is not written: nothing to re-normalise)
+                        self._gn_done[(cat.data_ptr(), id(norm))] = (planes, bool(silu))
+                        self._unwritten.add(cat.data_ptr())
+                        self._unwritten.add(out.data_ptr())
+                        self._cat_done.add(cat.data_ptr())
+                        handled = True
+            if not handled and gn is not None and self.gn_from_producer and gn[1] % 16 == 0 and out.shape[-1] % 32 == 0:
                 st = self.gn_slot(out, gn[0], gn[1], out.shape[-1])
                 if st is not None:
                     kw.update(gn_stats=st, gn_hw=gn[1], gn_groups=32)
@@ -164,7 +193,12 @@ class Ctx:
                             kw["gn_apply"] = (norm.weight, norm.bias, norm.eps, hip.GNA_SILU if silu else 0, planes)
                             self._gn_done[(out.data_ptr(), id(norm))] = (planes, bool(silu))
         if gn is not None:
-            self.next_gn = None         # (a hint is for the first output-producing GEMM after it was set)
+            if os.environ.get("MVD_GN_DEBUG") and not self.capturing:
+                print(f"[gn] kind={kind} M={out.shape[0]} N={out.shape[-1]} explicit={gn_apply is not None} hint={self.next_gn is not None} "
+                      f"cat={self.next_cat is not None} -> fused_apply={'gn_apply' in kw} cat={'cat' in kw}", flush=True)
+            if gn_apply is None:        # (the hints are for the layer's OUTPUT GEMM; a ResBlock's conv1 -- explicit gn_apply -- leaves them)
+                self.next_gn = None
+                self.next_cat = None
         r = hip.gemm(A, W, out, **kw)
         if gn_apply is not None and not applied:
             self.groupnorm(out, gn_apply[1], gn_apply[0], gn[0], gn[1], out.shape[-1], gn_apply[2])

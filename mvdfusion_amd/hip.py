@@ -64,6 +64,7 @@ class GemmDesc(C.Structure):
         ("rs_out", _vp), ("rs_count", _vp), ("rs_ld", _i),
         ("ln_stats", _vp), ("ln_count", _vp), ("ln_colsum", _vp), ("ln_ld", _i), ("ln_dim", _i), ("ln_eps", _f),
         ("gna_out_sp", _vp), ("gna_gamma", _vp), ("gna_beta", _vp), ("gna_eps", _f), ("gna_flags", _i),
+        ("cat_b", _vp), ("cat_cb", _i), ("cat_raw_sp", _vp),
     ]
 
 
@@ -395,7 +396,7 @@ def split_planes(x, out=None, ldp=None):
 
 def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
          bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
-         out_planes=None, out_planes_col=0, cfg=None, gn_stats=None, gn_hw=0, gn_groups=32, row_stats=None, ln=None, gn_apply=None):
+         out_planes=None, out_planes_col=0, cfg=None, gn_stats=None, gn_hw=0, gn_groups=32, row_stats=None, ln=None, gn_apply=None, cat=None):
     """out = epilogue(A @ W^T).  A: split planes (M, 2*K) int16 (dense) or the NHWC image rows (B*H*W, 2*C) with
     conv=dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
     out: fp32 tensor or None; out_planes: split-planes tensor or None (feeds the next GEMM); out_planes_col: first column
@@ -407,6 +408,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     consumer); ln = (RowStats of the producer of A, LnFold of this weight): LayerNorm(A rows) folded into this QKV / GEGLU GEMM.
     gn_apply = (gamma, beta, eps, flags, planes): the GroupNorm consuming `out` is applied behind the GEMM (needs gn_stats): `planes`
     receives act(GroupNorm(out)) -- fused with the split-K reduce when the GEMM splits (mvd_gemm_desc.gna_out_sp; flags GNA_*).
+    cat = (skip (M, cb) fp32, raw planes (M, 2 * (N + cb)) or None): the GroupNorm of gn_apply runs over [out | skip] (mvd_gemm_desc.cat_b).
     """
     assert A.dtype == torch.int16, "A must be in split-planes format (see hip.split_planes)"
     d = GemmDesc()
@@ -459,7 +461,12 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.gn_stats, d.gn_hw, d.gn_groups = gn_stats.data_ptr(), int(gn_hw), int(gn_groups)
     if gn_apply is not None:
         gamma, beta, eps, flags, planes = gn_apply
-        assert gn_stats is not None and out is not None and planes.dtype == torch.int16 and planes.shape[-1] == 2 * d.N
+        ct = d.N + (cat[0].shape[-1] if cat is not None else 0)
+        assert gn_stats is not None and out is not None and planes.dtype == torch.int16 and planes.shape[-1] == 2 * ct
+        if cat is not None:
+            skip, raw = cat
+            assert skip.dtype == torch.float32 and skip.is_contiguous() and skip.shape[0] == d.M and (raw is None or raw.shape[-1] == 2 * ct)
+            d.cat_b, d.cat_cb, d.cat_raw_sp = skip.data_ptr(), int(skip.shape[-1]), (raw.data_ptr() if raw is not None else None)
         d.gna_gamma, d.gna_beta, d.gna_eps, d.gna_flags, d.gna_out_sp = gamma.data_ptr(), beta.data_ptr(), float(eps), int(flags), planes.data_ptr()
     if row_stats is not None:
         assert row_stats.slots.shape[0] >= d.M and row_stats.ld >= (d.N + 31) // 32
@@ -474,7 +481,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         d.workspace = workspace.data_ptr()
         d.workspace_elems = workspace.numel()
     key = (d.M, d.N, d.K, d.a_mode, d.Cin, d.stride, d.upsample, d.no_pad_tl, d.epi, d.prec, res is not None, out is not None,
-           out_planes is not None, splitk, d.b_mode, row_stats is not None, ln is not None, gn_apply is not None)
+           out_planes is not None, splitk, d.b_mode, row_stats is not None, ln is not None, gn_apply is not None, cat[0].shape[-1] if cat is not None else 0)
     if cfg is None:
         tuned = _TUNED.get(key)
         if tuned is None and AUTOTUNE and 2.0 * d.M * d.N * d.K >= AUTOTUNE_MIN_FLOPS:
@@ -492,7 +499,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
 # mvd_gemm_desc.cfg = 1 + CFG_STRIDE * tile + 2 * loop + order (include/mvd_hip.h: MVD_GEMM_CFG_STRIDE)
 CFG_STRIDE = 32
 GNA_SILU, GNA_ROUND_F16, GNA_OUT_UNUSED = 1, 2, 4      # mvd_gemm_desc.gna_flags
-TUNE_CACHE_VERSION = 7             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
+TUNE_CACHE_VERSION = 8             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
 GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch", "ws", "ws-reg", 8)  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
                                  # (3 / 4 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel

@@ -137,14 +137,16 @@ def gn_hint(layer):
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
-    def run(self, ctx, x, H, W, out=None, x_planes=None, next_layer=None):
+    def run(self, ctx, x, H, W, out=None, x_planes=None, next_layer=None, next_cat=None):
         """Run the layers in order; `out` (optional) is the buffer the LAST layer must write (skip tensors);
         `x_planes`: split-bf16 planes of x when the caller has them (the concat kernel writes both); next_layer: the layer that
-        consumes this block's output directly (its leading GroupNorm is applied by the last layer's output GEMM)."""
+        consumes this block's output directly (its leading GroupNorm is applied by the last layer's output GEMM); next_cat: the block
+        output goes into the decoder's next concat (Ctx.next_cat: the last layer's output GEMM produces that concat's planes)."""
         n = len(self)
         for i, layer in enumerate(self):
             dst = out if i == n - 1 else None
             ctx.next_gn = gn_hint(self[i + 1] if i + 1 < n else next_layer)
+            ctx.next_cat = next_cat if i == n - 1 else None
             if isinstance(layer, (Upsample, Downsample)):
                 x, H, W = layer.run(ctx, x, H, W, out=dst)
             elif isinstance(layer, ResBlock):
@@ -152,6 +154,7 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
             else:
                 x = layer.run(ctx, x, H, W, out=dst)
             ctx.next_gn = None
+            ctx.next_cat = None
         return x, H, W
 
 
@@ -321,23 +324,44 @@ class UNetModel(nn.Module):
             hs.append((h, H, W))
         if rec is not None:
             rec.append((self.middle_block, h.clone(), H, W, 0))
-        h, H, W = self.middle_block.run(ctx, h, H, W)       # (its output goes into the first concat: no direct GroupNorm consumer)
-        for blk in self.output_blocks:
+        def cat_hint(nblk, co, Hn, Wn):
+            """Ctx.next_cat for the concat in front of decoder block `nblk`, whose first operand (co channels at Hn x Wn) the current
+            block is about to produce: (skip, cat buffer, raw planes buffer, norm, planes name, silu); None where the concat kernel stays."""
+            first = nblk[0]
+            if rec is not None or not isinstance(first, ResBlock) or isinstance(first.skip_connection, nn.Identity):
+                return None                                  # (the fp32 concatenation has a reader there)
+            nsk = hs[-1][0]
+            Mn = B * Hn * Wn
+            return (nsk, ctx.ws.get("cat", (Mn, co + nsk.shape[-1])), ctx.ws.planes("catp", Mn, co + nsk.shape[-1])) + gn_hint(first)
+
+        def out_geometry(blk, H, W):
+            last = blk[-1]
+            co = last.out_channels if isinstance(last, (ResBlock, Upsample)) else last.in_channels
+            return (co, 2 * H, 2 * W) if isinstance(last, Upsample) else (co, H, W)
+
+        # (the middle block's output goes into the first concat, a decoder block's into the next one: no direct GroupNorm consumer, but
+        #  the GEMM that produces it can write that concat's normalised + raw planes -- Ctx.next_cat)
+        h, H, W = self.middle_block.run(ctx, h, H, W, next_cat=cat_hint(self.output_blocks[0], *out_geometry(self.middle_block, H, W)))
+        for bi, blk in enumerate(self.output_blocks):
             sk, _, _ = hs.pop()
             M = B * H * W
             ca, cb = h.shape[-1], sk.shape[-1]
             cat = ctx.ws.get("cat", (M, ca + cb))
             catp = ctx.ws.planes("catp", M, ca + cb)          # planes for the ResBlock's 1x1 skip conv
-            # concat + the block's leading GroupNorm / SiLU in one launch; the fp32 concatenation itself is only read by a ResBlock
-            # without a skip convolution (none in this decoder) and by the training recorder
             first = blk[0]
-            need_cat = rec is not None or not isinstance(first, ResBlock) or isinstance(first.skip_connection, nn.Identity)
-            ctx.concat(h, ca, sk, cb, cat, catp, B, H * W, gn_apply=gn_hint(first), need_out=need_cat)
+            if cat.data_ptr() in ctx._cat_done:               # produced by the previous block's output GEMM
+                ctx._cat_done.discard(cat.data_ptr())
+            else:
+                # concat + the block's leading GroupNorm / SiLU in one launch; the fp32 concatenation itself is only read by a ResBlock
+                # without a skip convolution (none in this decoder) and by the training recorder
+                need_cat = rec is not None or not isinstance(first, ResBlock) or isinstance(first.skip_connection, nn.Identity)
+                ctx.concat(h, ca, sk, cb, cat, catp, B, H * W, gn_apply=gn_hint(first), need_out=need_cat)
             if rec is not None:
                 rec.append((blk, cat.clone(), H, W, ca))
+            last_blk = bi + 1 == len(self.output_blocks)
             # (a decoder block's output goes into the next concat; the last one feeds the head's GroupNorm + SiLU)
-            h, H, W = blk.run(ctx, cat, H, W, x_planes=catp,
-                              next_layer=(self.out[0], "res.a", True) if blk is self.output_blocks[-1] else None)
+            h, H, W = blk.run(ctx, cat, H, W, x_planes=catp, next_layer=(self.out[0], "res.a", True) if last_blk else None,
+                              next_cat=None if last_blk else cat_hint(self.output_blocks[bi + 1], *out_geometry(blk, H, W)))
         if self._head is None:
             self._head = hip.pack_conv3x3(self.out[2].weight, self.out[2].bias)
         M = B * H * W

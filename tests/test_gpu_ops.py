@@ -416,6 +416,57 @@ def test_gemm_groupnorm_apply_behind_the_gemm(hip, splitk, flags):
             assert rel_err(planes_to_float(y2).cpu(), want) < tol, (kind, B, HW, K, N)
 
 
+@pytest.mark.parametrize("splitk", [0, 1, 3])
+def test_gemm_concat_groupnorm_behind_the_gemm(hip, splitk):
+    """mvd_gemm_desc.cat_b: the GEMM's output goes straight into torch.cat([out, skip], 1) -> GroupNorm32 -> SiLU (unet.py:550 -> the next
+    ResBlock's in_layers): the split-K reduce kernel (or one launch behind an unsplit GEMM) writes the normalised planes and the raw planes
+    of the concatenation; neither the GEMM output nor the concatenation needs to exist in fp32.  3x3 convolution with residual (a decoder
+    ResBlock's conv2) and a dense GEMM; groups straddling the boundary (640 | 320: 30 channels per group)."""
+    ws = torch.empty(32 * 1024 * 1024, device="cuda")
+    for kind, B, HW, K, N, cb in [("conv", 2, 64, 64, 640, 320), ("conv", 2, 16, 96, 1280, 1280), ("dense", 2, 256, 320, 640, 640),
+                                  ("dense", 1, 1024, 128, 320, 320)]:
+        M, C = B * HW, N + cb
+        gm, bt = torch.randn(C, generator=g(74)) + 1.0, torch.randn(C, generator=g(75))
+        sk = torch.randn(M, cb, generator=g(76)) * 1.5 + 0.3
+        r = torch.randn(M, N, generator=g(73))
+        if kind == "conv":
+            H = int(math.isqrt(HW))
+            x = torch.randn(B, K, H, H, generator=g(70)) + 0.2
+            w = torch.randn(N, K, 3, 3, generator=g(71)) / math.sqrt(9 * K)
+            bias = torch.randn(N, generator=g(72))
+            ref = F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1).reshape(M, N) + r
+            Wp = hip.pack_conv3x3(w.cuda(), bias.cuda())
+            ap = hip.split_planes(x.permute(0, 2, 3, 1).reshape(M, K).contiguous().cuda())
+            kw = dict(conv=dict(B=B, Hin=H, Win=H, Cin=K, Hout=H, Wout=H, stride=1, upsample=0), res=r.cuda())
+        else:
+            a = torch.randn(M, K, generator=g(70)) + 0.1
+            w = torch.randn(N, K, generator=g(71)) / math.sqrt(K)
+            bias = torch.randn(N, generator=g(72))
+            ref = a @ w.t() + bias + r
+            Wp = hip.pack_linear(w.cuda(), bias.cuda())
+            ap = hip.split_planes(a.cuda())
+            kw = dict(res=r.cuda())
+        cat = torch.cat([ref, sk], 1)
+        want = F.silu(F.group_norm(cat.view(B, HW, C).permute(0, 2, 1), 32, gm, bt, eps=1e-5).permute(0, 2, 1).reshape(M, C))
+        gc, bc, skc = gm.cuda(), bt.cuda(), sk.cuda()
+        runs = []
+        for rep in range(2):
+            out = torch.full((M, N), float("nan"), device="cuda")
+            y, raw = hip.planes_like(M, C, "cuda"), hip.planes_like(M, C, "cuda")
+            st = torch.zeros(B, 32, 2, dtype=torch.int64, device="cuda")
+            hip.gemm(ap, Wp, out, prec=4, workspace=ws, splitk=splitk, gn_stats=st, gn_hw=HW,
+                     gn_apply=(gc, bc, 1e-5, hip.GNA_SILU | hip.GNA_OUT_UNUSED, y), cat=(skc, raw), **kw)
+            runs.append((planes_to_float(y).cpu(), planes_to_float(raw).cpu(), st.cpu()))
+        assert all(torch.equal(runs[0][i], runs[1][i]) for i in range(3))
+        assert rel_err(runs[0][0], want) < PL + 4e-6, (kind, B, HW, K, N, cb)
+        assert rel_err(runs[0][1], cat) < TOL[4] + PL, (kind, B, HW, K, N, cb)
+        # the statistics slot is the concatenation's
+        cg = C // 32
+        xg = cat.double().view(B, HW, 32, cg)
+        sums = torch.stack([xg.sum(dim=(1, 3)), (xg * xg).sum(dim=(1, 3))], -1)
+        assert rel_err(runs[0][2].double() / 2.0 ** 24, sums) < 1e-5
+
+
 @pytest.mark.parametrize("silu", [1, 0])
 def test_concat_groupnorm_one_launch(hip, silu):
     """mvd_concat_groupnorm: torch.cat([h, skip], 1) -> GroupNorm32 -> SiLU (unet.py:550, openaimodel.py:201-204) in one launch: normalised
