@@ -63,6 +63,8 @@ class Ctx:
     gn_from_producer = True         # False: every GroupNorm runs its own statistics kernel (A/B measurement, bench.py --gn-two-pass)
     ln_fold = True                  # False: LayerNorm kernels instead of the fold into the QKV / GEGLU GEMMs (A/B: bench.py --ln-kernels)
     gn_fuse = True                  # False: GroupNorm apply always as its own launch (A/B: bench.py --gn-apply-kernels)
+    keep_fp32 = False               # True (training forwards: the backward reads the blocks' fp32 inputs from the workspace): fused producers
+                                    # write every fp32 tensor they would otherwise skip (the decoder's concatenations)
 
     def __init__(self, device, prec=hip.PREC_X4, policy=None):
         self.device = torch.device(device)

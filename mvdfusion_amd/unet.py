@@ -324,11 +324,13 @@ class UNetModel(nn.Module):
             hs.append((h, H, W))
         if rec is not None:
             rec.append((self.middle_block, h.clone(), H, W, 0))
+        keep = rec is not None or ctx.keep_fp32               # a backward will read the blocks' fp32 inputs
+
         def cat_hint(nblk, co, Hn, Wn):
             """Ctx.next_cat for the concat in front of decoder block `nblk`, whose first operand (co channels at Hn x Wn) the current
             block is about to produce: (skip, cat buffer, raw planes buffer, norm, planes name, silu); None where the concat kernel stays."""
             first = nblk[0]
-            if rec is not None or not isinstance(first, ResBlock) or isinstance(first.skip_connection, nn.Identity):
+            if keep or not isinstance(first, ResBlock) or isinstance(first.skip_connection, nn.Identity):
                 return None                                  # (the fp32 concatenation has a reader there)
             nsk = hs[-1][0]
             Mn = B * Hn * Wn
@@ -354,7 +356,7 @@ class UNetModel(nn.Module):
             else:
                 # concat + the block's leading GroupNorm / SiLU in one launch; the fp32 concatenation itself is only read by a ResBlock
                 # without a skip convolution (none in this decoder) and by the training recorder
-                need_cat = rec is not None or not isinstance(first, ResBlock) or isinstance(first.skip_connection, nn.Identity)
+                need_cat = keep or not isinstance(first, ResBlock) or isinstance(first.skip_connection, nn.Identity)
                 ctx.concat(h, ca, sk, cb, cat, catp, B, H * W, gn_apply=gn_hint(first), need_out=need_cat)
             if rec is not None:
                 rec.append((blk, cat.clone(), H, W, ca))

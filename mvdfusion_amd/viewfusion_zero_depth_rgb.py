@@ -480,8 +480,14 @@ class ViewFusion(nn.Module):
         s1m = self.scheduler.sqrt_one_minus_alphas_cumprod.to(dev)[t].view(V, 1, 1, 1)
         noisy = sac * batch_latents + s1m * noise                                          # scheduler.q_sample (:55-64)
         prev_depth = input_latents[:, 4:].clone() if self.feed_prev_depth else None          # (:377-379)
-        pred = self.apply_model(noisy, batch_cameras, input_latents, input_cameras, clip_v_embed, t, prev_depth=prev_depth,
-                                depth_noise=depth_noise, drop_rand=drop_rand)
+        from . import engine as _engine
+        keep, force = _engine.Ctx.keep_fp32, getattr(self, "_force_eager", False)
+        _engine.Ctx.keep_fp32, self._force_eager = True, True      # the backward reads block inputs from the workspace: every fp32 tensor is
+        try:                                                      # written, and no graph captured in inference mode is replayed
+            pred = self.apply_model(noisy, batch_cameras, input_latents, input_cameras, clip_v_embed, t, prev_depth=prev_depth,
+                                    depth_noise=depth_noise, drop_rand=drop_rand)
+        finally:
+            _engine.Ctx.keep_fp32, self._force_eager = keep, force
         if self.objective == "noise":
             target = noise
         elif self.objective == "x_start":
