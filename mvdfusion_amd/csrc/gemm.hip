@@ -28,8 +28,12 @@
 // covered by the partner's MFMAs.  Two LDS buffers for the other two variants: 2 = plain (DMA of k-tile t+1 in flight under the MFMAs of t;
 // two co-resident workgroups per CU hide each other's waits), 3 = register-pipelined (fragments of t+1 read and DMA of
 // t+2 issued under the MFMAs of t).  One `s_waitcnt vmcnt lgkmcnt` + raw `s_barrier` per k-tile.
-// NS = 1: acc += A_hi*B_hi.  NS = 3: acc += A_lo*B_hi + A_hi*B_lo + A_hi*B_hi.  NS = 4: + A_lo*B_lo first (the kernel is
-// operand-delivery bound, not MFMA bound, so the 4th product is almost free and removes the 2^-22 truncation term).
+// NS = 1: acc += A_hi*B_hi.  NS = 3 (the default, "f16x3"): acc += A_lo*B_hi + A_hi*B_lo + A_hi*B_hi.  NS = 4: + A_lo*B_lo first.  The
+// fourth product is NOT free: measured -5 ... -7 % step time for x3 (the long-K convolutions are ~50 % MFMA-bound; the short-K
+// projections do not care), and its 2^-22 term is below the fp32 accumulation noise -- indistinguishable in the 50-step trajectory
+// (DESIGN.md section 4).
+// Also here: the split-K reduce kernels, among them splitk_gn_kernel -- reduce + epilogue + GroupNorm / SiLU of the output (optionally over
+// its concatenation with a skip tensor) in one launch, a workgroup per (image, group) with the group's values in LDS.
 #include <stdlib.h>
 #include <type_traits>
 
