@@ -631,6 +631,45 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert ctypes.sizeof(hip.GemmDesc) > 0
 
 
+def test_gemm_descriptor_layout_matches_the_header(tmp_path):
+    """struct mvd_gemm_desc crosses the boundary by pointer: the ctypes mirror (hip.GemmDesc) must have the header's field order, offsets
+    and size -- gcc compiles the header as plain C and prints offsetof() of every field; a mismatch (a field added on one side only)
+    would make the library read garbage without any error."""
+    import shutil
+    import subprocess
+    from mvdfusion_amd import hip
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    fields = [f[0] for f in hip.GemmDesc._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mvd_hip.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{f} %zu\\n", offsetof(mvd_gemm_desc, {f}));\n' for f in fields) +
+                   '  printf("sizeof %zu\\n", sizeof(mvd_gemm_desc));\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]         # (also: the header is valid C, every mirrored field exists in it)
+    got = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip().splitlines())
+    for f in fields:
+        assert int(got[f]) == getattr(hip.GemmDesc, f).offset, (f, got[f], getattr(hip.GemmDesc, f).offset)
+    assert int(got["sizeof"]) == ctypes.sizeof(hip.GemmDesc)
+    # ... and no field of the header is missing from the mirror: count the declarators of the struct body
+    hdr = open(os.path.join(ROOT, "include", "mvd_hip.h")).read()
+    body = hdr[hdr.index("typedef struct mvd_gemm_desc"):hdr.index("} mvd_gemm_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl or decl.startswith("typedef struct"):
+            decl = decl.split("{", 1)[-1].strip()
+            if not decl:
+                continue
+        for part in decl.split(","):
+            m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part.strip())
+            if m:
+                names.append(m.group(1))
+    assert names == fields, (set(names) ^ set(fields))
+
+
 def test_params_signature_tracks_updates_and_does_not_cancel():
     """hip.params_signature (the guard of every packed-weight / engine / graph cache): per-tensor (pointer, version) pairs, so
     in-place updates, re-allocation and a storage SWAP between two parameters (which a xor / sum fingerprint cancels) all change it;
