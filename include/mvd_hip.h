@@ -86,7 +86,7 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, floa
 #define MVD_ACT_QUICKGELU 3 /* x * sigmoid(1.702 x): the MLP activation of OpenAI CLIP's vision transformer */
 
 #define MVD_GEMM_TILES 5 /* tile shapes of mvd_gemm_desc.cfg */
-#define MVD_GEMM_LOOPS 10 /* k-loop variants of mvd_gemm_desc.cfg */
+#define MVD_GEMM_LOOPS 11 /* k-loop variants of mvd_gemm_desc.cfg */
 #define MVD_GEMM_CFG_STRIDE 32 /* cfg = 1 + MVD_GEMM_CFG_STRIDE * tile + 2 * loop + order */
 #define MVD_B_PACKED 0   /* B: weight image of mvd_pack_linear_weight / mvd_pack_conv3x3_weight */
 #define MVD_B_PLANES 1   /* B: (N, ldb) row-major split planes (an activation), N % 16 == 0 */
@@ -155,7 +155,12 @@ typedef struct mvd_gemm_desc {
    *          loads, hold NBUF - 2 k-tiles of their share in VGPRs and ds_write_b128 each k-tile into its LDS slot one iteration before it
    *          is read -- same LDS image and MFMA order as 7: bit-identical), 9 = register-staged delivery in the plain kernel (tiles 0 - 3: every
    *          wavefront loads its granules two k-tiles ahead with 16-byte global loads and ds_write_b128's them into the other of two LDS
-   *          buffers: ~20 issue cycles per granule instead of ~100 for an LDS-DMA, which bounds the small tiles);
+   *          buffers: ~20 issue cycles per granule instead of ~100 for an LDS-DMA, which bounds the small tiles), 10 = the PERSISTENT role-split
+   *          kernel (tile 1, every epilogue; csrc/gemm_pt.hip): one 16-wave workgroup per CU walks a contiguous run of output tiles -- 8 consumer
+   *          wavefronts (MFMAs), 2 loader wavefronts (all LDS-DMAs of a 4-stage ring, across tile boundaries) and 6 epilogue wavefronts that
+   *          take a finished tile from an LDS staging tile while the consumers multiply the next one; counters in LDS instead of barriers.
+   *          Outputs bit-identical to the other loops; rs_out then holds one slot per 128 columns (rs_count says so) and the GroupNorm /
+   *          row statistics partials are summed in another order; a problem it does not take (K < 64, n_store % 4 != 0) runs loop 0 of tile 1;
    *          mvd_gemm_cfg_supported() tells whether a cfg serves a problem
    *   order: 0 = n-fastest, 1 = m-fastest order of the output tiles over the 8 XCDs.
    * The host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the

@@ -8,7 +8,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "gridattn.hip", "gridattn_fused.hip", "backward.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_pt.hip", "norm.hip", "attention.hip", "elementwise.hip", "gridattn.hip", "gridattn_fused.hip", "backward.hip"]
 LIB = os.path.join(HERE, "libmvd_hip.so")            # fp16 MFMA operands (default)
 LIB_BF16 = os.path.join(HERE, "libmvd_hip_bf16.so")  # bf16 MFMA operands (-DMVD_OPERAND_BF16)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -23,7 +23,7 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    common = [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "gridattn_common.hpp"),
+    common = [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "gridattn_common.hpp"), os.path.join(HERE, "gemm_common.hpp"),
               os.path.join(HERE, "..", "..", "include", "mvd_hip.h")]
     flavours = [("", [], LIB), ("_bf16", ["-DMVD_OPERAND_BF16"], LIB_BF16)]
     jobs, links = [], []

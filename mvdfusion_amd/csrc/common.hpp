@@ -167,3 +167,14 @@ __device__ __forceinline__ void gn_stats_add(long long* stats, int b, int g, int
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per DEVICE (function attributes may be per device: a model moved to another GPU of
+// the same process must get it too -- ADVICE r04).  `done` is a per-kernel bitmask of device ordinals (ordinals >= 64 set it every time).
+static inline hipError_t mvd_raise_dynamic_lds(const void* fn, int bytes, unsigned long long* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= 0 && dev < 64 && ((*done >> dev) & 1ull)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && dev >= 0 && dev < 64) *done |= 1ull << dev;
+  return e;
+}

@@ -433,11 +433,10 @@ extern "C" int mvd_concat_groupnorm(const float* a, int Ca, const float* b, int 
   MVD_CHECK_ARG(((uintptr_t)a & 7) == 0 && ((uintptr_t)b & 7) == 0 && ((uintptr_t)out & 7) == 0 && ((uintptr_t)y_sp & 127) == 0 &&
                     ((uintptr_t)raw_sp & 127) == 0, "mvd_concat_groupnorm: alignment");
   const size_t lds = (size_t)hw * ((Ca + Cb) / groups) * 4;
-  static bool raised = false;
-  if (!raised) {      // (more than the default 64 KiB of dynamic LDS: the largest groups of a step are 1024 rows x 30 channels)
-    const hipError_t e = hipFuncSetAttribute((const void*)concat_gn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  {                   // (more than the default 64 KiB of dynamic LDS: the largest groups of a step are 1024 rows x 30 channels)
+    static unsigned long long raised = 0;
+    const hipError_t e = mvd_raise_dynamic_lds((const void*)concat_gn_kernel, 128 * 1024, &raised);
     MVD_CHECK_ARG(e == hipSuccess, "mvd_concat_groupnorm: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
-    raised = true;
   }
   hipLaunchKernelGGL(concat_gn_kernel, dim3(B * groups), dim3(MVD_CGN_THREADS), lds, (hipStream_t)stream, a, Ca, b, Cb, out, (u16*)raw_sp,
                      (u16*)y_sp, gamma, beta, gn_stats, hw, groups, eps, silu);

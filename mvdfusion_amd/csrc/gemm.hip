@@ -37,22 +37,11 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#include "common.hpp"
-#include "../../include/mvd_hip.h"
+#include "gemm_common.hpp"
 
 namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];
-
-struct GemmParams {
-  mvd_gemm_desc d;
-  int nk;        // K / 32
-  int nt16;      // packed N / 16
-  int kt_per_split;
-  int splits;
-  int tiles_m, tiles_n;
-  int m_fastest;
-};
 
 // ------------------------------------------------------------------------------------------------ epilogue
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -2137,6 +2126,7 @@ static bool cfg_supported(const mvd_gemm_desc& d, int cfg) {
   if (loop == 6) return (tile == 1 || tile == 2 || tile == 4) && patch_shares(d, kTiles[tile]) > 0;
   if (loop == 7 || loop == 8) return tile == 1 || ((tile == 2 || tile == 4) && d.epi == MVD_EPI_STORE);   // (64x64 wave tiles: every epilogue)
   if (loop == 9) return tile <= 3;
+  if (loop == 10) return tile == 1 && mvd_gemm_pt_supported(d);      // gemm_pt.hip: the persistent role-split kernel (128x128 tiles, every epilogue)
   return true;
 }
 
@@ -2229,6 +2219,9 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     tile = (d.cfg - 1) / MVD_GEMM_CFG_STRIDE;
     loop = ((d.cfg - 1) % MVD_GEMM_CFG_STRIDE) >> 1;
     order = (d.cfg - 1) & 1;
+    if (loop == 10 && tile == 1 && !mvd_gemm_pt_supported(d)) loop = 0;   // (a problem the persistent kernel does not take -- K < 64, ragged n_store --
+                                                                            //  runs the plain loop of the same tile; mvd_gemm_cfg_supported says so)
+    else
     MVD_CHECK_ARG(cfg_supported(d, d.cfg), "mvd_gemm: cfg %d (tile %d, loop %d) does not serve this problem (include/mvd_hip.h: cfg)", d.cfg, tile,
                   loop);
   } else {
@@ -2256,6 +2249,14 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     else {
       const size_t cap = d.workspace_elems / ((size_t)d.M * d.N);
       if ((size_t)splits > cap) splits = cap < 1 ? 1 : (int)cap;
+    }
+  }
+  if (loop == 10) {       // gemm_pt_kernel: every split needs >= 2 k-tiles (a tile's last two ring slots become its staging tile)
+    const int need = mvd_gemm_pt_min_ktiles();
+    while (splits > 1) {
+      const int kps = cdiv(p.nk, splits), ns = cdiv(p.nk, kps);
+      if (p.nk - (ns - 1) * kps >= need) break;
+      --splits;
     }
   }
   p.kt_per_split = cdiv(p.nk, splits);
@@ -2297,6 +2298,7 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     case 24: launch_ws<128, 128, 2, 2, 1>(p, s); break;
     case 40: launch_ws<128, 80, 4, 1, 1>(p, s); break;
     case 72: launch_ws<128, 160, 2, 2, 1>(p, s); break;
+    case 26: mvd_gemm_pt_launch(p, s); break;
     default: MVD_CHECK_ARG(false, "mvd_gemm: no kernel for tile %d loop %d", tile, loop);
   }
   MVD_CHECK_LAUNCH("mvd_gemm");
@@ -2309,11 +2311,10 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
                          gna_cg <= 128 && gna_lds <= 128 * 1024 && d.ldo % 2 == 0 && (!d.res || d.ldr % 2 == 0) && (!d.bias_b || d.ldbb % 2 == 0) &&
                          d.N % 2 == 0;
   if (gna_fused) {
-    static bool raised = false;
-    if (!raised) {     // (more than the default 64 KiB of dynamic LDS: 1024 rows x 30 channels of a concatenation)
-      const hipError_t e = hipFuncSetAttribute((const void*)splitk_gn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    {                  // (more than the default 64 KiB of dynamic LDS: 1024 rows x 30 channels of a concatenation)
+      static unsigned long long raised = 0;
+      const hipError_t e = mvd_raise_dynamic_lds((const void*)splitk_gn_kernel, 128 * 1024, &raised);
       MVD_CHECK_ARG(e == hipSuccess, "mvd_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
-      raised = true;
     }
     p.d.gn_stats = gna_stats;      // (the slot of the normalised tensor -- of the concatenation in concat mode)
     hipLaunchKernelGGL(splitk_gn_kernel, dim3((d.M / d.gn_hw) * d.gn_groups), dim3(MVD_GNK_THREADS), gna_lds, s, p);

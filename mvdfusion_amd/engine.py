@@ -63,8 +63,8 @@ class Ctx:
     gn_from_producer = True         # False: every GroupNorm runs its own statistics kernel (A/B measurement, bench.py --gn-two-pass)
     ln_fold = True                  # False: LayerNorm kernels instead of the fold into the QKV / GEGLU GEMMs (A/B: bench.py --ln-kernels)
     gn_fuse = True                  # False: GroupNorm apply always as its own launch (A/B: bench.py --gn-apply-kernels)
-    keep_fp32 = False               # True (training forwards: the backward reads the blocks' fp32 inputs from the workspace): fused producers
-                                    # write every fp32 tensor they would otherwise skip (the decoder's concatenations)
+    # keep_fp32 (instance attribute, see __init__): True during training forwards -- the backward reads the blocks' fp32 inputs from the
+    # workspace, so fused producers write every fp32 tensor they would otherwise skip (the decoder's concatenations)
 
     def __init__(self, device, prec=hip.PREC_X4, policy=None):
         self.device = torch.device(device)
@@ -94,6 +94,7 @@ class Ctx:
         # layer): (skip tensor, cat buffer, raw planes buffer, norm module, planes buffer name, silu); _cat_done: cat buffers so produced
         self.next_cat = None
         self._cat_done = set()
+        self.keep_fp32 = False      # instance attribute: a training forward sets it on ITS engine's context only
 
     def begin_step(self):
         """Reset the rotation of the layer-output buffers: the eager warm-up step and the captured step then walk the
@@ -118,6 +119,16 @@ class Ctx:
         self._gn_next += 1
         self._gn[out.data_ptr()] = (st, B, HW, C)
         return st
+
+    def _forget(self, out):
+        """`out` is about to be overwritten: its producer statistics, its 'fp32 not written' mark and every 'GroupNorm already applied'
+        entry keyed on its address are stale (a stale (ptr, norm) match is impossible by construction then)."""
+        ptr = out.data_ptr()
+        self._gn.pop(ptr, None)
+        self._unwritten.discard(ptr)
+        if self._gn_done:
+            for k in [k for k in self._gn_done if k[0] == ptr]:
+                del self._gn_done[k]
 
     def row_stats(self, tag, rows, width):
         """Static per-row statistics slots for a (rows, width) tensor whose LayerNorm is folded into the consumer GEMM."""
@@ -156,8 +167,7 @@ class Ctx:
         kw.setdefault("workspace", self.gemm_ws)
         applied = False
         if out is not None:
-            self._gn.pop(out.data_ptr(), None)          # whatever statistics the buffer had are stale now
-            self._unwritten.discard(out.data_ptr())
+            self._forget(out)                           # whatever statistics / normalised planes the buffer had are stale now
             handled = False
             if gn is not None and gn_apply is None and self.next_cat is not None and self.gn_fuse and self.gn_from_producer and \
                     gn[1] % 16 == 0 and out.is_contiguous():
@@ -223,8 +233,7 @@ class Ctx:
         """out = [a | b] along the channels (+ its split planes), with the GroupNorm statistics of the result.
         gn_apply = (norm, planes buffer name, silu): the GroupNorm that consumes the result is applied in the same launch
         (mvd_concat_groupnorm) when a group fits the LDS; need_out=False: nobody reads the fp32 concatenation itself."""
-        self._gn.pop(out.data_ptr(), None)
-        self._unwritten.discard(out.data_ptr())
+        self._forget(out)
         st = None
         if gn_apply is not None and self.gn_fuse and self.gn_from_producer and HW % 16 == 0 and (ca + cb) % 32 == 0 and \
                 gn_apply[0].num_groups == 32 and gn_apply[0].num_channels == ca + cb and \

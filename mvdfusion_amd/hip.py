@@ -26,8 +26,11 @@ def parse_precision(name):
     """'f16x4' / 'f16x3' / 'bf16x3' / 'f16' / 'bf16' -> (operand format, default products, {}); a policy string
     'f16x4:conv=3,geglu=3' (default x4, the named layer classes of PREC_KINDS at x3) -> (format, 4, {'conv': 3, 'geglu': 3})."""
     base, _, over = name.partition(":")
-    fmt = "bf16" if base.startswith("bf16") else "f16"
-    default = {"x3": PREC_X3, "x4": PREC_X4}.get(base[-2:], PREC_X1)
+    names = {"f16": ("f16", PREC_X1), "bf16": ("bf16", PREC_X1), "f16x3": ("f16", PREC_X3), "f16x4": ("f16", PREC_X4),
+             "bf16x3": ("bf16", PREC_X3), "bf16x4": ("bf16", PREC_X4)}
+    if base not in names:          # (ADVICE r04: a typo such as 'f16x33' used to select the one-product mode silently)
+        raise ValueError(f"precision '{name}': base must be one of {sorted(names)}")
+    fmt, default = names[base]
     policy = {}
     for item in filter(None, over.split(",")):
         k, _, v = item.partition("=")
@@ -256,7 +259,7 @@ def register_param_maxima(params):
             norms = [torch.linalg.vector_norm(p.detach().reshape(-1), ord=float("inf")) for p in ps]
         vals = torch.stack([n.reshape(()) for n in norms]).tolist()
     for p, v in zip(ps, vals):
-        _PARAM_MAX[p.data_ptr()] = (weakref.ref(p), p.numel(), float(v))
+        _PARAM_MAX[p.data_ptr()] = (weakref.ref(p), p.numel(), float(v), p._version)
     return len(ps)
 
 
@@ -266,13 +269,15 @@ def forget_param_maxima():
 
 
 def _known_max(t):
-    """max|t| from the registry if `t` is (a view of the whole of) a registered, still-alive parameter; else None."""
+    """max|t| from the registry if `t` is (a view of the whole of) a registered, still-alive, UNMODIFIED parameter; else None."""
     ent = _PARAM_MAX.get(t.data_ptr())
     if ent is None:
         return None
-    ref, numel, mx = ent
+    ref, numel, mx, version = ent
     p = ref()
-    if p is None or p.data_ptr() != t.data_ptr() or numel != t.numel():
+    # (ADVICE r04: an in-place update -- optimizer step, load_state_dict into a submodule -- bumps the parameter's version counter: the
+    #  recorded maximum is stale then and the caller falls back to the one-reduction path)
+    if p is None or p.data_ptr() != t.data_ptr() or numel != t.numel() or p._version != version:
         return None
     return mx
 
@@ -499,15 +504,16 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
 # mvd_gemm_desc.cfg = 1 + CFG_STRIDE * tile + 2 * loop + order (include/mvd_hip.h: MVD_GEMM_CFG_STRIDE)
 CFG_STRIDE = 32
 GNA_SILU, GNA_ROUND_F16, GNA_OUT_UNUSED = 1, 2, 4      # mvd_gemm_desc.gna_flags
-TUNE_CACHE_VERSION = 8             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
+TUNE_CACHE_VERSION = 9             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
-GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch", "ws", "ws-reg", 8)  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
+GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch", "ws", "ws-reg", 8, "pt")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
                                  # (3 / 4 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
                                  # (stride-1 3x3 convolutions: the input patch is staged once per channel block)
 PATCH_LOOP = 6
 WS_LOOP = 7                      # gemm_ws_kernel: consumer / loader wavefront roles (tiles 1, 2, 4; EPI_STORE)
 WSR_LOOP = 8                     # ... with register-staged operand delivery (global_load -> VGPR -> ds_write_b128) instead of LDS-DMA
 REG_LOOP = 9                     # gemm_kernel<..., 8>: register-staged delivery in the plain kernel (tiles 0 - 3)
+PT_LOOP = 10                     # gemm_pt_kernel (csrc/gemm_pt.hip): persistent 16-wave workgroups, consumer / loader / epilogue wavefront roles (tile 1)
 
 
 def _cfg_parts(cfg):
@@ -526,7 +532,8 @@ def _cfg_valid(cfg, epi, b_mode=0):
     waves = wm * wn
     return (loop not in (2, 3) or waves == 8) and (loop != 3 or tile == 1) and (loop != 5 or waves == 4) and \
         (loop != PATCH_LOOP or tile in (1, 2, 4)) and (tile < 2 or epi == EPI_STORE) and \
-        (loop not in (WS_LOOP, WSR_LOOP) or tile == 1 or (tile in (2, 4) and epi == EPI_STORE)) and (loop != REG_LOOP or tile <= 3)
+        (loop not in (WS_LOOP, WSR_LOOP) or tile == 1 or (tile in (2, 4) and epi == EPI_STORE)) and (loop != REG_LOOP or tile <= 3) and \
+        (loop != PT_LOOP or tile == 1)
 
 
 _ALL_CONFIGS = tuple(c for c in range(1, CFG_STRIDE * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
@@ -556,6 +563,8 @@ def kernel_symbol(cfg, prec, conv):
     bm, bn, wm, wn = GEMM_TILES[tile]
     if loop == PATCH_LOOP:
         return f"conv_patch_kernel<{bm}, {bn}, {wm}, {wn}, {prec}>"
+    if loop == PT_LOOP:
+        return f"gemm_pt_kernel<{prec}, {1 if conv else 0}>"
     if loop in (WS_LOOP, WSR_LOOP):
         cm, cn = {1: (2, 2), 2: (4, 1), 4: (2, 2)}[tile]
         return f"gemm_ws_kernel<{bm}, {bn}, {cm}, {cn}, {prec}, {1 if conv else 0}, {1 if loop == WSR_LOOP else 0}>"
@@ -631,9 +640,10 @@ def _autotune(d, A=None, reps=4, trials=3, W_data=None):
     stats_ptr, d.gn_stats = d.gn_stats, None          # the statistics atomics must run exactly once: only in the real launch
     if d.gna_out_sp:                                   # GroupNorm apply behind the GEMM: needs statistics -- a scratch slot while timing (the
         n = (d.M // d.gn_hw) * d.gn_groups * 2         # planes it writes are rewritten by the real launch)
+        n = (n, str(A.device) if A is not None else "cuda")          # (the scratch slot lives on the device of the operands: ADVICE r04)
         scratch = _TUNE_STATS.get(n)
         if scratch is None:
-            scratch = _TUNE_STATS[n] = torch.zeros(n, dtype=torch.int64, device="cuda")
+            scratch = _TUNE_STATS[n] = torch.zeros(n[0], dtype=torch.int64, device=A.device if A is not None else "cuda")
         d.gn_stats = scratch.data_ptr()
     # split-K: the library's model (0 = auto) or none (1); the timed region includes the reduce kernel of a split GEMM
     # Loops the tuner does not time unless asked (MVD_TUNE_INCLUDE_LOOPS=8,9): the two register-staged delivery paths of round 4 were

@@ -438,9 +438,12 @@ class ViewFusion(nn.Module):
             drop_cat, drop_all = (r > 0.05) & (r <= 0.1), r <= 0.05
             eng.drop_masks = tuple(1.0 - (dm | drop_all).float() for dm in (drop_clip, drop_vol, drop_cat))
         self._last_drop_masks = eng.drop_masks
+        keep = eng.ctx.keep_fp32
+        eng.ctx.keep_fp32 = keep or bool(getattr(self, "_train_keep_fp32", False))      # this engine only (never a class-wide switch)
         try:
             eng.step(cfg_scale, do_update=False, use_graph=eng.drop_masks is None and not getattr(self, "_force_eager", False))
         finally:
+            eng.ctx.keep_fp32 = keep
             eng.drop_masks = None      # (depth_mode stays: the training backward re-derives the geometry from the same depth source)
         return hip.check_finite(eng.eps.clone(), "ViewFusion.apply_model")
 
@@ -480,14 +483,13 @@ class ViewFusion(nn.Module):
         s1m = self.scheduler.sqrt_one_minus_alphas_cumprod.to(dev)[t].view(V, 1, 1, 1)
         noisy = sac * batch_latents + s1m * noise                                          # scheduler.q_sample (:55-64)
         prev_depth = input_latents[:, 4:].clone() if self.feed_prev_depth else None          # (:377-379)
-        from . import engine as _engine
-        keep, force = _engine.Ctx.keep_fp32, getattr(self, "_force_eager", False)
-        _engine.Ctx.keep_fp32, self._force_eager = True, True      # the backward reads block inputs from the workspace: every fp32 tensor is
-        try:                                                      # written, and no graph captured in inference mode is replayed
-            pred = self.apply_model(noisy, batch_cameras, input_latents, input_cameras, clip_v_embed, t, prev_depth=prev_depth,
-                                    depth_noise=depth_noise, drop_rand=drop_rand)
+        force = getattr(self, "_force_eager", False)
+        self._train_keep_fp32, self._force_eager = True, True      # the backward reads block inputs from the workspace: every fp32 tensor is
+        try:                                                      # written (apply_model sets keep_fp32 on ITS engine's context only: ADVICE
+            pred = self.apply_model(noisy, batch_cameras, input_latents, input_cameras, clip_v_embed, t, prev_depth=prev_depth,   # r04), and
+                                    depth_noise=depth_noise, drop_rand=drop_rand)              # no graph captured in inference mode is replayed
         finally:
-            _engine.Ctx.keep_fp32, self._force_eager = keep, force
+            self._train_keep_fp32, self._force_eager = False, force
         if self.objective == "noise":
             target = noise
         elif self.objective == "x_start":
@@ -544,12 +546,13 @@ class ViewFusion(nn.Module):
         from . import backward_gridattn as bg
         tune = self.train_autotune_min_flops is not None and not hip.AUTOTUNE
         if tune:          # the forward of the training step runs eagerly (condition dropout): its GEMMs and the backward's are tuned here,
+            prev_min = hip.AUTOTUNE_MIN_FLOPS
             hip.AUTOTUNE, hip.AUTOTUNE_MIN_FLOPS = True, float(self.train_autotune_min_flops)      # once per shape (cached), big ones only
         try:
             return self._gradients(batch, trainer_config, noise_source, only_trainable)
         finally:
             if tune:
-                hip.AUTOTUNE, hip.AUTOTUNE_MIN_FLOPS = False, 0.0
+                hip.AUTOTUNE, hip.AUTOTUNE_MIN_FLOPS = False, prev_min
                 hip.release_tuning_buffers()
 
     def _gradients(self, batch, trainer_config, noise_source, only_trainable):
