@@ -31,11 +31,24 @@ sys.path.insert(0, ROOT)
 
 MFMA_16BIT_DENSE_PEAK = 2.5e15  # FLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (dense; not the 2:1-sparse figure)
 HBM_PEAK = 8.0e12               # B/s (spec; ~6.3 TB/s achievable), same guide
-ROUND = "r04"
+ROUND = "r05"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def tree_fingerprint():
+    """sha256 over the sources that decide which kernels a step launches (csrc/*.hip, *.hpp, the header, the host mirror): files under
+    profiles/ written by tools/pmc_traffic.py carry it, and their numbers enter the bench line only when it matches the running tree."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pats = ("mvdfusion_amd/csrc/*.hip", "mvdfusion_amd/csrc/*.hpp", "include/*.h", "mvdfusion_amd/*.py")
+    for f in sorted(f for pat in pats for f in glob.glob(os.path.join(ROOT, pat))):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build(V, S, D, precision, sd=None):
@@ -144,6 +157,13 @@ def profile_kernel_groups(m, eng, cfg_scale):
 
     lib = hip.lib()
     real_fused = lib.mvd_gridattn_fused
+    # every mvd_gemm descriptor of the step, by value: replayed back to back from ONE graph below (graph-replay time of the family, in-run)
+    import ctypes as C
+    real_mvd_gemm, descs = lib.mvd_gemm, []
+
+    def recording_mvd_gemm(dref, stream):
+        descs.append(hip.GemmDesc.from_buffer_copy(bytes(dref._obj)))
+        return real_mvd_gemm(dref, stream)
 
     def timed_fused(*a):
         e0, e1 = ev_pair()
@@ -155,6 +175,7 @@ def profile_kernel_groups(m, eng, cfg_scale):
         return r
 
     lib.mvd_gridattn_fused = timed_fused
+    lib.mvd_gemm = recording_mvd_gemm
     hip.gemm, hip.attention, hip.groupnorm, hip.layernorm, GridAttn.run = timed_gemm, timed_attention, timed_groupnorm, \
         timed_layernorm, timed_ga
     try:
@@ -170,6 +191,30 @@ def profile_kernel_groups(m, eng, cfg_scale):
         hip.gemm, hip.attention, hip.groupnorm, hip.layernorm, GridAttn.run = real["gemm"], real["attention"], \
             real["groupnorm"], real["layernorm"], real["ga"]
         lib.mvd_gridattn_fused = real_fused
+        lib.mvd_gemm = real_mvd_gemm
+    # the GEMM family under graph replay, measured HERE: one graph holding every mvd_gemm launch of the step (their split-K reduce /
+    # GroupNorm-apply kernels ride along), the same buffers, one event pair per replay -- no eager launch gaps inside the timed region
+    family_replay_ms = None
+    try:
+        graph = hip.Graph()
+        with graph:
+            for dd in descs:
+                hip.check(real_mvd_gemm(C.byref(dd), hip.stream()))
+        graph.launch()
+        torch.cuda.synchronize()
+        best = float("inf")
+        for _ in range(3):
+            e0, e1 = ev_pair()
+            e0.record()
+            graph.launch()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_ms(e1))
+        family_replay_ms = best
+        eng.rewind(it)           # (the replays re-added producer statistics: the next step zeroes its arena anyway; restore the state)
+        eng.x.copy_(x)
+    except Exception as e:       # the figure is optional: never fail the bench line for it
+        log(f"[bench] family graph replay skipped: {e}")
     by = {}
     for r in recs:
         ms = r["ev"][0].elapsed_ms(r["ev"][1])
@@ -183,7 +228,7 @@ def profile_kernel_groups(m, eng, cfg_scale):
     for k, lst in groups.items():
         ms = sum(r["ev"][0].elapsed_ms(r["ev"][1]) for r in lst)
         gsum[k] = dict(n=len(lst), ms=ms, flops=sum(r["flops"] for r in lst), bytes=sum(r["bytes"] for r in lst))
-    return by, gsum
+    return by, gsum, family_replay_ms
 
 
 def cpu_baseline(sd, V, S, D, cfg_scale, n_timed=3, threads=16):
@@ -371,14 +416,17 @@ def main():
             "metric": "denoising-steps/sec", "value": a.steps / dt, "unit": "steps/s", "n_gpus": N, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "rccl_ranks": world if backend == "nccl" else 0,
-            "scaling": "strong" if N > 1 else "weak", "vs_baseline": None,
+            # N = 1: one GPU runs the whole fixed workload -- neither weak nor strong scaling applies; the contract's field holds "strong"
+            # (total work fixed) for every N so that the driver's per-N values are comparable
+            "scaling": "strong", "vs_baseline": None,
             "dtype": f"{a.precision} ({p_fmt} MFMA operands" + (f" split hi+lo, {p_default} partial products" if p_default > 1 else "") +
                      (f"; layer classes at other counts: {p_policy}" if p_policy else "") + ", fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": workload_label(V, S, D, N, cfg_scale),
                        "views": V, "latent": S, "depth_samples": D, "cfg_scale": cfg_scale,
                        "parallelism": "single GPU, CFG pair batched as 2V" if N == 1 else
-                       f"view-parallel: {V} views over {N} GPUs, 1 RCCL all-gather of latent rows per step",
+                       f"view-parallel: {V} views over {N} GPUs, 1 all-gather of latent rows per step over "
+                       f"{'RCCL (torch.distributed backend nccl)' if backend == 'nccl' else 'torch.distributed backend ' + str(backend)}",
                        "hipgraph": graph},
             "gpu_ms_per_step_hip_events": gpu_ms,
             "algorithmic_tflop_per_step": step_flops / 1e12,
@@ -386,7 +434,7 @@ def main():
         }
     # ---- roofline of the dominant kernel family + per-group rooflines (N == 1 only; HIP events on the launch stream)
     if world == 1:
-        by, gsum = profile_kernel_groups(m, eng, cfg_scale)
+        by, gsum, family_replay_ms = profile_kernel_groups(m, eng, cfg_scale)
         tot = sum(b["ms"] for b in by.values())
         for k, b in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
             log(f"[bench] {k:40s} launches {b['n']:4d}  total {b['ms']:8.3f} ms  avg {b['ms'] / b['n'] * 1e3:8.1f} us  "
@@ -400,17 +448,24 @@ def main():
         nprod = sum(b["mfma_flops"] for b in by.values()) / fl_all      # FLOP-weighted mean of the partial products per MAC (precision policy)
         by_all = sum(b["bytes"] for b in by.values())
         ach = fl_all / (tot * 1e-3)
-        # HBM traffic: only from PMC passes of THIS workload (tools/pmc_traffic.sh <tag> --views V --latent S ...), else null
+        # HBM traffic: only from PMC passes of THIS workload AND THIS TREE (tools/pmc_traffic.sh <tag> --views V --latent S ...: the file
+        # records the fingerprint of the sources it was measured on), else null
         pmc, tsrc = {}, None
         tfile = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic_v{V}_s{S}_d{D}.json")
+        tree = tree_fingerprint()
         if os.path.exists(tfile):
-            pmc = json.load(open(tfile))["kernels"]
-            tsrc = (f"profiles/{os.path.basename(tfile)}: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
-                    "command and workload, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch over the graph-replayed steps only; averaged over "
-                    "every GEMM-family launch of those passes")
+            doc = json.load(open(tfile))
+            if doc.get("tree") == tree:
+                pmc = doc["kernels"]
+                tsrc = (f"profiles/{os.path.basename(tfile)} (tree {tree}): separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
+                        "command and workload, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch over the graph-replayed steps only; averaged over "
+                        "every GEMM-family launch of those passes")
+            else:
+                tsrc = (f"profiles/{os.path.basename(tfile)} was measured on tree {doc.get('tree')}, this run is tree {tree}: counter traffic "
+                        "omitted (re-run tools/pmc_traffic.sh)")
         # family figure: every GEMM-family kernel of the PMC passes (same workload; the tuner's per-shape picks differ a little from run to
         # run, so the per-variant match below may be partial -- `traffic_launch_coverage` -- while the family average stays comparable)
-        fam = [v for kk, v in pmc.items() if kk.startswith(("gemm_kernel", "gemm_ws_kernel", "conv_patch_kernel"))]
+        fam = [v for kk, v in pmc.items() if kk.startswith(("gemm_kernel", "gemm_ws_kernel", "conv_patch_kernel", "gemm_pt_kernel"))]
         fam_n = sum(v["launches_profiled"] for v in fam)
         fam_traffic = sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in fam) / fam_n if fam_n else None
         variants, tr_sum, tr_n = [], 0.0, 0
@@ -439,17 +494,14 @@ def main():
                                    "launches; the split-operand kernels issue `mfma_products_per_mac` MFMA products per "
                                    "algorithmic MAC, so the MFMA pipe runs at mfma_pipe_frac of the dense 16-bit peak",
                            "gemm_share_of_step_ms": tot, "variants": variants}
-        # the same family under GRAPH REPLAY (no eager launch gaps inside the event pairs): kernel time from the rocprofv3 kernel trace
-        # of this command and workload (tools/round_artifacts.sh -> profiles/<round>_step_trace_v<V>.json)
-        sfile = os.path.join(ROOT, "profiles", f"{ROUND}_step_trace_v{V}.json")
-        if os.path.exists(sfile) and (S, D) == (32, 1) and a.precision == DEFAULT_PRECISION:
-            tr = json.load(open(sfile))
-            fam_us = sum(v["us_per_step"] for k, v in tr["kernels"].items() if k.startswith(("gemm_kernel", "gemm_ws_kernel", "conv_patch_kernel")))
-            if fam_us > 0:
-                out["roofline"].update(frac_graph_replay=fl_all / (fam_us * 1e-6) / MFMA_16BIT_DENSE_PEAK,
-                                       graph_replay_family_ms=fam_us * 1e-3,
-                                       graph_replay_source=f"profiles/{os.path.basename(sfile)} (rocprofv3 --kernel-trace of the graph-replayed steps; "
-                                                           "split-K reduce kernels not included on either side)")
+        # the same family under GRAPH REPLAY (no eager launch gaps inside the event pairs), measured in THIS run: every mvd_gemm launch of
+        # the step replayed from one graph (profile_kernel_groups); the reduce / GroupNorm-apply kernels mvd_gemm launches ride along
+        out["roofline"]["tree"] = tree
+        if family_replay_ms:
+            out["roofline"].update(frac_graph_replay=fl_all / (family_replay_ms * 1e-3) / MFMA_16BIT_DENSE_PEAK,
+                                   graph_replay_family_ms=family_replay_ms,
+                                   graph_replay_source="this run: one hipGraph of the step's mvd_gemm launches (incl. the split-K reduce / "
+                                                       "GroupNorm-apply kernels they launch), min of 3 replays, one HIP-event pair each")
         rg = {}
         for k, g in gsum.items():
             if not g["n"] or g["ms"] <= 0:

@@ -257,15 +257,16 @@ __global__ __launch_bounds__(256, MVD_ATTN_MIN_WAVES(DQ)) void attn_kernel(const
         for (int i = 0; i < DT; ++i) o[t2][i] *= alpha;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          union { op16x8 v; u16 e[8]; } H8, L8;
+          union { op16x8 v; u16 e[8]; uint32_t w[4]; } H8, L8;
+          if (NS >= 3) {     // packed split: v_cvt_pk + v_pk_add, 5 instructions per pair (common.hpp: split_op16x2)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float pv = j < 4 ? s[t2][2 * u][j] : s[t2][2 * u + 1][j - 4];
-            if (NS >= 3) {
-              split_op16(pv, H8.e[j], L8.e[j]);
-            } else {
-              H8.e[j] = to_op_bits(pv);
+            for (int j = 0; j < 4; ++j) {
+              const f32x4& sv = j < 2 ? s[t2][2 * u] : s[t2][2 * u + 1];
+              split_op16x2(sv[2 * (j & 1)], sv[2 * (j & 1) + 1], H8.w[j], L8.w[j]);
             }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) H8.e[j] = to_op_bits(j < 4 ? s[t2][2 * u][j] : s[t2][2 * u + 1][j - 4]);
           }
           ph[t2][u] = H8.v;
           if (NS >= 3) pl2[t2][u] = L8.v;
@@ -414,15 +415,16 @@ __global__ __launch_bounds__(256, MVD_ATTN_MIN_WAVES(DQ)) void attn_kernel(const
       // ---- P^T as MFMA B operand: k-slot (g, j): j<4 -> key 32u + 4g + j ; j>=4 -> key 32u + 16 + 4g + (j-4)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        union { op16x8 v; u16 e[8]; } H8, L8;
+        union { op16x8 v; u16 e[8]; uint32_t w[4]; } H8, L8;
+        if (NS >= 3) {     // packed split: v_cvt_pk + v_pk_add, 5 instructions per pair (common.hpp: split_op16x2)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pv = j < 4 ? s[t2][2 * u][j] : s[t2][2 * u + 1][j - 4];
-          if (NS >= 3) {
-            split_op16(pv, H8.e[j], L8.e[j]);
-          } else {
-            H8.e[j] = to_op_bits(pv);
+          for (int j = 0; j < 4; ++j) {
+            const f32x4& sv = j < 2 ? s[t2][2 * u] : s[t2][2 * u + 1];
+            split_op16x2(sv[2 * (j & 1)], sv[2 * (j & 1) + 1], H8.w[j], L8.w[j]);
           }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) H8.e[j] = to_op_bits(j < 4 ? s[t2][2 * u][j] : s[t2][2 * u + 1][j - 4]);
         }
         ph[t2][u] = H8.v;
         if (NS >= 3) pl2[t2][u] = L8.v;

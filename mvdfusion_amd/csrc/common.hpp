@@ -73,6 +73,20 @@ __device__ __forceinline__ void split_op16(float x, u16& hi, u16& lo) {
   hi = __builtin_bit_cast(u16, h);
   lo = __builtin_bit_cast(u16, l);
 }
+// Two values at once, packed: hi2 = {hi(a) | hi(b) << 16}, lo2 likewise.  Written on 2-vectors so that hipcc emits the PACKED forms --
+// v_cvt_pk_f16_f32 (both roundings to the operand type), v_pk_add_f32 (the residual): 5 instructions per pair against ~11 for two scalar
+// splits + packing.  Same roundings, same results bit for bit; a wavefront issues one VALU instruction per ~7.5 cycles
+// (profiles/r05_hw_facts_probe.log), and every epilogue, norm kernel and the fused GridAttn kernel split every value they hand to a GEMM.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) op_t op16x2;
+__device__ __forceinline__ void split_op16x2(float a, float b, uint32_t& hi2, uint32_t& lo2) {
+  const f32x2 v = {a, b};
+  const op16x2 h = __builtin_convertvector(v, op16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const op16x2 l = __builtin_convertvector(r, op16x2);
+  hi2 = __builtin_bit_cast(uint32_t, h);
+  lo2 = __builtin_bit_cast(uint32_t, l);
+}
 __device__ __forceinline__ u16 to_op_bits(float x) { return __builtin_bit_cast(u16, (op_t)x); }
 
 // ------------------------------------------------------------------------------------------------
@@ -85,14 +99,12 @@ __device__ __forceinline__ size_t sp_index(size_t row, int ld, int k) { return r
 
 // four consecutive elements k..k+3 (k % 4 == 0) of one row
 __device__ __forceinline__ void store_sp4(u16* __restrict__ base, size_t row, int ld, int k, float a, float b, float c, float d) {
-  u16 h[4], l[4];
-  split_op16(a, h[0], l[0]);
-  split_op16(b, h[1], l[1]);
-  split_op16(c, h[2], l[2]);
-  split_op16(d, h[3], l[3]);
+  uint32_t h0, l0, h1, l1;
+  split_op16x2(a, b, h0, l0);
+  split_op16x2(c, d, h1, l1);
   u16* p = base + sp_index(row, ld, k);
-  *(uint2*)p = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-  *(uint2*)(p + 32) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+  *(uint2*)p = make_uint2(h0, h1);
+  *(uint2*)(p + 32) = make_uint2(l0, l1);
 }
 __device__ __forceinline__ void store_sp1(u16* __restrict__ base, size_t row, int ld, int k, float a) {
   u16 h, l;
@@ -105,13 +117,11 @@ __device__ __forceinline__ void store_sp1(u16* __restrict__ base, size_t row, in
 // attention operand planes (separate hi / lo arrays): four consecutive elements -> 8 bytes in each plane
 __device__ __forceinline__ void store_planes4(u16* __restrict__ hi, u16* __restrict__ lo, size_t idx, float a, float b,
                                               float c, float d) {
-  u16 h[4], l[4];
-  split_op16(a, h[0], l[0]);
-  split_op16(b, h[1], l[1]);
-  split_op16(c, h[2], l[2]);
-  split_op16(d, h[3], l[3]);
-  *(uint2*)(hi + idx) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-  *(uint2*)(lo + idx) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+  uint32_t h0, l0, h1, l1;
+  split_op16x2(a, b, h0, l0);
+  split_op16x2(c, d, h1, l1);
+  *(uint2*)(hi + idx) = make_uint2(h0, h1);
+  *(uint2*)(lo + idx) = make_uint2(l0, l1);
 }
 __device__ __forceinline__ void store_planes1(u16* __restrict__ hi, u16* __restrict__ lo, size_t idx, float a) {
   u16 h, l;

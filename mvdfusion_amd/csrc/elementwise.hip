@@ -210,12 +210,11 @@ __global__ __launch_bounds__(MVD_CGN_THREADS) void concat_gn_kernel(const float*
           const int n = c0 + 2 * jj[u];
           if (out) *(float2*)(out + m * C + n) = v[u];
           if (raw_sp) {
-            u16 h0, l0, h1, l1;
-            split_op16(v[u].x, h0, l0);
-            split_op16(v[u].y, h1, l1);
+            uint32_t hh, ll;
+            split_op16x2(v[u].x, v[u].y, hh, ll);
             u16* pp = raw_sp + sp_index(m, C, n);
-            *(uint32_t*)pp = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            *(uint32_t*)(pp + 32) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+            *(uint32_t*)pp = hh;
+            *(uint32_t*)(pp + 32) = ll;
           }
           *(float2*)(s_val + 2 * (e0 + u * NT)) = v[u];
           s += v[u].x + v[u].y;
@@ -264,12 +263,11 @@ __global__ __launch_bounds__(MVD_CGN_THREADS) void concat_gn_kernel(const float*
         v.x = silu_f(v.x);
         v.y = silu_f(v.y);
       }
-      u16 h0, l0, h1, l1;
-      split_op16(v.x, h0, l0);
-      split_op16(v.y, h1, l1);
+      uint32_t hh, ll;
+      split_op16x2(v.x, v.y, hh, ll);
       u16* pp = y_sp + sp_index(m0 + r, C, c0 + 2 * j);
-      *(uint32_t*)pp = (uint32_t)h0 | ((uint32_t)h1 << 16);
-      *(uint32_t*)(pp + 32) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+      *(uint32_t*)pp = hh;
+      *(uint32_t*)(pp + 32) = ll;
       r += dq;
       j += dj;
       if (j >= cg2) {

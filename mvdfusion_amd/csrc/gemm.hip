@@ -507,13 +507,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
           po += ostep;
         }
         if (psp) {
-          u16 h[4], l[4];
-          split_op16(f[j].x, h[0], l[0]);
-          split_op16(f[j].y, h[1], l[1]);
-          split_op16(f[j].z, h[2], l[2]);
-          split_op16(f[j].w, h[3], l[3]);
-          *(uint2*)psp = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-          *(uint2*)(psp + 32) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+          uint32_t h0, l0, h1, l1;
+          split_op16x2(f[j].x, f[j].y, h0, l0);
+          split_op16x2(f[j].z, f[j].w, h1, l1);
+          *(uint2*)psp = make_uint2(h0, h1);
+          *(uint2*)(psp + 32) = make_uint2(l0, l1);
           psp += sstep;
         }
       }
@@ -1942,12 +1940,11 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
           const int m = m0 + rr[u], n = c0 + 2 * jj[u];
           if (put_out && own[u]) *(float2*)(d.out + (size_t)m * d.ldo + n) = v;
           if (d.cat_raw_sp) {                      // raw planes of [out | cat_b] (the next ResBlock's 1x1 skip convolution reads them)
-            u16 h0, l0, h1, l1;
-            split_op16(v.x, h0, l0);
-            split_op16(v.y, h1, l1);
+            uint32_t hh, ll;
+            split_op16x2(v.x, v.y, hh, ll);
             u16* pp = (u16*)d.cat_raw_sp + sp_index((size_t)m, CT, n);
-            *(uint32_t*)pp = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            *(uint32_t*)(pp + 32) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+            *(uint32_t*)pp = hh;
+            *(uint32_t*)(pp + 32) = ll;
           }
           *(float2*)(s_val + 2 * (e0 + u * NT)) = v;
           s += v.x + v.y;
@@ -1998,12 +1995,11 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
         v.x = silu_f(v.x);
         v.y = silu_f(v.y);
       }
-      u16 h0, l0, h1, l1;
-      split_op16(v.x, h0, l0);
-      split_op16(v.y, h1, l1);
+      uint32_t hh, ll;
+      split_op16x2(v.x, v.y, hh, ll);
       u16* pp = ysp + sp_index((size_t)(m0 + r), CT, c0 + 2 * j);
-      *(uint32_t*)pp = (uint32_t)h0 | ((uint32_t)h1 << 16);
-      *(uint32_t*)(pp + 32) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+      *(uint32_t*)pp = hh;
+      *(uint32_t*)(pp + 32) = ll;
       r += dq;
       j += dj;
       if (j >= cg2) {

@@ -32,13 +32,13 @@ namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_pt_zero_page[4];
 
-constexpr int NCW = 8, NLW = 2, NEW = 6;               // consumer / loader / epilogue wavefronts
+constexpr int NCW = 8, NLW = 4, NEW = 4;               // consumer / loader / epilogue wavefronts
 constexpr int PT_THREADS = (NCW + NLW + NEW) * 64;
 constexpr int NBUF = 4, STAGE = 32 * 1024;
-constexpr int LGR = 8;                                 // granules (1 KiB) of each operand per loader and k-tile
+constexpr int LGR = 16;                                // granules (1 KiB) of each operand per k-tile
 constexpr int RING_BYTES = NBUF * STAGE;
 constexpr int OFF_TAB = RING_BYTES;                    // conv: per loader, source offset of (tile row) x (tap)
-constexpr int TAB_BYTES = NLW * 64 * 9 * 4;
+constexpr int TAB_BYTES = NLW * 128 * 9 * 4;
 constexpr int OFF_ECOL = OFF_TAB + TAB_BYTES;          // per epilogue wave: column {sum, sum of squares} [128][2]
 constexpr int OFF_FLAGS = OFF_ECOL + NEW * 1024;
 enum { F_FULL = 0, F_CREAD = 4, F_ECNT = 8, F_STAG = 12, F_TICKET = 14, F_ABORT = 15, F_COUNT = 16 };
@@ -151,40 +151,53 @@ __device__ __forceinline__ int pt_item_nkt(const GemmParams& p, int item) {
 }
 
 // ---------------------------------------------------------------------------------------------- LDS-DMA (inline asm: hipcc does not count these)
-// Eight 1 KiB granules as two groups of four: LDS dst .. dst + 4 KiB and dst + 8 KiB .. dst + 12 KiB.  The immediate offset of
-// global_load_lds moves the LDS destination AND the global source (tools/probes/dma_offset_probe.hip): M0 is written once per FOUR granules
-// and the offsets 0 / 1 / 2 / 3 KiB do the rest -- 1.5 instructions per KiB instead of 3 (a single wavefront issues one instruction per
-// ~8 cycles: the loaders were issue bound).  The callers pre-compensate the sources: granule i's lane offset is
-// v[i] = true offset + 3072 - (i & 3) * 1024 against sbase - 3072.
-__device__ __forceinline__ void dma8_saddr(const unsigned* v, const void* sbase, unsigned dst) {
+// Sixteen 1 KiB granules to LDS dst, dst + 1 KiB, ...  The immediate offset of global_load_lds moves the LDS destination AND the global
+// source (tools/probes/dma_offset_probe.hip): M0 is written once per FOUR granules and the offsets 0 / 1 / 2 / 3 KiB do the rest -- 1.5
+// instructions per KiB instead of 3 (a single wavefront issues one instruction per ~8 cycles: the loaders are issue bound).  The callers
+// pre-compensate the sources: granule g's lane offset is v[g] = true offset + 3072 - (g & 3) * 1024 against sbase - 3072.
+__device__ __forceinline__ void dma16_saddr(const unsigned* v, const void* sbase, unsigned dst) {
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %10\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %9\n\tglobal_load_lds_dwordx4 %2, %9 offset:1024\n\t"
-      "global_load_lds_dwordx4 %3, %9 offset:2048\n\tglobal_load_lds_dwordx4 %4, %9 offset:3072\n\t"
-      "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %5, %9\n\tglobal_load_lds_dwordx4 %6, %9 offset:1024\n\t"
-      "global_load_lds_dwordx4 %7, %9 offset:2048\n\tglobal_load_lds_dwordx4 %8, %9 offset:3072\n\t"
+      "s_mov_b32 m0, %18\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %17\n\tglobal_load_lds_dwordx4 %2, %17 offset:1024\n\t"
+      "global_load_lds_dwordx4 %3, %17 offset:2048\n\tglobal_load_lds_dwordx4 %4, %17 offset:3072\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %5, %17\n\tglobal_load_lds_dwordx4 %6, %17 offset:1024\n\t"
+      "global_load_lds_dwordx4 %7, %17 offset:2048\n\tglobal_load_lds_dwordx4 %8, %17 offset:3072\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %9, %17\n\tglobal_load_lds_dwordx4 %10, %17 offset:1024\n\t"
+      "global_load_lds_dwordx4 %11, %17 offset:2048\n\tglobal_load_lds_dwordx4 %12, %17 offset:3072\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %13, %17\n\tglobal_load_lds_dwordx4 %14, %17 offset:1024\n\t"
+      "global_load_lds_dwordx4 %15, %17 offset:2048\n\tglobal_load_lds_dwordx4 %16, %17 offset:3072\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "s"(sbase), "s"(dst)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]),
+        "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "s"(sbase), "s"(dst)
       : "memory", "scc");
 }
-// ... sources as per-lane 64-bit pointers, pre-compensated by -(i & 3) * 1024 (conv A: a tap in the zero padding sources the zero page)
-__device__ __forceinline__ void dma8_vaddr(const void* const* a, unsigned dst) {
+// ... sources as per-lane 64-bit pointers, pre-compensated by -(g & 3) * 1024 (conv A: a tap in the zero padding sources the zero page)
+__device__ __forceinline__ void dma16_vaddr(const void* const* a, unsigned dst) {
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %9\n\ts_nop 0\n\t"
+      "s_mov_b32 m0, %17\n\ts_nop 0\n\t"
       "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
       "global_load_lds_dwordx4 %3, off offset:2048\n\tglobal_load_lds_dwordx4 %4, off offset:3072\n\t"
-      "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
       "global_load_lds_dwordx4 %5, off\n\tglobal_load_lds_dwordx4 %6, off offset:1024\n\t"
       "global_load_lds_dwordx4 %7, off offset:2048\n\tglobal_load_lds_dwordx4 %8, off offset:3072\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %9, off\n\tglobal_load_lds_dwordx4 %10, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %11, off offset:2048\n\tglobal_load_lds_dwordx4 %12, off offset:3072\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %13, off\n\tglobal_load_lds_dwordx4 %14, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %15, off offset:2048\n\tglobal_load_lds_dwordx4 %16, off offset:3072\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "s"(dst)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]),
+        "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]), "s"(dst)
       : "memory", "scc");
 }
 __device__ __forceinline__ const void* uniform_ptr(const void* p) {
@@ -195,15 +208,17 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 }
 
 // ============================================================================================== LOADER
-// Loader l stages granule groups {4l .. 4l+3} and {8+4l .. 8+4l+3} of both operands of EVERY k-tile (16 DMAs per k-tile and loader).  A
-// wavefront's VM_CNT is 6 bits: it can have 63 DMAs in flight, i.e. just under 4 k-tiles of its share -- a loader that takes whole k-tiles
-// (32 DMAs each) stalls at the issue of its second one until the first has landed and delivers one k-tile per DMA latency
-// (profiles/r05_pt_stamp_v6.log: 2 700 cycles per own k-tile).
+// FOUR loaders, loader l OWNS ring slot l: it stages the k-tiles q = l, l + 4, l + 8, ... whole (16 A + 16 B granules).  Why four and why
+// whole k-tiles (profiles/r05_pt_stamp_v*.log): a single wavefront issues ONE instruction per ~8 cycles, and the bookkeeping of a k-tile --
+// counters, item cursor, addresses: ~150 scalar instructions as hipcc compiles it -- costs a loader ~1 200 cycles whatever the number of DMAs
+// behind it; two loaders that each touch every k-tile deliver one k-tile per ~1 500 cycles (MFMA time of the tile: 768).  With four, a loader
+// has four k-tile times per k-tile of its own.  Its VM_CNT (6 bits) holds one whole k-tile (32 DMAs) comfortably.
 template <int AMODE>
 __device__ __forceinline__ void pt_loader(const GemmParams& p, unsigned char* smem, unsigned lds0, int i0, int i1, int l, int lane) {
+  static_assert(NLW == NBUF, "a loader owns one ring slot");
   const mvd_gemm_desc& d = p.d;
   const unsigned fl = lds0 + OFF_FLAGS, abort_addr = fl + F_ABORT * 4;
-  int* const tab = (int*)(smem + OFF_TAB) + l * 64 * 9;
+  int* const tab = (int*)(smem + OFF_TAB) + l * 128 * 9;
   const int gr = lane >> 3;
   // Empty the compiler's VMEM scoreboard here: a register reloaded from scratch in the common prologue would otherwise get its
   // `s_waitcnt vmcnt(0)` at its first use INSIDE the issue loop below (seen in the ISA) -- and there it waits for every LDS-DMA in flight.
@@ -211,10 +226,10 @@ __device__ __forceinline__ void pt_loader(const GemmParams& p, unsigned char* sm
   int Qtotal = 0;
   for (int i = i0; i < i1; ++i) Qtotal += pt_item_nkt(p, i);
 
+  // cursor over ALL k-tiles of the workgroup (the other loaders' are skipped, but every item's geometry is walked)
   int item = i0, it = 0, nkt = 0, kt0 = 0, tab_m0 = -1;
   unsigned voffA[LGR], voffB[LGR];
-  int a_chunk[LGR];                                        // conv: chunk offset of this lane inside granule i's 128-byte line
-  int c_tap = 0, c_cb = 0;
+  int a_chunk[LGR];                                        // conv: chunk offset of this lane inside granule g's 128-byte line
   const size_t b_kbytes = d.b_mode == MVD_B_PLANES ? (size_t)128 : (size_t)p.nt16 * 2048;
   auto setup_item = [&]() {
     const PtItem w = pt_item(p, item);
@@ -222,157 +237,137 @@ __device__ __forceinline__ void pt_loader(const GemmParams& p, unsigned char* sm
     kt0 = w.kt0;
     it = 0;
 #pragma unroll
-    for (int i = 0; i < LGR; ++i) {
-      const int gi = (i >> 2) * 8 + l * 4 + (i & 3);       // granule = 8-row group of the tile (A) / fragment image or 8-row group (B)
+    for (int gi = 0; gi < LGR; ++gi) {                     // granule = 8-row group of the tile (A) / fragment image or 8-row group (B)
       const int R = (gi & 1) * 8 + gr;
       const int gc = (lane & 7) ^ ((R >> 1) & 7);
-      const unsigned comp = 3072u - (unsigned)(i & 3) * 1024u;        // (dma8_saddr: immediate offsets 0 .. 3 KiB against a base 3 KiB lower)
+      const unsigned comp = 3072u - (unsigned)(gi & 3) * 1024u;       // (dma16_saddr: immediate offsets 0 .. 3 KiB against a base 3 KiB lower)
       int m = w.m0 + gi * 8 + gr;
       if (m > d.M - 1) m = d.M - 1;                        // rows past M: any valid line (the epilogue never stores them)
-      voffA[i] = (unsigned)m * (unsigned)(4 * d.lda) + gc * 16 + comp;
-      a_chunk[i] = gc * 8;
+      voffA[gi] = (unsigned)m * (unsigned)(4 * d.lda) + gc * 16 + comp;
+      a_chunk[gi] = gc * 8;
       if (d.b_mode == MVD_B_PLANES) {
         int n = w.n0 + gi * 8 + gr;
         if (n > d.N - 1) n = d.N - 1;
-        voffB[i] = (unsigned)n * (unsigned)(4 * d.ldb) + gc * 16 + comp;
+        voffB[gi] = (unsigned)n * (unsigned)(4 * d.ldb) + gc * 16 + comp;
       } else {
         int nt = (w.n0 >> 4) + (gi >> 1);
         if (nt > p.nt16 - 1) nt = p.nt16 - 1;
-        voffB[i] = (unsigned)nt * 2048u + (gi & 1) * 1024 + lane * 16 + comp;
+        voffB[gi] = (unsigned)nt * 2048u + (gi & 1) * 1024 + lane * 16 + comp;
       }
     }
-    if (AMODE != MVD_A_DENSE) {
-      c_cb = kt0 / 9;
-      c_tap = kt0 - c_cb * 9;
-      if (w.m0 != tab_m0) {                                // source offset of every (row of this loader, tap); -1: zero padding / past M
-        tab_m0 = w.m0;
-        const int hw = d.Hout * d.Wout;
-        for (int e = lane; e < 64 * 9; e += 64) {
-          const int rs = e / 9, tap = e - rs * 9;          // rs = i * 8 + row of the granule
-          const int i = rs >> 3;
-          const int row = ((i >> 2) * 8 + l * 4 + (i & 3)) * 8 + (rs & 7);
-          const int m = w.m0 + row;
-          int off = -1;
-          if (m < d.M) {
-            const int b = m / hw;
-            const int rem = m - b * hw;
-            const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            int iy, ix;
-            bool ok;
-            if (d.upsample) {
-              const int uy = oy + ky - 1, ux = ox + kx - 1;
-              ok = uy >= 0 && uy < d.Hout && ux >= 0 && ux < d.Wout;
-              iy = uy >> 1;
-              ix = ux >> 1;
-            } else {
-              iy = oy * d.stride + ky - (d.no_pad_tl ? 0 : 1);
-              ix = ox * d.stride + kx - (d.no_pad_tl ? 0 : 1);
-              ok = iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
-            }
-            if (ok) off = ((b * d.Hin + iy) * d.Win + ix) * 2 * d.Cin;
+    if (AMODE != MVD_A_DENSE && w.m0 != tab_m0) {          // source offset of every (tile row, tap); -1: zero padding / past M
+      tab_m0 = w.m0;
+      const int hw = d.Hout * d.Wout;
+      for (int e = lane; e < 128 * 9; e += 64) {
+        const int row = e / 9, tap = e - row * 9;
+        const int m = w.m0 + row;
+        int off = -1;
+        if (m < d.M) {
+          const int b = m / hw;
+          const int rem = m - b * hw;
+          const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
+          const int ky = tap / 3, kx = tap - ky * 3;
+          int iy, ix;
+          bool ok;
+          if (d.upsample) {
+            const int uy = oy + ky - 1, ux = ox + kx - 1;
+            ok = uy >= 0 && uy < d.Hout && ux >= 0 && ux < d.Wout;
+            iy = uy >> 1;
+            ix = ux >> 1;
+          } else {
+            iy = oy * d.stride + ky - (d.no_pad_tl ? 0 : 1);
+            ix = ox * d.stride + kx - (d.no_pad_tl ? 0 : 1);
+            ok = iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
           }
-          tab[e] = off;
+          if (ok) off = ((b * d.Hin + iy) * d.Win + ix) * 2 * d.Cin;
         }
+        tab[e] = off;
       }
     }
   };
-  auto issue_a = [&](int slot) {
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + slot * STAGE + l * 4096));
+  const unsigned dstA = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + l * STAGE)), dstB = dstA + 16384;
+  auto issue_a = [&]() {
     if (AMODE == MVD_A_DENSE) {
-      dma8_saddr(voffA, uniform_ptr((const unsigned char*)d.A + (size_t)(kt0 + it) * 128 - 3072), dst);
+      dma16_saddr(voffA, uniform_ptr((const unsigned char*)d.A + (size_t)(kt0 + it) * 128 - 3072), dstA);
     } else {
+      const int kt = kt0 + it, cb = kt / 9, tap = kt - cb * 9;
       const void* src[LGR];
 #pragma unroll
-      for (int i = 0; i < LGR; ++i) {
-        const int off = tab[(i * 8 + gr) * 9 + c_tap];
-        const unsigned char* sp = off >= 0 ? (const unsigned char*)((const u16*)d.A + (unsigned)(off + c_cb * 64 + a_chunk[i]))
+      for (int gi = 0; gi < LGR; ++gi) {
+        const int off = tab[(gi * 8 + gr) * 9 + tap];
+        const unsigned char* sp = off >= 0 ? (const unsigned char*)((const u16*)d.A + (unsigned)(off + cb * 64 + a_chunk[gi]))
                                            : (const unsigned char*)g_pt_zero_page;
-        src[i] = sp - (i & 3) * 1024;
+        src[gi] = sp - (gi & 3) * 1024;
       }
-      dma8_vaddr(src, dst);
-      if (++c_tap == 9) {
-        c_tap = 0;
-        ++c_cb;
-      }
+      dma16_vaddr(src, dstA);
     }
   };
-  auto issue_b = [&](int slot) {
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + slot * STAGE + 16384 + l * 4096));
-    dma8_saddr(voffB, uniform_ptr((const unsigned char*)d.Wp + (size_t)(kt0 + it) * b_kbytes - 3072), dst);
-  };
+  auto issue_b = [&]() { dma16_saddr(voffB, uniform_ptr((const unsigned char*)d.Wp + (size_t)(kt0 + it) * b_kbytes - 3072), dstB); };
 
-  int qi = 0, signalled = 0;
-  unsigned issued_instr = 0;
+  // My slot's latest use may have ended as (half of) a staging tile: then the EPILOGUE waves release it (F_ECNT: four 16-row units per
+  // staged use), else the consumers' fragment reads do (F_CREAD counts every use).
+  unsigned uses = 0, staged_uses = 0;   // uses of my slot issued so far / of which staged
+  bool staged_last = false;
+  int qi = l;                           // my next k-tile (global index)
+  int passed = 0;                       // k-tiles the cursor (item, it) has walked over
+  int mine_signalled = 0;
+  const int mine_total = Qtotal > l ? (Qtotal - l + NLW - 1) / NLW : 0;
   int idle = 0;
-  // Slots whose latest use ended as (half of) a staging tile are released by the EPILOGUE waves (F_ECNT: four 16-row units per slot and
-  // staged use), the others by the consumers' fragment reads (F_CREAD).  staged_uses: 16 bits per slot; staged_last: bit per slot.
-  unsigned long long staged_uses = 0;
-  unsigned staged_last = 0;
-  // The release counters of the NEXT slot are read while this k-tile's DMAs are being issued (an LDS round trip takes hundreds of cycles
-  // when eight consumer waves keep the LDS queue full).  The counters only grow: a stale "free" is still free, a stale "busy" is polled again.
-  unsigned long long pre = 0;        // {F_CREAD[slot], F_ECNT[slot]} of slot qi & 3, read one iteration ago
-  bool pre_valid = false;
   [[maybe_unused]] long long st_iter = 0, st_idle = 0, st_issue = 0, st_notfree = 0, st_flyfull = 0;
   [[maybe_unused]] const long long st_t0 = PT_NOW();
-  while (signalled < Qtotal) {
+  auto walk_to = [&](int q) {           // move the cursor to k-tile q (whole items at a time where possible)
+    while (passed < q) {
+      if (it == nkt) setup_item();
+      const int step = min(nkt - it, q - passed);
+      it += step;
+      passed += step;
+      if (it == nkt && passed < Qtotal) ++item;
+      else if (it == nkt) break;
+    }
+    if (it == nkt && passed < Qtotal) setup_item();
+  };
+  while (mine_signalled < mine_total) {
     bool progress = false;
 #ifdef MVD_PT_STAMP
     ++st_iter;
 #endif
-    // ---- what has landed (loads return in order): publish
-    if (signalled < qi) {
-      const int landed = (MVD_PT_VARIANT & 4) ? qi : (int)((issued_instr - read_vmcnt()) >> 4);
-      while (signalled < landed) {
-        lds_add1(fl + (F_FULL + (signalled & 3)) * 4);
-        ++signalled;
+    // ---- has my k-tile in flight landed?  (at most one: the next use of my slot needs it consumed first)
+    if ((int)uses > mine_signalled) {
+      const bool landed = (MVD_PT_VARIANT & 4) ? true : read_vmcnt() == 0;
+      if (landed) {
+        lds_add1(fl + (F_FULL + l) * 4);
+        ++mine_signalled;
         progress = true;
       }
     }
-    // ---- issue my share of the next k-tile as soon as its slot is free (<= 3 k-tiles = 48 DMAs in flight: VM_CNT is 6 bits)
-    if (qi < Qtotal && qi - signalled < 3) {
-      const int slot = qi & 3;
+    // ---- issue my next k-tile as soon as my slot is free
+    if (qi < Qtotal && (int)uses == mine_signalled) {
       bool free_ = true;
-      if (qi >= NBUF) {
-        if (!pre_valid) asm volatile("ds_read2_b32 %0, %1 offset1:4\n\ts_waitcnt lgkmcnt(0)" : "=v"(pre) : "v"(fl + (F_CREAD + slot) * 4) : "memory");
-        const unsigned cr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pre);
-        const unsigned ec = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pre >> 32));
-        pre_valid = false;
-        free_ = ge(cr, NCW * (unsigned)(qi >> 2));                          // every consumer has read all earlier uses of the slot ...
-        if ((staged_last >> slot) & 1) {                                    // ... and the epilogue waves the staging units it last held
-          const unsigned want = 4u * (unsigned)((staged_uses >> (slot * 16)) & 0xffffu);      // (modulo 2^16)
-          free_ = free_ && (short)(unsigned short)(ec - want) >= 0;
-        }
+      if (uses > 0) {
+        unsigned cr, ec;
+        lds_ld2(fl + (F_CREAD + l) * 4, cr, ec);
+        free_ = ge(cr, NCW * uses);                                         // every consumer has read all earlier uses of the slot ...
+        if (staged_last) free_ = free_ && ge(ec, 4u * staged_uses);         // ... and the epilogue waves the staging units it last held
       }
 #ifdef MVD_PT_STAMP
       if (!free_) ++st_notfree;
 #endif
       if (free_) {
         PT_T(ti);
-        if (it == nkt) setup_item();                                        // (nkt = 0 before the first item)
-        const bool look = qi + 1 >= NBUF && qi + 1 < Qtotal;
-        if (look) asm volatile("ds_read2_b32 %0, %1 offset1:4" : "=v"(pre) : "v"(fl + (F_CREAD + ((qi + 1) & 3)) * 4) : "memory");
+        walk_to(qi);
         if (!(MVD_PT_VARIANT & 4)) {
-          issue_a(slot);
-          issue_b(slot);
-        }
-        if (look) {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre)::"memory");
-          pre_valid = true;
+          issue_a();
+          issue_b();
         }
         PT_ACC(st_issue, ti);
-        issued_instr += 2 * LGR;
-        const bool staged = it >= nkt - 2;                                  // the tile's last two k-tiles
-        staged_last = (staged_last & ~(1u << slot)) | ((staged ? 1u : 0u) << slot);
-        if (staged) staged_uses += 1ull << (slot * 16);
-        ++it;
-        if (it == nkt) ++item;
-        ++qi;
+        staged_last = it >= nkt - 2;                                        // the tile's last two k-tiles: their slots become its staging tile
+        if (staged_last) ++staged_uses;
+        ++uses;
+        qi += NLW;
         progress = true;
       }
     }
 #ifdef MVD_PT_STAMP
-    if (qi < Qtotal && qi - signalled >= 3) ++st_flyfull;
     if (!progress) ++st_idle;
 #endif
     if (!progress) {
@@ -386,7 +381,7 @@ __device__ __forceinline__ void pt_loader(const GemmParams& p, unsigned char* sm
       idle = 0;
     }
   }
-  if (l == 0) PT_DUMP(d, 1, PT_NOW() - st_t0, st_iter, st_idle, st_issue, st_notfree, st_flyfull, (long long)Qtotal);
+  if (l == 0) PT_DUMP(d, 1, PT_NOW() - st_t0, st_iter, st_idle, st_issue, st_notfree, st_flyfull, (long long)mine_total);
 }
 
 // ============================================================================================== CONSUMER
@@ -413,7 +408,7 @@ __device__ __forceinline__ void pt_consumer(const GemmParams& p, unsigned char* 
   for (int i = i0; i < i1; ++i) Qtotal += pt_item_nkt(p, i);
   [[maybe_unused]] long long st_full = 0, st_dumpw = 0, st_dump = 0, st_nwait = 0;
   [[maybe_unused]] const long long st_t0 = PT_NOW();
-  if (!wait_ge(fl + F_FULL * 4, NLW, abort_addr)) return;
+  if (!wait_ge(fl + F_FULL * 4, 1, abort_addr)) return;
   [[maybe_unused]] const long long st_t1 = PT_NOW();
   // Two nested loops on purpose: with ONE flat loop over k-tiles and the tile end (dump, accumulators = 0) as a branch inside it, the
   // accumulators become a phi of {MFMA result, zero} and hipcc copies all 32 of them to other registers and back in EVERY iteration
@@ -495,7 +490,7 @@ __device__ __forceinline__ void pt_consumer(const GemmParams& p, unsigned char* 
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fnext)::"memory");
       ++q;
       if (q < Qtotal) {                                      // the next k-tile (of this tile or of the next one) must have landed
-        const unsigned need = NLW * ((q >> 2) + 1);           // (every loader publishes its share of the k-tile)
+        const unsigned need = (q >> 2) + 1;                   // (the slot's owner publishes the whole k-tile)
         if (!ge((unsigned)__builtin_amdgcn_readfirstlane((int)fnext), need)) {
           PT_T(tw);
           if (!wait_ge(fl + (F_FULL + (q & 3)) * 4, need, abort_addr)) return;

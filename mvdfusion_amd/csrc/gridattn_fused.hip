@@ -23,18 +23,38 @@
 // consumer, one `s_waitcnt vmcnt(8)` + barrier per slot (64 MFMAs per wave).  The small vectors (adaLN modulation of this
 // step, biases, weight_layer) are DMA'd once into LDS, so the main loop issues no ordinary global load (those would drain
 // the DMA queue at their vmcnt(0)).
+#include <type_traits>
+
 #include "gridattn_common.hpp"
 
 namespace {
 
-constexpr int G4_RING_SLOTS = 3;
+constexpr int G4_RING_SLOTS = 4;
 constexpr int G4_SLOT_BYTES = 32768;                   // 16 micro-tiles (16 weight rows x 32 k, hi | lo = 2 KiB)
-constexpr int G4_VEC_BLOCK = 3328;                     // floats per DiT block: mod 1536 | b_qkv 768 | b_proj 256 | b_fc1 512 | b_fc2 256
-constexpr int G4_VEC_MISC = 3 * G4_VEC_BLOCK;          // b_pre 256 | weight_layer w 256 | weight_layer b (1) ... | acc scales at +520
-constexpr int G4_VEC_GRANULES = 44;                    // 44 KiB staged (11264 floats; 11008 used)
-constexpr int G4_SMEM = G4_RING_SLOTS * G4_SLOT_BYTES + G4_VEC_GRANULES * 1024;
+constexpr int G4_VEC_BLOCK = 3328;                     // floats per DiT block: mod 1536 | b_qkv 768 | b_proj 256 | b_fc1 512 | b_fc2 256 (13 KiB)
+constexpr int G4_VEC_MISC = 3 * G4_VEC_BLOCK;          // (global layout) b_pre 256 | weight_layer w 256 | weight_layer b (1) ... | acc scales at +520
+constexpr int G4_VEC_GRANULES = 44;                    // 44 KiB in global memory (11264 floats; 11008 used)
+// LDS: a ring of FOUR weight slots (three in flight ahead of the consumer) + the misc vectors (4 KiB) + the vectors of TWO DiT blocks
+// (13 KiB each, double-buffered: block b + 1 arrives while block b runs).  The kernel is bound by what one CU has in flight from the
+// Infinity Cache: its 6.9 MB weight stream does not fit the XCD's 4 MiB L2, a slot takes ~2 us to arrive, and with a 3-slot ring (64 KiB in
+// flight) a CU received 12 B/clk -- 2 700 cycles per slot against 768 cycles of MFMA work (r05_g4_time.log).  All three blocks' vectors
+// resident (44 KiB) left no room for the fourth slot.
+constexpr int G4_OFF_MISC = G4_RING_SLOTS * G4_SLOT_BYTES;
+constexpr int G4_OFF_BLK = G4_OFF_MISC + 4096;
+constexpr int G4_BLK_BYTES = G4_VEC_BLOCK * 4;         // 13 312 = 13 granules
+constexpr int G4_SMEM = G4_OFF_BLK + 2 * G4_BLK_BYTES;
+static_assert(G4_SMEM <= 160 * 1024 && G4_BLK_BYTES == 13 * 1024, "LDS budget");
+
+// -DMVD_G4_STAMP (tools/probes/g4_stamp.sh): cycle accounting of workgroup 0 / wave 0 -- waiting for weight slots (DMA + barrier), inside
+// the slots (fragment reads + MFMAs), everything else (the VALU phases) -- written to the buffer mvd_gridattn_fused_debug() names.
+#ifdef MVD_G4_STAMP
+#define G4_NOW() ((long long)__builtin_readcyclecounter())
+#else
+#define G4_NOW() 0ll
+#endif
 
 struct G4Params {
+  long long* dbg;
   const float *x, *depth_noise, *steps;
   const int* iter;
   const float *grid_lin, *feat, *in_feat, *cams, *in_cam;
@@ -51,9 +71,9 @@ struct Frag {   // one MFMA operand fragment (8 elements) as hi + lo
 
 __device__ __forceinline__ Frag make_frag(const float (&v)[8]) {
   Frag f;
-  union { op16x8 v; u16 e[8]; } H, L;
+  union { op16x8 v; uint32_t e[4]; } H, L;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) split_op16(v[j], H.e[j], L.e[j]);
+  for (int j = 0; j < 4; ++j) split_op16x2(v[2 * j], v[2 * j + 1], H.e[j], L.e[j]);      // (packed: 5 instructions per pair)
   f.hi = H.v;
   f.lo = L.v;
   return f;
@@ -178,44 +198,94 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
-  const float* svec = (const float*)(smem + G4_RING_SLOTS * G4_SLOT_BYTES);
+  const float* const smisc = (const float*)(smem + G4_OFF_MISC);        // index = global index - G4_VEC_MISC
   const int V = p.V, Vp = p.Vp, lv = p.lv, S = p.S, D = p.D, SS = S * S;
 
   // ------------------------------------------------------------------ LDS-DMA engine
-  const unsigned char* wsrc = p.wstream + (size_t)wave * 8192 + lane * 16;   // this wave copies granules [8 wave, 8 wave + 8) of a slot
+  // This wave copies granules [8 wave, 8 wave + 8) of every slot.  The copy is linear (source stride = destination stride = 1 KiB), so
+  // the DMAs are issued in the scalar-base form with immediate offsets, which move source and destination alike
+  // (tools/probes/dma_offset_probe.hip): M0 written twice per slot, 12 instructions for 8 KiB.  Through the builtin each DMA was a 64-bit
+  // pointer add + s_mov m0 + load, 32 instructions per slot on a wave that issues one instruction per ~8 cycles and has only 48 MFMAs
+  // (768 cycles) of work per slot.  Inline asm: hipcc does not count these; the counted waits are in g4_wait_barrier.
+  const unsigned dma_voff = lane * 16;
+  const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+  auto dma8 = [&](const unsigned char* sbase, unsigned dst) {      // 8 KiB: sbase + lane * 16 + i KiB -> LDS dst + i KiB (lane-linear)
+    unsigned keep;
+    const unsigned v1 = dma_voff + 4096;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:2048\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:2048\n\tglobal_load_lds_dwordx4 %2, %3 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(dma_voff), "v"(v1), "s"(sbase), "s"(dst)
+        : "memory", "scc");
+  };
+  const unsigned char* const wsrc = p.wstream + (size_t)wave * 8192;
   int s_issue = 0;                 // next slot to stage
   auto issue_slot = [&]() {
-    if (s_issue < p.nslots) {
-      unsigned char* dst = smem + (s_issue % G4_RING_SLOTS) * G4_SLOT_BYTES + wave * 8192;
-      const unsigned char* src = wsrc + (size_t)s_issue * G4_SLOT_BYTES;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-    }
+    if (s_issue < p.nslots) dma8(wsrc + (size_t)s_issue * G4_SLOT_BYTES, lds_ring + (s_issue % G4_RING_SLOTS) * G4_SLOT_BYTES + wave * 8192);
     ++s_issue;
   };
-  {   // the small vectors: 44 granules, 11 per wave
-    const unsigned char* vsrc = (const unsigned char*)p.vecs + (size_t)wave * 11 * 1024 + lane * 16;
-    unsigned char* vdst = smem + G4_RING_SLOTS * G4_SLOT_BYTES + wave * 11 * 1024;
-#pragma unroll
-    for (int i = 0; i < 11; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(vdst + i * 1024), 16, 0, 0);
-  }
+  // 1 - 4 consecutive granules (wave-uniform count)
+  auto dma_run = [&](const unsigned char* sbase, unsigned dst, int cnt) {
+    unsigned keep;
+    if (cnt == 4)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(dma_voff), "s"(sbase), "s"(dst) : "memory");
+    else if (cnt == 3)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(dma_voff), "s"(sbase), "s"(dst) : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(dma_voff), "s"(sbase), "s"(dst) : "memory");
+  };
+  // the 13 granules of DiT block `blk`'s vectors -> LDS buffer blk & 1: wave 0 takes granules 0-3, waves 1-3 three each
+  auto stage_block_vecs = [&](int blk) {
+    const int g0 = wave == 0 ? 0 : 1 + 3 * wave, cnt = wave == 0 ? 4 : 3;
+    dma_run((const unsigned char*)p.vecs + (size_t)blk * G4_BLK_BYTES + g0 * 1024, lds_ring + G4_OFF_BLK + (blk & 1) * G4_BLK_BYTES + g0 * 1024, cnt);
+  };
+  dma_run((const unsigned char*)p.vecs + (size_t)G4_VEC_MISC * 4 + wave * 1024, lds_ring + G4_OFF_MISC + wave * 1024, 1);      // misc: 4 granules
+  stage_block_vecs(0);
+  stage_block_vecs(1);
+  bool stage_blk2 = false;         // set at the top of block 1: block 2's vectors replace block 0's behind the next barrier
+  issue_slot();
   issue_slot();
   issue_slot();
   int s_cur = 0;                   // slot being consumed
-  // returns the LDS base of slot s_cur once it has landed for every wave, and stages slot s_cur + 2 into the ring position
-  // that slot s_cur - 1 occupied (every wave has passed its last read of it: lgkmcnt(0) before the barrier)
-  auto acquire = [&]() -> const unsigned char* {
-    if (s_cur + 1 < p.nslots) g4_wait_barrier<8>();
+  // acquire_wait: the LDS base of slot s_cur once it has landed for every wave; stage_ahead: DMA of the slot THREE ahead of the one being
+  // consumed into the ring position of the slot consumed before it (every wave has passed its last read of that one: lgkmcnt(0) before the
+  // barrier of acquire_wait).  Called between the first and second MFMA group of a slot, so that the
+  // fragment reads of the slot go out first and the DMA instructions issue in the shadow of running MFMAs.
+  [[maybe_unused]] long long st_wait = 0, st_slot = 0;
+  [[maybe_unused]] const long long st_t0 = G4_NOW();
+  auto acquire_wait = [&]() -> const unsigned char* {
+    [[maybe_unused]] const long long tw = G4_NOW();
+    // (counted: the DMAs of the slots issued AFTER slot s_cur may stay in flight -- two in the steady state; the vector DMAs in between only
+    //  make the wait longer, never shorter: a wave's loads return in order)
+    if (s_cur + 2 < p.nslots) g4_wait_barrier<16>();
+    else if (s_cur + 1 < p.nslots) g4_wait_barrier<8>();
     else g4_wait_barrier<0>();
-    issue_slot();
+    if (stage_blk2) {              // every wave is past its last read of block 0's vectors (it has entered block 1)
+      stage_block_vecs(2);
+      stage_blk2 = false;
+    }
     const unsigned char* base = smem + (s_cur % G4_RING_SLOTS) * G4_SLOT_BYTES;
     ++s_cur;
+#ifdef MVD_G4_STAMP
+    st_wait += G4_NOW() - tw;
+#endif
     return base;
   };
+  auto stage_ahead = [&]() { issue_slot(); };
   // fragment read offsets inside a 2 KiB micro-tile (same swizzle as gemm.hip): row R = lane & 15, 16-byte chunk g (hi) / 4 + g (lo)
   const int fsw = (r16 >> 1) & 7;
   const int fbase = (r16 >> 3) * 1024 + (r16 & 7) * 128;
@@ -226,6 +296,40 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
     f.hi = *(const op16x8*)(slot + mt * 2048 + foff_hi);
     f.lo = *(const op16x8*)(slot + mt * 2048 + foff_lo);
     return f;
+  };
+  auto read_group = [&](const unsigned char* slot, int gq, Frag (&w)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = read_w(slot, gq * 4 + q);
+  };
+  // One slot = 16 micro-tiles = 4 groups of 4 tiles (12 MFMAs per group: four independent accumulators per product term).  ONE wavefront
+  // per SIMD runs this kernel (360+ registers), so nothing hides an LDS round trip it waits for: left to itself hipcc places each fragment
+  // read right in front of the MFMA that needs it ("R w M R w M": 2 800 cycles per slot for 768 cycles of MFMA, 27 % of the pipe).  Here
+  // the reads run two groups ahead of the MFMAs in three register sets, and scheduling barriers pin the phases
+  //   R(g0) R(g1) R(g2) | M(g0) + DMA of the slot two ahead | R(g3) | M(g1) M(g2) | M(g3)
+  // -- one exposed round trip per slot (its first group), the rest under 12 - 24 MFMAs; the counted lgkmcnt waits are the compiler's.
+  // group_fn(integral_constant<gq>, w): the MFMAs of group gq (term-major over its four tiles, as before: same order per accumulator).
+  auto run_slot = [&](auto&& group_fn) {
+    using std::integral_constant;
+    const unsigned char* sl = acquire_wait();
+    [[maybe_unused]] const long long ts = G4_NOW();
+    Frag wa[4], wb[4], wc[4];
+    read_group(sl, 0, wa);
+    read_group(sl, 1, wb);
+    read_group(sl, 2, wc);
+    __builtin_amdgcn_sched_barrier(0);
+    group_fn(integral_constant<int, 0>{}, wa);
+    stage_ahead();
+    __builtin_amdgcn_sched_barrier(0);
+    read_group(sl, 3, wa);
+    __builtin_amdgcn_sched_barrier(0);
+    group_fn(integral_constant<int, 1>{}, wb);
+    group_fn(integral_constant<int, 2>{}, wc);
+    __builtin_amdgcn_sched_barrier(0);
+    group_fn(integral_constant<int, 3>{}, wa);
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef MVD_G4_STAMP
+    st_slot += G4_NOW() - ts;
+#endif
   };
 
   // ------------------------------------------------------------------ G1-G3: this lane's row of the token matrix
@@ -298,12 +402,8 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
   for (int j = 0; j < 16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // one slot = the 16 output tiles of one k-step, in groups of 4 tiles (four independent accumulators per MFMA burst)
   auto slot_16tiles = [&](const Frag& xf) {
-    const unsigned char* sl = acquire();
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      Frag w[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) w[q] = read_w(sl, gq * 4 + q);
+    run_slot([&](auto gq_c, const Frag (&w)[4]) {
+      constexpr int gq = decltype(gq_c)::value;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if constexpr (NS == 4) mma_lolo(acc[gq * 4 + q], w[q], xf);
@@ -313,7 +413,7 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
       for (int q = 0; q < 4; ++q) mma_hilo(acc[gq * 4 + q], w[q], xf);
 #pragma unroll
       for (int q = 0; q < 4; ++q) mma_hihi(acc[gq * 4 + q], w[q], xf);
-    }
+    });
   };
   // The token fragments are produced in chunks of four k-steps right before they are consumed (all 23 at once would not fit
   // the register file); the ordinary loads of a chunk wait at vmcnt(0), i.e. once per chunk the two prefetched weight slots
@@ -342,10 +442,10 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
     slot_16tiles(make_frag(v));
   }
   {
-    const float sc = svec[G4_VEC_MISC + 520];
+    const float sc = smisc[520];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float4 bb = *(const float4*)(svec + G4_VEC_MISC + 16 * j + 4 * g);
+      const float4 bb = *(const float4*)(smisc + 16 * j + 4 * g);
       h[j][0] = gelu_erf(acc[j][0] * sc + bb.x);
       h[j][1] = gelu_erf(acc[j][1] * sc + bb.y);
       h[j][2] = gelu_erf(acc[j][2] * sc + bb.z);
@@ -403,25 +503,22 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
 
   // ------------------------------------------------------------------ 3 x DiTBlock (view_attn_efficient2.py:42-67)
   for (int blk = 0; blk < 3; ++blk) {
-    const float* vb = svec + blk * G4_VEC_BLOCK;
+    const float* vb = (const float*)(smem + G4_OFF_BLK + (blk & 1) * G4_BLK_BYTES);
+    if (blk == 1) stage_blk2 = true;
     const float* mod = vb;                 // shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
-    const float sc_qkv = svec[G4_VEC_MISC + 521 + blk * 4], sc_proj = svec[G4_VEC_MISC + 522 + blk * 4];
-    const float sc_fc1 = svec[G4_VEC_MISC + 523 + blk * 4], sc_fc2 = svec[G4_VEC_MISC + 524 + blk * 4];
+    const float sc_qkv = smisc[521 + blk * 4], sc_proj = smisc[522 + blk * 4];
+    const float sc_fc1 = smisc[523 + blk * 4], sc_fc2 = smisc[524 + blk * 4];
     ln_modulate(mod, mod + 256);
     // ---- attention over the V views, head by head: qkv (3 slots) then this head's slice of proj (1 slot)
     for (int hd = 0; hd < 8; ++hd) {
       f32x4 qkv[6];      // q0 q1 k0 k1 (transposed layout: row r16, d = 16j + 4g + r) | v0 v1 (row 4g + r, d = 16j + r16)
 #pragma unroll
       for (int t6 = 0; t6 < 6; ++t6) qkv[t6] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int sl3 = 0; sl3 < 3; ++sl3) {
-        const unsigned char* sl = acquire();
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          Frag w[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) w[q] = read_w(sl, gq * 4 + q);
-          // micro-tile index within the head phase: mt = 16 sl3 + 4 gq + q -> k-step mt / 6, tile mt % 6
+      // micro-tile index within the head phase: mt = 16 sl3 + 4 gq + q -> k-step mt / 6, tile mt % 6
+      auto qkv_slot = [&](auto sl3_c) {
+        constexpr int sl3 = decltype(sl3_c)::value;
+        run_slot([&](auto gq_c, const Frag (&w)[4]) {
+          constexpr int gq = decltype(gq_c)::value;
 #pragma unroll
           for (int term = 0; term < 4; ++term) {
 #pragma unroll
@@ -441,8 +538,11 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
               }
             }
           }
-        }
-      }
+        });
+      };
+      qkv_slot(std::integral_constant<int, 0>{});
+      qkv_slot(std::integral_constant<int, 1>{});
+      qkv_slot(std::integral_constant<int, 2>{});
       // bias (+ scale on q): timm Attention q = (x Wq^T + bq) * hd^-0.5
       const float* bq = vb + 1536 + 32 * hd;
       const float* bk = vb + 1536 + 256 + 32 * hd;
@@ -488,18 +588,18 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
       // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]   (16x16x16 MFMA; A = V^T fragment = the un-transposed v tile)
       op4_t ph, pl;
       {
-        union { op4_t v; u16 e[4]; } H, L;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) split_op16(st[r] / den, H.e[r], L.e[r]);
+        union { op4_t v; uint32_t w[2]; } H, L;
+        split_op16x2(st[0] / den, st[1] / den, H.w[0], L.w[0]);
+        split_op16x2(st[2] / den, st[3] / den, H.w[1], L.w[1]);
         ph = H.v;
         pl = L.v;
       }
       f32x4 ot[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        union { op4_t v; u16 e[4]; } H, L;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) split_op16(qkv[4 + j][r], H.e[r], L.e[r]);
+        union { op4_t v; uint32_t w[2]; } H, L;
+        split_op16x2(qkv[4 + j][0], qkv[4 + j][1], H.w[0], L.w[0]);
+        split_op16x2(qkv[4 + j][2], qkv[4 + j][3], H.w[1], L.w[1]);
         ot[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         ot[j] = MVD_MFMA_16x16x16(L.v, pl, ot[j]);
         ot[j] = MVD_MFMA_16x16x16(L.v, ph, ot[j]);
@@ -517,15 +617,10 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
       f32x4 f1[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) f1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int sl2 = 0; sl2 < 2; ++sl2) {
-        const unsigned char* sl = acquire();
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {     // group = one k-step, the chunk's four 16-channel tiles
-          Frag w[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) w[q] = read_w(sl, gq * 4 + q);
-          const int ks = 4 * sl2 + gq;
+      auto fc1_slot = [&](auto sl2_c) {       // group = one k-step, the chunk's four 16-channel tiles
+        constexpr int sl2 = decltype(sl2_c)::value;
+        run_slot([&](auto gq_c, const Frag (&w)[4]) {
+          constexpr int ks = 4 * sl2 + decltype(gq_c)::value;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if constexpr (NS == 4) mma_lolo(f1[q], w[q], xf[ks]);
@@ -535,8 +630,10 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
           for (int q = 0; q < 4; ++q) mma_hilo(f1[q], w[q], xf[ks]);
 #pragma unroll
           for (int q = 0; q < 4; ++q) mma_hihi(f1[q], w[q], xf[ks]);
-        }
-      }
+        });
+      };
+      fc1_slot(std::integral_constant<int, 0>{});
+      fc1_slot(std::integral_constant<int, 1>{});
       const float* b1 = vb + 2560 + 64 * ch;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -554,7 +651,7 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
 
   // ------------------------------------------------------------------ weight_layer + softmax over V + weighted sum (:83,396-397)
   {
-    const float* wl = svec + G4_VEC_MISC + 256;
+    const float* wl = smisc + 256;
     float part = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -563,7 +660,7 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
     }
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
-    const float lg = pad_row ? -INFINITY : part + svec[G4_VEC_MISC + 512];
+    const float lg = pad_row ? -INFINITY : part + smisc[512];
     // the Vp slots of a point are Vp consecutive lanes (r16): reduce over the low log2(Vp) lane bits (slot 0 is always real)
     float mx = lg;
     for (int o = 1; o < Vp; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -584,10 +681,21 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
       if (vslot == 0) store_sp4(p.pooled_sp, prow, 256, 16 * j + 4 * g, v0, v1, v2, v3);
     }
   }
+#ifdef MVD_G4_STAMP
+  if (p.dbg && blockIdx.x == 0 && tid == 0) {
+    p.dbg[0] = G4_NOW() - st_t0;
+    p.dbg[1] = st_wait;
+    p.dbg[2] = st_slot;
+  }
+#endif
 }
 
 }  // namespace
 
+static long long* g_g4_dbg = nullptr;
+#ifdef MVD_G4_STAMP
+extern "C" void mvd_gridattn_fused_debug(long long* p) { g_g4_dbg = p; }
+#endif
 extern "C" int mvd_gridattn_fused_slots(void) { return 23 + 3 * 64; }
 extern "C" size_t mvd_gridattn_fused_stream_bytes(void) { return (size_t)(23 + 3 * 64) * G4_SLOT_BYTES; }
 extern "C" size_t mvd_gridattn_fused_vec_floats(void) { return (size_t)G4_VEC_GRANULES * 256; }
@@ -609,6 +717,7 @@ extern "C" int mvd_gridattn_fused(const float* x, const float* depth_noise, cons
   const size_t T = (size_t)Vq * S * S * D * Vp;           // token rows incl. the padding slots
   MVD_CHECK_ARG(T % 64 == 0, "mvd_gridattn_fused: padded token count %zu must be a multiple of 64", T);
   G4Params p;
+  p.dbg = g_g4_dbg;
   p.x = x; p.depth_noise = depth_noise; p.steps = steps; p.iter = iter; p.grid_lin = grid_lin; p.feat = feat;
   p.in_feat = in_feat; p.cams = cams; p.in_cam = in_cam; p.wstream = (const unsigned char*)wstream; p.vecs = vecs;
   p.pooled_sp = (u16*)pooled_sp; p.V = V; p.Vp = Vp; p.lv = lv; p.q0 = q0; p.Vq = Vq; p.S = S; p.D = D; p.nslots = 23 + 3 * 64;

@@ -649,7 +649,9 @@ def _autotune(d, A=None, reps=4, trials=3, W_data=None):
     # Loops the tuner does not time unless asked (MVD_TUNE_INCLUDE_LOOPS=8,9): the two register-staged delivery paths of round 4 were
     # candidates for a whole session and were selected for NO shape of any workload (profiles/r04_ws_variants.json);
     # they stay built, tested (test_gemm_configurations_agree) and selectable by cfg.  MVD_TUNE_EXCLUDE_LOOPS: A/B measurements.
-    skip = {WSR_LOOP, REG_LOOP} - {int(t) for t in os.environ.get("MVD_TUNE_INCLUDE_LOOPS", "").split(",") if t}
+    # ... and the persistent role-split kernel of round 5 (loop 10, csrc/gemm_pt.hip): correct on every epilogue, but its k-loop runs at
+    # ~1 100 cycles per 128x128 k-tile against ~764 for two co-resident workgroups of the plain kernel (profiles/r05_pt_*.log).
+    skip = {WSR_LOOP, REG_LOOP, PT_LOOP} - {int(t) for t in os.environ.get("MVD_TUNE_INCLUDE_LOOPS", "").split(",") if t}
     skip |= {int(t) for t in os.environ.get("MVD_TUNE_EXCLUDE_LOOPS", "").split(",") if t}      # (e.g. "7" = no role-split kernel)
     cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode, conv=d.a_mode == A_CONV3X3) if cfg_supported(d, c) and _cfg_parts(c)[1] not in skip
              for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]

@@ -4,6 +4,7 @@ HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in
 128-byte requests of wide coalesced reads (global_load_dwordx4 and LDS-DMA alike) at 64 bytes (MI355X_MICROARCH.md, HBM).
 """
 import csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def steady_rows(rows):
@@ -50,7 +51,8 @@ def main():
         nw, sw = write.get(k, [1, 0.0])
         res[k] = {"launches_profiled": nf, "fetch_size_kib_per_launch": sf / nf, "write_size_kib_per_launch": sw / max(nw, 1),
                   "hbm_bytes_per_launch": (2.0 * sf / nf + sw / max(nw, 1)) * 1024.0}
-    json.dump({"recipe": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 12 --warmup 1 "
+    import bench
+    json.dump({"tree": bench.tree_fingerprint(), "recipe": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 12 --warmup 1 "
                          "--no-cpu-baseline [workload flags]; graph-replayed steps only; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
                "workload_args": sys.argv[4:], "kernels": res}, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"])[:12]:
