@@ -150,6 +150,34 @@ __device__ __forceinline__ float erf_nobranch(float x) {
   return copysignf(1.0f - e, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_nobranch(x * 0.70710678118654752440f)); }
+// Two GELUs at once with the polynomial on PACKED fp32 (v_pk_fma_f32 / v_pk_mul_f32: one instruction per pair): the same operations in the
+// same order as gelu_erf on each element => bit-identical results, ~2/3 of the VALU instructions.  (The erf-GELU epilogue of the GEGLU
+// projections is VALU-issue bound: DESIGN.md section 6.)
+typedef __attribute__((ext_vector_type(2))) float mvd_f32x2;
+__device__ __forceinline__ void gelu_erf2(float& x0, float& x1) {
+  const mvd_f32x2 x = {x0, x1};
+  const mvd_f32x2 t = x * 0.70710678118654752440f;
+  const mvd_f32x2 a = {fminf(fabsf(t.x), 4.0f), fminf(fabsf(t.y), 4.0f)};
+  mvd_f32x2 p = {-8.043882189667784e-06f, -8.043882189667784e-06f};
+  p = __builtin_elementwise_fma(p, a, (mvd_f32x2){0.00010602718248264864f, 0.00010602718248264864f});
+  p = __builtin_elementwise_fma(p, a, (mvd_f32x2){-0.0005879526142962277f, -0.0005879526142962277f});
+  p = __builtin_elementwise_fma(p, a, (mvd_f32x2){0.0015767638105899096f, 0.0015767638105899096f});
+  p = __builtin_elementwise_fma(p, a, (mvd_f32x2){-5.878534648218192e-05f, -5.878534648218192e-05f});
+  p = __builtin_elementwise_fma(p, a, (mvd_f32x2){-0.01921714097261429f, -0.01921714097261429f});
+  p = __builtin_elementwise_fma(p, a, (mvd_f32x2){0.10279920697212219f, 0.10279920697212219f});
+  p = __builtin_elementwise_fma(p, a, (mvd_f32x2){0.6366161108016968f, 0.6366161108016968f});
+  p = __builtin_elementwise_fma(p, a, (mvd_f32x2){1.1283793449401855f, 1.1283793449401855f});
+  const mvd_f32x2 arg = p * a * -1.4426950408889634f;
+  const float e0 = __builtin_amdgcn_exp2f(arg.x), e1 = __builtin_amdgcn_exp2f(arg.y);
+  const mvd_f32x2 erf = {copysignf(1.0f - e0, t.x), copysignf(1.0f - e1, t.y)};
+  const mvd_f32x2 r = 0.5f * x * (1.0f + erf);
+  x0 = r.x;
+  x1 = r.y;
+}
+__device__ __forceinline__ void gelu_erf4(float& a, float& b, float& c, float& d) {
+  gelu_erf2(a, b);
+  gelu_erf2(c, d);
+}
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division (~10 instructions: div_scale / rcp / 3 fma / div_fmas /
 // div_fixup): the GroupNorm-apply kernels evaluate it for every element of 55 tensors per step.
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

@@ -281,7 +281,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
-        v.x *= gelu_erf(g.x); v.y *= gelu_erf(g.y); v.z *= gelu_erf(g.z); v.w *= gelu_erf(g.w);
+        gelu_erf4(g.x, g.y, g.z, g.w);        // (packed polynomial: common.hpp)
+        v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
         gv[ps] = v;
       }
     };
@@ -452,7 +453,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         if (HAS_BB) {
           v.x += qb[j].x; v.y += qb[j].y; v.z += qb[j].z; v.w += qb[j].w;
         }
-        if (ACT != MVD_ACT_NONE) {
+        if (ACT == MVD_ACT_GELU) {
+          gelu_erf4(v.x, v.y, v.z, v.w);
+        } else if (ACT != MVD_ACT_NONE) {
           v.x = apply_act(v.x, ACT); v.y = apply_act(v.y, ACT); v.z = apply_act(v.z, ACT); v.w = apply_act(v.w, ACT);
         }
         if (has_cs) {

@@ -611,7 +611,9 @@ __device__ __forceinline__ void pt_epi_store(const GemmParams& p, const PtUnit& 
       if (HAS_BB) {
         x.x += qb[j].x; x.y += qb[j].y; x.z += qb[j].z; x.w += qb[j].w;
       }
-      if (ACT != MVD_ACT_NONE) {
+      if (ACT == MVD_ACT_GELU) {
+        gelu_erf4(x.x, x.y, x.z, x.w);
+      } else if (ACT != MVD_ACT_NONE) {
         x.x = pt_act(x.x, ACT); x.y = pt_act(x.y, ACT); x.z = pt_act(x.z, ACT); x.w = pt_act(x.w, ACT);
       }
       if (has_cs) {
@@ -747,7 +749,8 @@ __device__ __forceinline__ void pt_epi_geglu(const GemmParams& p, const PtUnit& 
     }
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
-    v.x *= gelu_erf(g.x); v.y *= gelu_erf(g.y); v.z *= gelu_erf(g.z); v.w *= gelu_erf(g.w);
+    gelu_erf4(g.x, g.y, g.z, g.w);
+    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
     vv[t] = v;
   }
 #pragma unroll

@@ -446,10 +446,9 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const float4 bb = *(const float4*)(smisc + 16 * j + 4 * g);
-      h[j][0] = gelu_erf(acc[j][0] * sc + bb.x);
-      h[j][1] = gelu_erf(acc[j][1] * sc + bb.y);
-      h[j][2] = gelu_erf(acc[j][2] * sc + bb.z);
-      h[j][3] = gelu_erf(acc[j][3] * sc + bb.w);
+      float t0 = acc[j][0] * sc + bb.x, t1 = acc[j][1] * sc + bb.y, t2 = acc[j][2] * sc + bb.z, t3 = acc[j][3] * sc + bb.w;
+      gelu_erf4(t0, t1, t2, t3);           // (packed polynomial: common.hpp)
+      h[j] = (f32x4){t0, t1, t2, t3};
     }
   }
 
@@ -638,10 +637,9 @@ __global__ __launch_bounds__(256) void g4_fused_kernel(G4Params p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 b4 = *(const float4*)(b1 + 16 * q + 4 * g);
-        f1[q][0] = gelu_erf(f1[q][0] * sc_fc1 + b4.x);
-        f1[q][1] = gelu_erf(f1[q][1] * sc_fc1 + b4.y);
-        f1[q][2] = gelu_erf(f1[q][2] * sc_fc1 + b4.z);
-        f1[q][3] = gelu_erf(f1[q][3] * sc_fc1 + b4.w);
+        float t0 = f1[q][0] * sc_fc1 + b4.x, t1 = f1[q][1] * sc_fc1 + b4.y, t2 = f1[q][2] * sc_fc1 + b4.z, t3 = f1[q][3] * sc_fc1 + b4.w;
+        gelu_erf4(t0, t1, t2, t3);
+        f1[q] = (f32x4){t0, t1, t2, t3};
       }
       slot_16tiles(make_frag(f1[0], f1[1]));
       slot_16tiles(make_frag(f1[2], f1[3]));
