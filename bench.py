@@ -439,7 +439,7 @@ def main():
         for k, b in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
             log(f"[bench] {k:40s} launches {b['n']:4d}  total {b['ms']:8.3f} ms  avg {b['ms'] / b['n'] * 1e3:8.1f} us  "
                 f"{b['flops'] / b['ms'] / 1e9:8.1f} TFLOP/s algorithmic")
-        # The dominant kernel is mvd_gemm's gemm_kernel (one source, csrc/gemm.hip; the template arguments are the
+        # The dominant kernel is mvd_gemm's gemm_kernel (one template, csrc/gemm_plain.hpp; the template arguments are the
         # tile / loop variants the autotuner picks per shape).  Headline = the whole family (every GEMM launch of the
         # step); `variants` lists each instantiation under the symbol rocprofv3 reports, for cross-checking
         # profiles/<round>_bench_n1_kernel_stats.csv.

@@ -144,24 +144,20 @@ typedef struct mvd_gemm_desc {
    *          MVD_EPI_STORE only (the GEGLU / QKV epilogues walk a wave tile in 32-column blocks)
    *   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop (two k-tiles in LDS, MFMA fragments double-buffered in
    *          registers), 2 = staggered (8-wave tiles only: three k-tiles in LDS, the two wavefronts of a SIMD half an
-   *          iteration apart, so one issues LDS-DMA / fragment reads while the other runs MFMAs), 3 = staggered with four
-   *          k-tiles in LDS (128x128 only), 4 = the register-pipelined loop over a ring of up to 4 k-tiles in LDS, 5 = over a
+   *          iteration apart, so one issues LDS-DMA / fragment reads while the other runs MFMAs), 4 = the register-pipelined loop over a ring of up to 4 k-tiles in LDS, 5 = over a
    *          ring of up to 8 (4-wave tiles): one workgroup per CU keeps 3 / 7 k-tiles of operands in flight, for the small grids
    *          of the low-resolution levels whose k-loop is otherwise one DMA round trip per k-tile, 6 = the input-patch kernel for
    *          stride-1 padded 3x3 convolutions (tiles 1, 2, 4): the tile's pixels + halo are staged once per 32-channel block and the
    *          nine taps read shifted slots of that patch (4-6x less A traffic into LDS), 7 = the wave-specialised kernel (tiles 1, 2,
    *          4; tile 1 with every epilogue, 2 and 4 MVD_EPI_STORE): four consumer wavefronts (fragment reads + MFMAs) and four loader wavefronts (all LDS-DMAs) per
-   *          workgroup, 8 = the same kernel with REGISTER-staged operand delivery (the loader wavefronts issue ordinary 16-byte global
-   *          loads, hold NBUF - 2 k-tiles of their share in VGPRs and ds_write_b128 each k-tile into its LDS slot one iteration before it
-   *          is read -- same LDS image and MFMA order as 7: bit-identical), 9 = register-staged delivery in the plain kernel (tiles 0 - 3: every
-   *          wavefront loads its granules two k-tiles ahead with 16-byte global loads and ds_write_b128's them into the other of two LDS
-   *          buffers: ~20 issue cycles per granule instead of ~100 for an LDS-DMA, which bounds the small tiles), 10 = the PERSISTENT role-split
+   *          workgroup, 10 = the PERSISTENT role-split
    *          kernel (tile 1, every epilogue; csrc/gemm_pt.hip): one 16-wave workgroup per CU walks a contiguous run of output tiles -- 8 consumer
-   *          wavefronts (MFMAs), 2 loader wavefronts (all LDS-DMAs of a 4-stage ring, across tile boundaries) and 6 epilogue wavefronts that
+   *          wavefronts (MFMAs), 4 loader wavefronts (all LDS-DMAs of a 4-stage ring, across tile boundaries) and 4 epilogue wavefronts that
    *          take a finished tile from an LDS staging tile while the consumers multiply the next one; counters in LDS instead of barriers.
    *          Outputs bit-identical to the other loops; rs_out then holds one slot per 128 columns (rs_count says so) and the GroupNorm /
    *          row statistics partials are summed in another order; a problem it does not take (K < 64, n_store % 4 != 0) runs loop 0 of tile 1;
-   *          mvd_gemm_cfg_supported() tells whether a cfg serves a problem
+   *          3, 8, 9 = removed (a four-buffer staggered loop and two register-staged operand deliveries, rounds 3 / 4: never the
+   *          fastest on any shape); mvd_gemm rejects them, and mvd_gemm_cfg_supported() tells whether a cfg serves a problem
    *   order: 0 = n-fastest, 1 = m-fastest order of the output tiles over the 8 XCDs.
    * The host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
    * winner from then on (mvdfusion_amd/hip.py: autotune). */

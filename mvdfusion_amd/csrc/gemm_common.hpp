@@ -1,5 +1,6 @@
-// Shared between the GEMM translation units (gemm.hip: tile-per-workgroup kernels, split-K reduces, host entry; gemm_pt.hip: the
-// persistent role-split kernel).
+// Shared between the GEMM translation units: gemm.hip (host entry mvd_gemm, split-K reduces, packing), gemm_plain_t0 ... t4.hip
+// (gemm_kernel per block tile), gemm_ws.hip (role-split kernel), gemm_patch.hip (input-patch convolution), gemm_pt.hip (persistent
+// role-split kernel).
 #pragma once
 #include "common.hpp"
 #include "../../include/mvd_hip.h"
@@ -19,3 +20,13 @@ struct GemmParams {
 bool mvd_gemm_pt_supported(const mvd_gemm_desc& d);
 int mvd_gemm_pt_min_ktiles();
 void mvd_gemm_pt_launch(const GemmParams& p, hipStream_t s);
+
+// Launchers of the tile-per-workgroup kernels, one per translation unit (grid = tiles x splits from GemmParams); false = the unit has no
+// kernel for that tile / loop (include/mvd_hip.h: cfg).
+bool mvd_gemm_launch_plain_t0(int loop, GemmParams& p, hipStream_t s);      // 64 x 64
+bool mvd_gemm_launch_plain_t1(int loop, GemmParams& p, hipStream_t s);      // 128 x 128
+bool mvd_gemm_launch_plain_t2(int loop, GemmParams& p, hipStream_t s);      // 128 x 80
+bool mvd_gemm_launch_plain_t3(int loop, GemmParams& p, hipStream_t s);      // 64 x 80
+bool mvd_gemm_launch_plain_t4(int loop, GemmParams& p, hipStream_t s);      // 128 x 160
+bool mvd_gemm_launch_ws(int tile, GemmParams& p, hipStream_t s);            // gemm_ws_kernel: tiles 1, 2, 4
+bool mvd_gemm_launch_patch(int tile, GemmParams& p, hipStream_t s, int patch_shares);      // conv_patch_kernel: tiles 1, 2, 4

@@ -1,0 +1,12 @@
+// gemm_kernel<128, 128, 2, 4, ...>: the loop variants of block tile 1 (include/mvd_hip.h: cfg), all three precisions, dense and 3x3-convolution A.
+#include "gemm_plain.hpp"
+
+bool mvd_gemm_launch_plain_t1(int loop, GemmParams& p, hipStream_t s) {
+  switch (loop) {
+    case 0: launch_cfg<128, 128, 2, 4, 2>(p, s); return true;
+    case 1: launch_cfg<128, 128, 2, 4, 3>(p, s); return true;
+    case 2: launch_cfg<128, 128, 2, 4, 4>(p, s); return true;
+    case 4: launch_cfg<128, 128, 2, 4, 6>(p, s); return true;
+  }
+  return false;
+}

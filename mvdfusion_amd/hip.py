@@ -294,7 +294,7 @@ def _pack_scale(w, like=None):
     if all(k is not None for k in known):
         mx = max(known)
     if mx is None:
-        mx = float(torch.linalg.vector_norm(w.reshape(-1), ord=float("inf")))      # max|w| in ONE reduction (abs().max() is two kernels and a temporary)
+        mx = float(torch.linalg.vector_norm(w.detach().reshape(-1), ord=float("inf")))      # max|w| in ONE reduction (abs().max() is two kernels and a temporary)
     if not (mx > 0.0) or not math.isfinite(mx):
         return 1.0
     return 2.0 ** (10 - math.floor(math.log2(mx)))
@@ -504,15 +504,15 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
 # mvd_gemm_desc.cfg = 1 + CFG_STRIDE * tile + 2 * loop + order (include/mvd_hip.h: MVD_GEMM_CFG_STRIDE)
 CFG_STRIDE = 32
 GNA_SILU, GNA_ROUND_F16, GNA_OUT_UNUSED = 1, 2, 4      # mvd_gemm_desc.gna_flags
-TUNE_CACHE_VERSION = 9             # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
+TUNE_CACHE_VERSION = 10            # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
-GEMM_LOOPS = (2, 3, 4, 5, 6, 7, "patch", "ws", "ws-reg", 8, "pt")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 / 5 = staggered wave groups
-                                 # (3 / 4 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
-                                 # (stride-1 3x3 convolutions: the input patch is staged once per channel block)
+GEMM_LOOPS = (2, 3, 4, None, 6, 7, "patch", "ws", None, None, "pt")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 = staggered wave
+                                 # groups (3 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
+                                 # (stride-1 3x3 convolutions: the input patch is staged once per channel block); None = loop variants removed in
+                                 # round 5 (never selected by the tuner; the numbering of the others is unchanged -- include/mvd_hip.h: cfg)
+REMOVED_LOOPS = tuple(i for i, l in enumerate(GEMM_LOOPS) if l is None)
 PATCH_LOOP = 6
 WS_LOOP = 7                      # gemm_ws_kernel: consumer / loader wavefront roles (tiles 1, 2, 4; EPI_STORE)
-WSR_LOOP = 8                     # ... with register-staged operand delivery (global_load -> VGPR -> ds_write_b128) instead of LDS-DMA
-REG_LOOP = 9                     # gemm_kernel<..., 8>: register-staged delivery in the plain kernel (tiles 0 - 3)
 PT_LOOP = 10                     # gemm_pt_kernel (csrc/gemm_pt.hip): persistent 16-wave workgroups, consumer / loader / epilogue wavefront roles (tile 1)
 
 
@@ -530,10 +530,9 @@ def _cfg_valid(cfg, epi, b_mode=0):
         return False
     bm, bn, wm, wn = GEMM_TILES[tile]
     waves = wm * wn
-    return (loop not in (2, 3) or waves == 8) and (loop != 3 or tile == 1) and (loop != 5 or waves == 4) and \
+    return loop not in REMOVED_LOOPS and (loop != 2 or waves == 8) and (loop != 5 or waves == 4) and \
         (loop != PATCH_LOOP or tile in (1, 2, 4)) and (tile < 2 or epi == EPI_STORE) and \
-        (loop not in (WS_LOOP, WSR_LOOP) or tile == 1 or (tile in (2, 4) and epi == EPI_STORE)) and (loop != REG_LOOP or tile <= 3) and \
-        (loop != PT_LOOP or tile == 1)
+        (loop != WS_LOOP or tile == 1 or (tile in (2, 4) and epi == EPI_STORE)) and (loop != PT_LOOP or tile == 1)
 
 
 _ALL_CONFIGS = tuple(c for c in range(1, CFG_STRIDE * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
@@ -565,9 +564,9 @@ def kernel_symbol(cfg, prec, conv):
         return f"conv_patch_kernel<{bm}, {bn}, {wm}, {wn}, {prec}>"
     if loop == PT_LOOP:
         return f"gemm_pt_kernel<{prec}, {1 if conv else 0}>"
-    if loop in (WS_LOOP, WSR_LOOP):
+    if loop == WS_LOOP:
         cm, cn = {1: (2, 2), 2: (4, 1), 4: (2, 2)}[tile]
-        return f"gemm_ws_kernel<{bm}, {bn}, {cm}, {cn}, {prec}, {1 if conv else 0}, {1 if loop == WSR_LOOP else 0}>"
+        return f"gemm_ws_kernel<{bm}, {bn}, {cm}, {cn}, {prec}, {1 if conv else 0}>"
     return f"gemm_kernel<{bm}, {bn}, {wm}, {wn}, {prec}, {1 if conv else 0}, {GEMM_LOOPS[loop]}>"
 
 
@@ -592,7 +591,8 @@ def load_tuned(path):
     n = 0
     for k, v in doc["entries"]:
         cfg = int(v[0])
-        if cfg != 0 and not (1 <= cfg <= CFG_STRIDE * len(GEMM_TILES) and _cfg_parts(cfg)[1] < len(GEMM_LOOPS)):
+        if cfg != 0 and not (1 <= cfg <= CFG_STRIDE * len(GEMM_TILES) and _cfg_parts(cfg)[1] < len(GEMM_LOOPS) and
+                             _cfg_parts(cfg)[1] not in REMOVED_LOOPS):
             continue
         _TUNED[tuple(k)] = tuple(v)
         n += 1
@@ -651,7 +651,7 @@ def _autotune(d, A=None, reps=4, trials=3, W_data=None):
     # they stay built, tested (test_gemm_configurations_agree) and selectable by cfg.  MVD_TUNE_EXCLUDE_LOOPS: A/B measurements.
     # ... and the persistent role-split kernel of round 5 (loop 10, csrc/gemm_pt.hip): correct on every epilogue, but its k-loop runs at
     # ~1 100 cycles per 128x128 k-tile against ~764 for two co-resident workgroups of the plain kernel (profiles/r05_pt_*.log).
-    skip = {WSR_LOOP, REG_LOOP, PT_LOOP} - {int(t) for t in os.environ.get("MVD_TUNE_INCLUDE_LOOPS", "").split(",") if t}
+    skip = {PT_LOOP} - {int(t) for t in os.environ.get("MVD_TUNE_INCLUDE_LOOPS", "").split(",") if t}
     skip |= {int(t) for t in os.environ.get("MVD_TUNE_EXCLUDE_LOOPS", "").split(",") if t}      # (e.g. "7" = no role-split kernel)
     cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode, conv=d.a_mode == A_CONV3X3) if cfg_supported(d, c) and _cfg_parts(c)[1] not in skip
              for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]

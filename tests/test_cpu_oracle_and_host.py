@@ -365,6 +365,9 @@ def test_precision_policy_parsing():
         hip.parse_precision("f16x4:nonsense=3")
     with pytest.raises(ValueError):
         hip.parse_precision("f16x4:conv=2")
+    for bad in ("fp16x3", "f16x2", "f32", "bf16x", "x3", "f16x3x3", ""):          # a mistyped BASE name must not become "f16, 1 product"
+        with pytest.raises(ValueError):
+            hip.parse_precision(bad)
     from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
     m = ViewFusion(**model_config(32, precision="f16x4:conv=3"))
     assert m.precision == 4 and m.precision_policy == {"conv": 3}
@@ -395,6 +398,11 @@ def test_param_maxima_registry_replaces_per_pack_synchronisation():
                                like=[lin.weight, conv.weight]) == want(lin.weight)
         assert hip._pack_scale(big, like=[lin.weight, big]) == want(big)                   # one unknown source: reduce the tensor itself
         assert hip._known_max(lin.weight.detach()[:10]) is None                            # same address, other size
+        before = hip._known_max(conv.weight.detach())                                      # an in-place update (an optimizer
+        with torch.no_grad():                                                              # step) bumps the tensor version: the cached maximum
+            conv.weight.mul_(64.0)                                                         # no longer answers, the tensor itself is reduced
+        assert before is not None and hip._known_max(conv.weight.detach()) is None
+        assert hip._pack_scale(conv.weight) == want(conv.weight)
         ptr = lin.weight.data_ptr()
         del lin
         gc.collect()
@@ -416,31 +424,45 @@ def test_fused_gridattn_serves_every_shipped_view_count():
 
 
 def test_hot_kernels_compile_without_scratch_spills(tmp_path):
-    """The attention kernel (up to 304 unified VGPRs per instantiation), the fused GridAttn kernel (357 - 361) and the reduce-and-normalise
-    kernels hold their working sets in registers: a private (scratch) segment would mean spills in the k-loop.  hipcc cross-compiles the
-    device code to assembly without a GPU (seconds per file; ADVICE r03: keep the resource check in the test suite); the kernel descriptors
-    carry `.amdhsa_private_segment_fixed_size` and `.amdhsa_next_free_vgpr`.  (gemm.hip takes minutes to compile and is checked by hand:
-    DESIGN.md section 0, ADVICE row -- its only scratch users are the register-staged 128x128 instantiations the tuner never selects.)"""
+    """Every GEMM instantiation the tuner can select (gemm_kernel per block tile, gemm_ws_kernel, conv_patch_kernel: 156 kernels), the split-K
+    reduce kernels, the attention kernel (up to 304 unified VGPRs per instantiation), the fused GridAttn kernel (357 - 361) and the
+    reduce-and-normalise kernels hold their working sets in registers: a private (scratch) segment would mean spills in the k-loop.  hipcc
+    cross-compiles the device code to assembly without a GPU (the GEMM family is one translation unit per kernel family since round 5,
+    ~20 s each, compiled in parallel here); the kernel descriptors carry `.amdhsa_private_segment_fixed_size` and
+    `.amdhsa_next_free_vgpr`.  gemm_pt_kernel (cfg loop 10, NOT a tuner candidate: hip.py autotune) is allowed the 96 bytes its epilogue
+    wavefronts spill outside the k-loop, and no more."""
     import shutil
     import subprocess
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not (os.path.exists(hipcc) or shutil.which(hipcc)):
         pytest.skip("no hipcc")
-    seen = 0
-    for src, budget in (("attention.hip", 512), ("gridattn_fused.hip", 512), ("elementwise.hip", 128)):
+    plan = [("gemm_plain_t%d.hip" % t, 512, 0) for t in range(5)] + [
+        ("gemm_ws.hip", 512, 0), ("gemm_patch.hip", 512, 0), ("gemm.hip", 128, 0), ("gemm_pt.hip", 128, 96),
+        ("attention.hip", 512, 0), ("gridattn_fused.hip", 512, 0), ("elementwise.hip", 128, 0)]
+
+    def compile_one(item):
+        src = item[0]
         out = tmp_path / (src + ".s")
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
                             os.path.join(ROOT, "mvdfusion_amd", "csrc", src), "-o", str(out)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
-        asm = out.read_text()
+        return out.read_text()
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        asms = list(ex.map(compile_one, plan))
+    seen, gemm_seen = 0, 0
+    for (src, budget, scratch_max), asm in zip(plan, asms):
         for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm, re.S):
             name, body = m.group(1), m.group(2)
             scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
             vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
-            assert scratch == 0, (src, name, scratch)
+            assert scratch <= scratch_max, (src, name, scratch)
             assert vgpr <= budget, (src, name, vgpr)
             seen += 1
-    assert seen >= 40
+            gemm_seen += src.startswith(("gemm_plain", "gemm_ws", "gemm_patch"))
+    assert gemm_seen == 5 * 24 + 18 + 18, gemm_seen          # 5 tiles x 4 loops x 3 precisions x {dense, conv}; 3 tiles x 6; 3 tiles x 3 x 2 shares
+    assert seen >= 200
 
 
 def test_product_fails_loudly_without_gpu():
@@ -611,6 +633,63 @@ def test_view_range_partition():
             rs = [view_range(V, r, world) for r in range(world)]
             assert sum(n for _, n in rs) == V
             assert all(rs[i][0] + rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+
+
+def test_gemm_configuration_table_and_tuner_cache(tmp_path):
+    """hip.GEMM_CONFIGS mirrors the library's cfg encoding (include/mvd_hip.h): loops 3, 8, 9 were removed in round 5 and are not valid
+    for any tile (the library rejects them: tests/test_gpu_ops.py), the persistent kernel (loop 10) exists for the 128 x 128 tile only, and
+    a tuner cache written before the removal cannot smuggle a removed configuration back in."""
+    import json
+    from mvdfusion_amd import hip
+    assert hip.REMOVED_LOOPS == (3, 8, 9)
+    parts = [hip._cfg_parts(c) for c in hip.GEMM_CONFIGS_CONV]
+    assert not [p for p in parts if p[1] in hip.REMOVED_LOOPS]
+    assert {p[0] for p in parts if p[1] == hip.PT_LOOP} == {1}
+    assert {p[0] for p in parts if p[1] == hip.WS_LOOP} == {1, 2, 4} and {p[0] for p in parts if p[1] == hip.PATCH_LOOP} == {1, 2, 4}
+    assert len(hip.GEMM_CONFIGS_CONV) == 2 * (5 * 4 + 3 + 3 + 1)            # two tile orders x (4 loops per tile + ws + patch + pt)
+    assert all(c in hip.gemm_configs(hip.EPI_STORE) for c in hip.gemm_configs(hip.EPI_GEGLU))
+    assert {hip._cfg_parts(c)[0] for c in hip.gemm_configs(hip.EPI_GEGLU)} == {0, 1}      # the 80-column family serves EPI_STORE only
+    assert hip.kernel_symbol(hip.make_cfg(2, hip.WS_LOOP), 3, True) == "gemm_ws_kernel<128, 80, 4, 1, 3, 1>"
+    assert hip.kernel_symbol(hip.make_cfg(0, 5), 3, False) == "gemm_kernel<64, 64, 2, 2, 3, 0, 7>"
+    assert hip.kernel_symbol(hip.make_cfg(1, hip.PT_LOOP), 4, False) == "gemm_pt_kernel<4, 0>"
+    path = tmp_path / "tuned.json"
+    good, removed = hip.make_cfg(1, 4), hip.make_cfg(1, 8)
+    doc = {"version": hip.TUNE_CACHE_VERSION, "cfg_stride": hip.CFG_STRIDE, "operand_format": hip.OPERAND_FORMAT,
+           "entries": [[[1, 2, 3], [good, 1]], [[4, 5, 6], [removed, 1]], [[7, 8, 9], [0, 2]]]}
+    saved = dict(hip._TUNED)
+    try:
+        hip._TUNED.clear()
+        path.write_text(json.dumps(doc))
+        assert hip.load_tuned(str(path)) == 2 and (4, 5, 6) not in hip._TUNED
+        doc["version"] = hip.TUNE_CACHE_VERSION - 1                              # a cache of the previous encoding: rejected as a whole
+        path.write_text(json.dumps(doc))
+        hip._TUNED.clear()
+        assert hip.load_tuned(str(path)) == 0 and not hip._TUNED
+    finally:
+        hip._TUNED.clear()
+        hip._TUNED.update(saved)
+
+
+def test_bench_tree_fingerprint_tracks_kernel_sources(tmp_path, monkeypatch):
+    """bench.tree_fingerprint() stamps every number that is read back from profiles/ (VERDICT r04 item 7): it must change when a kernel
+    source changes and only then."""
+    import importlib
+    bench = importlib.import_module("bench")
+    a = bench.tree_fingerprint()
+    assert re.fullmatch(r"[0-9a-f]{16}", a) and bench.tree_fingerprint() == a
+    src = os.path.join(ROOT, "mvdfusion_amd", "csrc", "norm.hip")
+    text = open(src).read()
+    real_open = open
+
+    def fake_open(path, *args, **kw):
+        f = real_open(path, *args, **kw)
+        if os.path.abspath(str(path)) == os.path.abspath(src) and ("b" in (args[0] if args else kw.get("mode", "r"))):
+            import io
+            f.close()
+            return io.BytesIO(text.encode() + b"\n// edited\n")
+        return f
+    monkeypatch.setattr("builtins.open", fake_open)
+    assert bench.tree_fingerprint() != a
 
 
 # ------------------------------------------------------------------------------------------------ C ABI

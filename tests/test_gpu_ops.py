@@ -56,6 +56,10 @@ def test_gemm_dense(hip, prec, M, N, K):
         out.zero_()
         hip.gemm(Ap, Wp, out, prec=prec, res=Rc, workspace=ws, splitk=1, cfg=cfg)
         assert rel_err(out, ref) < TOL[prec], cfg
+    # loop variants removed in round 5 (include/mvd_hip.h: cfg) fail loudly instead of running some other kernel
+    for loop in hip.REMOVED_LOOPS:
+        with pytest.raises(RuntimeError, match="does not serve"):
+            hip.gemm(Ap, Wp, out, prec=prec, res=Rc, workspace=ws, splitk=1, cfg=hip.make_cfg(1, loop))
     # plane output (feeds the next GEMM)
     if N % 32 == 0:
         op = hip.planes_like(M, N, "cuda")

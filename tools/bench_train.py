@@ -24,7 +24,13 @@ def main():
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--frozen-unet", action="store_true", help="finetune_unet: false (only the cross-attention / view-aligned parameters train); "
                     "default = configs/mvd_train.yaml:15 finetune_unet: true (all 1 039 M parameters)")
+    ap.add_argument("--tuned", default=None, help="tuner cache file (hip.save_tuned / load_tuned): loaded when present, written after the first step -- "
+                    "a profiling pass of the same command then launches the same kernels without timing candidates")
+    ap.add_argument("--cprofile", default=None, help="write a cProfile summary of the steady steps (host side) to this file")
     a = ap.parse_args()
+    from mvdfusion_amd import hip
+    if a.tuned and os.path.exists(a.tuned):
+        hip.load_tuned(a.tuned)
     from mvdfusion_amd.configs import model_config
     from mvdfusion_amd import synthetic as syn
     from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
@@ -44,8 +50,15 @@ def main():
     opt = m.configure_optimizers(lr=1e-5)
     n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
     times, losses = [], []
+    prof = None
+    mark = torch.zeros(1, dtype=torch.int32, device="cuda")      # step delimiter in a kernel trace (tools/trace_summary.py: advance_iter_kernel)
     for i in range(a.steps + 1):
+        hip.check(hip.lib().mvd_advance_iter(hip.ptr(mark), hip.stream()))
         torch.cuda.synchronize()
+        if a.cprofile and i == 1:
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t0 = time.perf_counter()
         loss = m(batch, {})
         opt.zero_grad()
@@ -54,6 +67,19 @@ def main():
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
         losses.append(float(loss.detach()))
+        if i == 0 and a.tuned:
+            hip.save_tuned(a.tuned)
+    hip.check(hip.lib().mvd_advance_iter(hip.ptr(mark), hip.stream()))
+    torch.cuda.synchronize()
+    if prof is not None:
+        import io
+        import pstats
+        prof.disable()
+        buf = io.StringIO()
+        st = pstats.Stats(prof, stream=buf)
+        st.sort_stats("cumulative").print_stats(60)
+        st.sort_stats("tottime").print_stats(45)
+        open(a.cprofile, "w").write(f"# {a.steps} steady steps of tools/bench_train.py --views {a.views} --depth-samples {a.depth_samples}\n" + buf.getvalue())
     dt = sum(times[1:]) / a.steps
     # algorithmic work of one step (SURVEY.md section 8(d), 2 FLOP per MAC): forward = V UNet passes (cfg 1: no null twin) + GridAttn; the
     # backward is a dgrad and a wgrad per contraction (2 x forward) and re-runs every block's forward once (activation checkpointing at block

@@ -24,6 +24,8 @@ def main():
         return
     n_last = segs[-1][1] - segs[-1][0]
     steady = [s for s in segs if s[1] - s[0] == n_last][-20:]
+    if os.environ.get("TRACE_LAST_STEPS"):          # eager workloads (tools/bench_train.py): the launch count may differ by step
+        steady = segs[-int(os.environ["TRACE_LAST_STEPS"]):]
     by, busy, span = {}, 0.0, 0.0
     for a, b in steady:
         seg = ev[a:b]
@@ -38,7 +40,7 @@ def main():
           f"idle between kernels {(span - busy) / n / 1e3:.1f} us/step ({(span - busy) / n / n_last:.0f} ns per launch)")
     out = {"steps": n, "launches_per_step": n_last, "span_us_per_step": span / n / 1e3, "busy_us_per_step": busy / n / 1e3, "kernels": {}}
     for k, (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-        print(f"  {k[:70]:70s} x{c / n:6.1f}  {t / n / 1e3:9.1f} us/step  avg {t / c / 1e3:7.2f} us  {100 * t / busy:5.1f}%")
+        print(f"  {k[:110]:110s} x{c / n:6.1f}  {t / n / 1e3:9.1f} us/step  avg {t / c / 1e3:7.2f} us  {100 * t / busy:5.1f}%")
         out["kernels"][k] = {"launches_per_step": c / n, "us_per_step": t / n / 1e3, "avg_us": t / c / 1e3}
     if len(sys.argv) > 2:
         json.dump(out, open(sys.argv[2], "w"), indent=1)
