@@ -216,6 +216,10 @@ def profile_kernel_groups(m, eng, cfg_scale):
     except Exception as e:       # the figure is optional: never fail the bench line for it
         log(f"[bench] family graph replay skipped: {e}")
     by = {}
+    if os.environ.get("MVD_BENCH_DUMP_GEMMS"):          # diagnosis: one line per mvd_gemm launch of the eager profile pass
+        with open(os.environ["MVD_BENCH_DUMP_GEMMS"], "w") as f:
+            for i, r in enumerate(recs):
+                f.write(f"{i} {r['sym']} M={r['M']} N={r['N']} K={r['K']} {r['ev'][0].elapsed_ms(r['ev'][1]) * 1e3:.1f}\n")
     for r in recs:
         ms = r["ev"][0].elapsed_ms(r["ev"][1])
         b = by.setdefault(r["sym"], dict(n=0, ms=0.0, flops=0.0, bytes=0.0, mfma_flops=0.0))

@@ -25,9 +25,8 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    common = [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "gridattn_common.hpp"), os.path.join(HERE, "gemm_common.hpp"), os.path.join(HERE, "gemm_device.hpp"),
-              os.path.join(HERE, "gemm_plain.hpp"),
-              os.path.join(HERE, "..", "..", "include", "mvd_hip.h")]
+    common = [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "gridattn_common.hpp"), os.path.join(HERE, "..", "..", "include", "mvd_hip.h")]
+    gemm_hdrs = [os.path.join(HERE, h) for h in ("gemm_common.hpp", "gemm_device.hpp", "gemm_plain.hpp")]      # (the GEMM units only)
     flavours = [("", [], LIB), ("_bf16", ["-DMVD_OPERAND_BF16"], LIB_BF16)]
     jobs, links = [], []
     for suffix, defs, lib in flavours:
@@ -36,7 +35,7 @@ def build(force=False, verbose=True):
             s_ = os.path.join(HERE, src)
             o = os.path.join(HERE, src.replace(".hip", suffix + ".o"))
             objs.append(o)
-            if force or _stale(o, [s_] + common):
+            if force or _stale(o, [s_] + common + (gemm_hdrs if src.startswith("gemm") else [])):
                 jobs.append([hipcc] + FLAGS + defs + ["-c", s_, "-o", o])
         links.append((lib, objs))
 

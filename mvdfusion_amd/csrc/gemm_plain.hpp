@@ -40,8 +40,14 @@
 
 namespace {
 
+// Second launch bound = wavefronts per SIMD the register allocation must leave room for.  The plain two-buffer loop of the 8-wave tiles
+// (128x128, dense A: the GEGLU / QKV projections) lives on TWO co-resident workgroups per CU (4 wavefronts per SIMD: <= 128 VGPRs) hiding each
+// other's barriers and DMA waits -- at 129
+// registers (round 5, after an epilogue edit) it silently dropped to one and every GEGLU / QKV projection lost 10 us; the register-pipelined
+// loop of the 64x80 tile wants three workgroups (<= 168).  tests/test_cpu_oracle_and_host.py checks the tiers from the kernel descriptors.
 template <int BM, int BN, int WM, int WN, int NS, int AMODE, int STAGES>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && STAGES == 2 && AMODE == MVD_A_DENSE) ? 4 : ((BM == 64 && BN == 80 && STAGES == 3) ? 3 : 1))
+void gemm_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
