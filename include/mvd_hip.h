@@ -91,6 +91,14 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, floa
 #define MVD_B_PACKED 0   /* B: weight image of mvd_pack_linear_weight / mvd_pack_conv3x3_weight */
 #define MVD_B_PLANES 1   /* B: (N, ldb) row-major split planes (an activation), N % 16 == 0 */
 
+/* one weight (or any read-only operand) a prefetcher should pull towards the chip: mvd_gemm_desc.pf_items, mvd_weight_prefetch */
+typedef struct mvd_prefetch_item_s {
+  const void* ptr;
+  unsigned long long bytes;
+  int start_after;      /* mvd_weight_prefetch only */
+  int consumer;         /* mvd_weight_prefetch only */
+} mvd_prefetch_item;
+
 typedef struct mvd_gemm_desc {
   int M, N, K;      /* logical sizes; N % 16 == 0 after padding of the packed weight, K as packed (multiple of 32) */
   /* A operand: activations in the SPLIT-PLANES format, produced by the previous kernel (mvd_groupnorm_nhwc,
@@ -211,6 +219,15 @@ typedef struct mvd_gemm_desc {
   const float* cat_b;
   int cat_cb;
   void* cat_raw_sp;
+  /* Launch-order progress counter for mvd_weight_prefetch (below): when non-NULL the GEMM kernel adds 1 to *progress as its first
+   * instruction (one device-scope atomic by one thread), so that a concurrently running prefetch kernel knows how far the step's GEMM
+   * sequence has come.  NULL = off. */
+  int* progress;
+  /* In-kernel weight prefetch (gemm_ws_kernel only, cfg loop 7; ignored by the other kernels): pf_n entries of a device table of weights
+   * that LATER launches of the step will read (mvd_prefetch_item: ptr, bytes; the other fields unused).  The launch's consumer wavefronts
+   * request every 128-byte line of them once at kernel start and drop the data: see mvd_weight_prefetch below for the why.  NULL = off. */
+  const struct mvd_prefetch_item_s* pf_items;
+  int pf_n;
 } mvd_gemm_desc;
 #define MVD_GNA_SILU 1
 #define MVD_GNA_ROUND_F16 2
@@ -220,6 +237,16 @@ int mvd_gemm(const mvd_gemm_desc* d, mvd_stream_t stream);
 /* 1 if kernel configuration `cfg` (see mvd_gemm_desc.cfg) serves the problem `d` describes (tile family vs epilogue, loop variant vs
  * tile, the input-patch kernel vs the convolution's geometry), else 0.  The host autotuner enumerates with it. */
 int mvd_gemm_cfg_supported(const mvd_gemm_desc* d, int cfg);
+
+/* Weight prefetch for a graph-replayed step.  A denoising step streams its whole weight set (3.4 GB of packed operands at model_channels
+ * 320) through a 256 MB Infinity Cache once per step, so every GEMM meets its weights cold and its short k-loop is a chain of HBM round
+ * trips (measured: 2 - 7 us per launch of the small and medium GEMMs, profiles/r05_prefetch_probe_whole_weight.log).  mvd_weight_prefetch
+ * enqueues ONE long-running kernel of `blocks` small workgroups that walks `items` (device array, launch order of the step's GEMMs):
+ * item j is read once -- bytes [0, bytes) of ptr, results discarded -- as soon as *progress >= start_after (the GEMM `start_after` launches
+ * before its consumer has started; mvd_gemm_desc.progress), and skipped when its consumer has already started (*progress > consumer).
+ * Run it on a second stream (a parallel branch of the captured graph) next to the step; it never writes anything but its own exit, and
+ * gives up after `spin_limit` polls without progress (so a step that launches fewer GEMMs than the table lists cannot hang it). */
+int mvd_weight_prefetch(const mvd_prefetch_item* items, int n_items, const int* progress, int blocks, int spin_limit, mvd_stream_t stream);
 
 /* fp32 (rows, cols) matrix with leading dim ldx -> split planes (rows, ldp), ldp % 32 == 0; columns [cols, ldp) are 0.
  * Used where a GEMM consumes a tensor that only exists in fp32 (residual stream into the 1x1 skip / up / down convs). */

@@ -37,7 +37,7 @@ extern "C" int mvd_graph_end(mvd_stream_t stream, void** graph_exec) {
   MVD_HIP(hipStreamEndCapture((hipStream_t)stream, &graph), "hipStreamEndCapture");
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (e != hipSuccess) {
     mvd_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
     return -3;

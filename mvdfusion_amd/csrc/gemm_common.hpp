@@ -15,6 +15,12 @@ struct GemmParams {
   int m_fastest;
 };
 
+// mvd_gemm_desc.progress: "this GEMM has started" for the weight prefetcher (prefetch.hip) -- one device-scope atomic by one thread of the launch.
+__device__ __forceinline__ void gemm_note_progress(const mvd_gemm_desc& d) {
+  if (d.progress != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    __hip_atomic_fetch_add(d.progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // gemm_pt.hip: persistent 128x128 kernel (mvd_gemm_desc.cfg loop 10).  pt_supported: whether it serves the problem; pt_launch enqueues it
 // (the split-K reduce / GroupNorm kernels that may follow stay with mvd_gemm).
 bool mvd_gemm_pt_supported(const mvd_gemm_desc& d);

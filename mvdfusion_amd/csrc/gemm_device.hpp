@@ -565,6 +565,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 }
 
 // ------------------------------------------------------------------------------------------------ main kernel
+// (consumer wavefronts of gemm_ws_kernel: they own no DMA; their prefetch requests must not be waited for)
+__device__ __forceinline__ void wait_lgkm_and_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int N>
 __device__ __forceinline__ void wait_vm_and_barrier() {
   // Counted wait on this wave's own DMA queue plus a full wait on its LDS reads, then the workgroup barrier, as ONE asm

@@ -938,6 +938,7 @@ __device__ __forceinline__ void pt_epilogue(const GemmParams& p, unsigned char* 
 // ============================================================================================== kernel
 template <int NS, int AMODE>
 __global__ __launch_bounds__(PT_THREADS) void gemm_pt_kernel(GemmParams p) {
+  gemm_note_progress(p.d);
   __shared__ __attribute__((aligned(1024))) unsigned char smem[PT_SMEM];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
   const int tid = threadIdx.x, lane = tid & 63;

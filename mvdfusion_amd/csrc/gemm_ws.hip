@@ -15,6 +15,7 @@ namespace {
 //                        t+2 (the NBUF-2 newer stages stay in flight); consumers read the fragments of k-tile t+1 and run the MFMAs of t.
 template <int BM, int BN, int CM, int CN, int NS, int AMODE>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
+  gemm_note_progress(p.d);
   constexpr int NC = CM * CN, NL = 4;
   static_assert(NC == 4, "four consumer wavefronts (one per SIMD) + four loader wavefronts");
   constexpr int WTM = BM / CM, WTN = BN / CN;
@@ -237,14 +238,33 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
       for (int j = 0; j < TN; ++j) acc[i][j] = MVD_MFMA_16x16x32(ah[i], bh[j], acc[i][j], 0, 0, 0);
   };
   op16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+  // ---- weight prefetch for the launches that FOLLOW (mvd_gemm_desc.pf_items): the consumer wavefronts have no memory instruction of their own
+  //      until the epilogue, and a convolution runs for 30 - 170 us with the HBM mostly idle: each consumer wave requests its share of the
+  //      listed weights' 128-byte lines (one dword per line and lane; the data is dropped) so that they sit in the Infinity Cache when their
+  //      GEMMs start.  The loads return into ONE register that stays reserved until the k-loop is over; nothing in the consumer's k-loop
+  //      waits for vmcnt (barriers below: lgkmcnt only), so the requests cost their issue slots and nothing else.
+  unsigned pf_sink = 0;
+  if (d.pf_items != nullptr) {
+    const int gw = (blockIdx.z * gridDim.x + blockIdx.x) * NC + wave, GW = gridDim.x * gridDim.z * NC;
+    // (the table is read with SCALAR loads -- constant address space -- so that no vector-memory wait sits between two items' requests)
+    const __attribute__((address_space(4))) mvd_prefetch_item* tab = (const __attribute__((address_space(4))) mvd_prefetch_item*)d.pf_items;
+    for (int it = 0; it < d.pf_n; ++it) {
+      const unsigned char* base = (const unsigned char*)tab[it].ptr;
+      const long lines = (long)((tab[it].bytes + 127) >> 7);
+      for (long l = (long)gw * 64 + lane; l < lines; l += (long)GW * 64) {
+        const unsigned char* a = base + (l << 7);
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(a) : "memory");
+      }
+    }
+  }
   MVD_STAMP_AT(d, wave, 1);
-  wait_vm_and_barrier<0>();                                           // barrier P
+  wait_lgkm_and_barrier();                                            // barrier P
   MVD_STAMP_AT(d, wave, 2);
   read_frags(0, fah[0], fal[0], fbh[0], fbl[0]);
   int br = 1 % NBUF;
   auto step = [&](auto parity, int it) {
     constexpr int Pq = decltype(parity)::value;
-    wait_vm_and_barrier<0>();                                         // B_it: my reads of k-tile it returned; k-tile it+1 landed
+    wait_lgkm_and_barrier();                                          // B_it: my reads of k-tile it returned; k-tile it+1 landed
     if (it + 1 < nkt) read_frags(br, fah[Pq ^ 1], fal[Pq ^ 1], fbh[Pq ^ 1], fbl[Pq ^ 1]);
     mfma_tile(fah[Pq], fal[Pq], fbh[Pq], fbl[Pq]);
     {
@@ -268,6 +288,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
   if (it < nkt) step(integral_constant<int, 0>{}, it);
   if (it + 1 < nkt) step(integral_constant<int, 1>{}, it + 1);
   MVD_STAMP_AT(d, wave, 3);
+  asm volatile("" ::"v"(pf_sink));      // (the prefetch requests' landing register was reserved up to here; vmcnt: the epilogue's own waits cover them)
   __syncthreads();
   tile_epilogue<BM, BN, CM, CN>(p, acc, smem, m0, n0, lane, wave, AMODE == MVD_A_DENSE && d.ln_stats != nullptr ? s_rows : nullptr);
   MVD_STAMP_AT(d, wave, 8);

@@ -68,7 +68,13 @@ class GemmDesc(C.Structure):
         ("ln_stats", _vp), ("ln_count", _vp), ("ln_colsum", _vp), ("ln_ld", _i), ("ln_dim", _i), ("ln_eps", _f),
         ("gna_out_sp", _vp), ("gna_gamma", _vp), ("gna_beta", _vp), ("gna_eps", _f), ("gna_flags", _i),
         ("cat_b", _vp), ("cat_cb", _i), ("cat_raw_sp", _vp),
+        ("progress", _vp), ("pf_items", _vp), ("pf_n", _i),
     ]
+
+
+class PrefetchItem(C.Structure):
+    """ctypes mirror of mvd_prefetch_item (include/mvd_hip.h)."""
+    _fields_ = [("ptr", _vp), ("bytes", C.c_ulonglong), ("start_after", _i), ("consumer", _i)]
 
 
 # name -> (restype, argtypes): every symbol declared in include/mvd_hip.h
@@ -109,6 +115,7 @@ SIGNATURES = {
     "mvd_groupnorm_from_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_fill_zero": (_i, [_vp, _sz, _vp]),
+    "mvd_weight_prefetch": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "mvd_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "mvd_advance_iter": (_i, [_vp, _vp]),
     "mvd_zembed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -497,8 +504,112 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     d.cfg = cfg or 0
     global LAST_CFG
     LAST_CFG = d.cfg
+    if GEMM_SEQUENCE is not None:            # a step engine follows its GEMM launches (weight prefetch, see WeightPrefetcher)
+        GEMM_SEQUENCE.note(d, W)
     check(lib().mvd_gemm(C.byref(d), stream()))
     return out
+
+
+GEMM_SEQUENCE = None      # set by a step engine around ITS launches (WeightPrefetcher.following())
+
+
+class WeightPrefetcher:
+    """Host side of the weight prefetch of ONE graph-captured step (include/mvd_hip.h: mvd_gemm_desc.pf_items / mvd_weight_prefetch).  While
+    `following(record=True)` is active (a second eager pass behind the tuned warm-up step) every hip.gemm launch appends its packed weight
+    and kernel kind to the launch-order list; `following()` during capture then hands every launch its share:
+      mode "ws"     -- in-kernel: every role-split launch (gemm_ws_kernel, the long convolutions: idle consumer wavefronts, idle HBM) requests
+                       the weights of the launches that follow it, up to and including the next role-split launch and `window` bytes
+                       (24 MB: the sweep of profiles/r05_prefetch_ab.log -- 4 ... 32 MB all gain 1.2 - 1.8 % of the step, 64 MB less, 128 MB
+                       loses: the big low-resolution weights push the step's activations out of the Infinity Cache);
+      mode "branch" -- one long-running kernel on a parallel graph branch (mvd_weight_prefetch) paced by a device launch counter the GEMMs
+                       bump (mvd_gemm_desc.progress).  Measured 12 % SLOWER than no prefetch: kept for the record.
+    """
+
+    def __init__(self, progress, mode="ws", window=24 << 20, lead=6, blocks=32, spin_limit=30000, max_items=24):
+        self.progress = progress          # int32 device counter, zeroed by the engine at the start of every step (engine.Ctx.begin_step)
+        self.mode = mode
+        self.window, self.lead, self.blocks, self.spin_limit, self.max_items = int(window), int(lead), int(blocks), int(spin_limit), int(max_items)
+        self.seq, self.recording, self.table, self.n, self.launch_idx, self.shares = [], False, None, 0, 0, {}
+
+    class _Following:
+        def __init__(self, pf, record):
+            self.pf, self.record = pf, record
+
+        def __enter__(self):
+            global GEMM_SEQUENCE
+            self.prev, GEMM_SEQUENCE = GEMM_SEQUENCE, self.pf
+            self.pf.recording = self.record
+            self.pf.launch_idx = 0
+            if self.record:
+                self.pf.seq = []
+            return self.pf
+
+        def __exit__(self, *exc):
+            global GEMM_SEQUENCE
+            GEMM_SEQUENCE = self.prev
+            if self.record and exc[0] is None:
+                self.pf._build()
+            self.pf.recording = False
+            return False
+
+    def following(self, record=False):
+        return WeightPrefetcher._Following(self, record)
+
+    def note(self, d, W):
+        """Called by hip.gemm right before the launch (d.cfg is final)."""
+        j = self.launch_idx
+        self.launch_idx += 1
+        is_ws = bool(d.cfg) and _cfg_parts(d.cfg)[1] == WS_LOOP
+        if self.recording:
+            packed = not isinstance(W, PlanesOperand)
+            self.seq.append((W.data.data_ptr(), W.data.numel() * W.data.element_size(), is_ws) if packed else (0, 0, is_ws))
+            return
+        if self.mode == "branch":
+            d.progress = self.progress.data_ptr()
+        elif is_ws and j in self.shares:
+            first, n = self.shares[j]
+            d.pf_items, d.pf_n = self.table.data_ptr() + first * C.sizeof(PrefetchItem), n
+
+    def _build(self):
+        items = []
+        self.shares = {}
+        if self.mode == "branch":
+            # item j = the weight of the j-th launch: requested when launch start_after has begun -- as early as `lead` launches ahead, as
+            # long as the weights requested but not yet consumed stay inside `window` bytes (progress = launches that have started)
+            for j, (ptr_, nbytes, _) in enumerate(self.seq):
+                if not nbytes:
+                    continue
+                d, acc = 1, nbytes
+                while d < self.lead and j - d >= 0 and acc + self.seq[j - d][1] <= self.window:
+                    acc += self.seq[j - d][1]
+                    d += 1
+                items.append((ptr_, nbytes, max(j - d + 1, 0), j))
+        else:
+            # role-split launch j takes the weights of launches j + 1 .. (next role-split launch), first come first served inside `window`
+            hosts = [j for j, e in enumerate(self.seq) if e[2]]
+            for h, j in enumerate(hosts):
+                end = hosts[h + 1] if h + 1 < len(hosts) else len(self.seq) - 1
+                first, acc, seen = len(items), 0, set()
+                for k in range(j + 1, end + 1):
+                    ptr_, nbytes, _ = self.seq[k]
+                    if not nbytes or ptr_ in seen or acc + nbytes > self.window or len(items) - first >= self.max_items:
+                        continue
+                    seen.add(ptr_)
+                    acc += nbytes
+                    items.append((ptr_, nbytes, j, k))
+                if len(items) > first:
+                    self.shares[j] = (first, len(items) - first)
+        self.n = len(items)
+        arr = (PrefetchItem * max(self.n, 1))()
+        for i, (ptr_, nbytes, sa, cons) in enumerate(items):
+            arr[i].ptr, arr[i].bytes, arr[i].start_after, arr[i].consumer = ptr_, nbytes, sa, cons
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.progress.device)
+        self.items = items
+
+    def launch(self):
+        """mode "branch": enqueue the prefetch kernel on the CURRENT stream (the caller forks a side stream inside the capture)."""
+        if self.mode == "branch" and self.table is not None and self.n:
+            check(lib().mvd_weight_prefetch(ptr(self.table), self.n, ptr(self.progress), self.blocks, self.spin_limit, stream()))
 
 
 # mvd_gemm_desc.cfg = 1 + CFG_STRIDE * tile + 2 * loop + order (include/mvd_hip.h: MVD_GEMM_CFG_STRIDE)

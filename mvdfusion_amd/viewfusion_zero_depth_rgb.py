@@ -24,6 +24,13 @@ from .scheduler import DDPMScheduler
 from .unet import UNetWrapper
 from .view_attn_efficient2 import GridAttn
 
+import os
+
+# Weight prefetch next to the graph-replayed step (include/mvd_hip.h: mvd_weight_prefetch).  MVD_PREFETCH=0 turns it
+# off (A/B runs); MVD_PREFETCH_OPTS="window=100663296,lead=6,blocks=32" overrides hip.WeightPrefetcher's parameters.
+PREFETCH_WEIGHTS = os.environ.get("MVD_PREFETCH", "ws")          # "ws" (in-kernel, default) | "branch" (parallel graph branch) | "0"
+PREFETCH_OPTIONS = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("MVD_PREFETCH_OPTS", "").split(",") if kv)}
+
 
 def _sinusoid_freqs(dim, max_period=10000):
     """exp(-ln(max_period) * i / half), computed on the host exactly as the reference does
@@ -67,6 +74,7 @@ class StepEngine:
         self.f256 = _sinusoid_freqs(256).to(dev)
         self.funet = _sinusoid_freqs(model.unet_model.unet_model.model_channels).to(dev)
         self.graphs = {}
+        self.prefetchers = {}      # per captured graph: its hip.WeightPrefetcher (None when PREFETCH_WEIGHTS is off)
         self.drop_masks = None     # training forward: (clip_mask, volume_mask, concat_mask), each (Vq,) in {0, 1} (unet.py:140-151)
         self.n_rows = 1            # rows of the device step table; the kernels index steps[iter], noise[iter] unchecked
         self.done = 0              # host mirror of the device iteration counter
@@ -108,12 +116,18 @@ class StepEngine:
         return (self.x0 if self.depth_mode == 1 else self.prev), self.steps_nodiv
 
     # -- one iteration -------------------------------------------------------------------------------
-    def enqueue(self, cfg_scale, do_update):
+    def enqueue(self, cfg_scale, do_update, prefetcher=None):
         m, ctx, L = self.m, self.ctx, hip.lib()
         V, S, D, B, q0, Vq = self.V, self.S, self.D, self.B, self.q0, self.Vq
         ctx.B, ctx.D = B, D
         ctx.begin_step()           # eager warm-up and graph capture walk the same rotating buffers
         st = hip.stream
+        side = None
+        if prefetcher is not None and prefetcher.mode == "branch":      # (capture only) fork: the prefetch kernel runs next to the whole step and is joined at its end;
+            side = torch.cuda.Stream()         # it starts behind begin_step's fill, which zeroed the launch counter it polls
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                prefetcher.launch()
         # embed_time (:276-279): sinusoid(256) -> Linear -> SiLU -> Linear; only row 0 is used downstream (t[:1])
         ts = ctx.ws.get("vf.tsin", (1, 256))
         hip.check(L.mvd_timestep_embedding(hip.ptr(self.steps), hip.ptr(self.iter), hip.ptr(self.f256), hip.ptr(ts), 256, st()))
@@ -159,6 +173,8 @@ class StepEngine:
         hip.check(L.mvd_cfg_ddim_update(hip.ptr(y), 8, hip.ptr(xq), hip.ptr(x0q), hip.ptr(epsq),
                                         hip.ptr(self.ddim_noise[:, q0:q0 + Vq]), V * 5 * S * S, hip.ptr(self.steps),
                                         hip.ptr(self.iter), Vq, S, int(self.cfg), float(cfg_scale), int(do_update), st()))
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         if do_update:
             hip.check(L.mvd_advance_iter(hip.ptr(self.iter), st()))
 
@@ -183,6 +199,17 @@ class StepEngine:
                 hip.AUTOTUNE = False
                 hip.release_tuning_buffers()
             torch.cuda.synchronize()
+            # weight prefetch (include/mvd_hip.h: mvd_weight_prefetch): a second eager pass with the tuned configurations records the
+            # step's GEMM launch order; the captured step then carries one long-running prefetch kernel on a parallel branch
+            pf = None
+            if PREFETCH_WEIGHTS in ("ws", "branch"):
+                pf = hip.WeightPrefetcher(self.ctx.progress, mode=PREFETCH_WEIGHTS, **PREFETCH_OPTIONS)
+                self.iter.copy_(it0)
+                self.x.copy_(x_keep)
+                self.x0.copy_(x0_keep)
+                with pf.following(record=True):
+                    self.enqueue(cfg_scale, do_update)
+                torch.cuda.synchronize()
             self.iter.copy_(it0)
             self.x.copy_(x_keep)
             self.x0.copy_(x0_keep)
@@ -190,10 +217,15 @@ class StepEngine:
             self.ctx.ws.frozen = True      # capture must not allocate: every buffer exists after the eager step
             try:
                 with g:
-                    self.enqueue(cfg_scale, do_update)
+                    if pf is None:
+                        self.enqueue(cfg_scale, do_update)
+                    else:
+                        with pf.following():
+                            self.enqueue(cfg_scale, do_update, prefetcher=pf)
             finally:
                 self.ctx.ws.frozen = False
             self.graphs[key] = g
+            self.prefetchers[key] = pf
         g.launch()
 
 

@@ -682,6 +682,34 @@ def test_gemm_configuration_table_and_tuner_cache(tmp_path):
         hip._TUNED.update(saved)
 
 
+def test_weight_prefetch_schedule():
+    """hip.WeightPrefetcher._build (host logic of mvd_gemm_desc.pf_items / mvd_weight_prefetch): which launch requests which weight."""
+    import ctypes
+    from mvdfusion_amd import hip
+    MB = 1 << 20
+    # launch order: (pointer, bytes, role-split kernel?); 0 bytes = an activation as B operand (never prefetched)
+    seq = [(0x1000, 1 * MB, False), (0x2000, 4 * MB, True), (0x3000, 2 * MB, False), (0, 0, False), (0x3000, 2 * MB, False),
+           (0x5000, 30 * MB, False), (0x6000, 3 * MB, True), (0x7000, 1 * MB, False)]
+    pf = hip.WeightPrefetcher(torch.zeros(4, dtype=torch.int32), mode="ws", window=8 * MB)
+    pf.seq = list(seq)
+    pf._build()
+    # host 1 takes launches 2 .. 6: the repeated pointer once, the 30 MB weight not (window), its own successor host's weight yes
+    assert pf.shares == {1: (0, 2), 6: (2, 1)}
+    assert [(it[0], it[3]) for it in pf.items] == [(0x3000, 2), (0x6000, 6), (0x7000, 7)]
+    raw = bytes(pf.table.numpy())
+    assert len(raw) == 3 * ctypes.sizeof(hip.PrefetchItem) == 72
+    first = hip.PrefetchItem.from_buffer_copy(raw[:24])
+    assert first.ptr == 0x3000 and first.bytes == 2 * MB
+    pb = hip.WeightPrefetcher(torch.zeros(4, dtype=torch.int32), mode="branch", window=8 * MB, lead=3)
+    pb.seq = list(seq)
+    pb._build()
+    by_consumer = {it[3]: it for it in pb.items}
+    assert sorted(by_consumer) == [0, 1, 2, 4, 5, 6, 7]
+    assert by_consumer[0][2] == 0 and by_consumer[2][2] == 0           # launches 0 .. 2 hold 7 MB: all requested at the start
+    assert by_consumer[5][2] == 5                                       # 30 MB > window: requested when its predecessor starts, alone
+    assert all(it[2] <= it[3] and it[3] - it[2] < 3 for it in pb.items)
+
+
 def test_bench_tree_fingerprint_tracks_kernel_sources(tmp_path, monkeypatch):
     """bench.tree_fingerprint() stamps every number that is read back from profiles/ (VERDICT r04 item 7): it must change when a kernel
     source changes and only then."""

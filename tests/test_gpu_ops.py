@@ -854,3 +854,50 @@ def test_cfg_ddim_update_golden(hip):
                                                 V * 5 * S * S, hip.ptr(steps), hip.ptr(it), V, S, 1, 2.5, 1, hip.stream()))
         assert rel_err(x, gd[f"x_prev_{index}"]) < 2e-6
         assert rel_err(x0, gd[f"x0_{index}"]) < 2e-6
+
+
+def test_weight_prefetch_requests_change_nothing():
+    """mvd_gemm_desc.pf_items (the role-split kernel's consumer wavefronts request the weights of later launches) and mvd_weight_prefetch
+    (the same from a kernel of its own, paced by mvd_gemm_desc.progress): both only READ -- outputs bit-identical with and without, the
+    weights untouched, the launch counter = number of GEMM launches, and the stand-alone kernel terminates when the step stops early."""
+    from mvdfusion_amd import hip
+    M, N, K = 1024, 320, 640
+    A = hip.split_planes(torch.randn(M, K, generator=g(1)).cuda())
+    Ws = [hip.pack_linear((torch.randn(N, K, generator=g(10 + i)) / math.sqrt(K)).cuda(), torch.zeros(N).cuda()) for i in range(4)]
+    keep = [w.data.clone() for w in Ws]
+    ws = torch.empty(8 * 1024 * 1024, device="cuda")
+    cfgs = [hip.make_cfg(2, hip.WS_LOOP), 0, hip.make_cfg(0, 0), hip.make_cfg(2, hip.WS_LOOP)]
+    outs = [torch.empty(M, N, device="cuda") for _ in range(4)]
+
+    def run():
+        for w, c, o in zip(Ws, cfgs, outs):
+            hip.gemm(A, w, o, prec=3, workspace=ws, splitk=1, cfg=c)
+        torch.cuda.synchronize()
+        return [o.clone() for o in outs]
+
+    ref = run()
+    progress = torch.zeros(4, dtype=torch.int32, device="cuda")
+    for mode in ("ws", "branch"):
+        pf = hip.WeightPrefetcher(progress, mode=mode, blocks=4, spin_limit=2000)
+        with pf.following(record=True):
+            run()
+        assert len(pf.seq) == 4 and [e[2] for e in pf.seq] == [True, False, False, True]
+        if mode == "ws":       # launch 0 hosts the weights of launches 1 .. 3, launch 3 (the last) nothing
+            assert pf.shares == {0: (0, 3)} and [it[3] for it in pf.items] == [1, 2, 3]
+        else:
+            assert [it[3] for it in pf.items] == [0, 1, 2, 3] and all(it[2] <= it[3] for it in pf.items)
+        progress.zero_()
+        side = torch.cuda.Stream()
+        if mode == "branch":
+            with torch.cuda.stream(side):
+                pf.launch()
+        with pf.following():
+            got = run()
+        side.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), mode
+        assert all(torch.equal(w.data, k) for w, k in zip(Ws, keep)), mode
+        assert int(progress[0]) == (4 if mode == "branch" else 0)
+    # a step that launches fewer GEMMs than the table lists: the kernel gives up after spin_limit polls instead of hanging
+    progress.zero_()
+    pf.launch()
+    torch.cuda.synchronize()
