@@ -425,6 +425,16 @@ int mvd_transpose_planes(const void* x, int src_planes, int rows, int cols, int 
 /* x_sp: channels-last (B,H,W,Cin) activation in split planes, Cin % 32 == 0  ->  out_sp (9*Cin, 2*ldo): row ci*9 + ky*3 + kx,
  * column = output pixel of the 3x3 / stride 1 / pad 1 conv (F.unfold order, transposed). */
 int mvd_im2col3x3_t_planes(const void* x_sp, int B, int H, int W, int Cin, void* out_sp, int ldo, mvd_stream_t stream);
+/* out2 = {s, 1/s}: the power of two s that brings max|x| of the n floats into [1024, 2048) (1 if the maximum is 0 or not finite) -- the
+ * scale a gradient is multiplied with before its fp16 hi + lo split (operand range contract above), on the device, one launch.
+ * scratch2: two zero-initialised 32-bit words owned by the caller; the kernel leaves them zero. */
+int mvd_pow2_scale(const float* x, size_t n, float* out2, unsigned* scratch2, mvd_stream_t stream);
+/* torch.optim.AdamW (no amsgrad) for a list of fp32 tensors in ONE launch (train.py:95 optimizer.step()).  tensors: device array of
+ * {float* p; const float* g; float* m; float* v; unsigned long long numel; unsigned first_chunk; unsigned pad;} (48 bytes): parameter,
+ * gradient, exp_avg, exp_avg_sq; first_chunk = running sum of ceil(numel / 4096) over the preceding entries, n_chunks = that sum over all.
+ * bias_c1 = 1 - beta1^step, bias_c2_sqrt = sqrt(1 - beta2^step); grad_scale multiplies every gradient first (1 = none). */
+int mvd_adamw_multi(const void* tensors, int n_tensors, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float bias_c1, float bias_c2_sqrt, float grad_scale, mvd_stream_t stream);
 /* out[c] = sum_r x[r][c] (bias gradient): fp64 partials, fixed order.  ws: mvd_col_sum_workspace_doubles(rows, cols) doubles. */
 size_t mvd_col_sum_workspace_doubles(int rows, int cols);
 int mvd_col_sum(const float* x, int rows, int cols, int ldx, float* out, double* ws, size_t ws_doubles, mvd_stream_t stream);

@@ -551,6 +551,104 @@ __global__ __launch_bounds__(256) void pixel_xattn_bwd_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------ gradient scale / optimizer
+// mvd_pow2_scale: out = {s, 1/s}, s the power of two that brings max|x| to [1024, 2048) (1 when the maximum is 0 or not finite).  One
+// launch: block maxima meet in an atomicMax on the float's bit pattern (non-negative floats order like their bits; NaN and inf sort above
+// every finite value and are caught below), the last block to arrive forms the scale and re-zeroes the two scratch words for the next call.
+__global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out, unsigned* scratch) {
+  unsigned m = 0;
+  const size_t n4 = n >> 2;
+  const float4* x4 = (const float4*)x;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = x4[i];
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu, __float_as_uint(v.z) & 0x7fffffffu));
+    m = max(m, __float_as_uint(v.w) & 0x7fffffffu);
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  __shared__ unsigned s_m[4];
+  __shared__ bool s_last;
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+    __hip_atomic_fetch_max(&scratch[0], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = __hip_atomic_fetch_add(&scratch[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    if (s_last) {
+      const unsigned bits = __hip_atomic_load(&scratch[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float s = 1.f;
+      if (bits != 0 && bits < 0x7f800000u) s = exp2f(10.f - floorf(log2f(__uint_as_float(bits))));
+      out[0] = s;
+      out[1] = 1.f / s;
+      __hip_atomic_store(&scratch[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&scratch[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// mvd_adamw_multi: torch.optim.AdamW's update (decoupled weight decay, bias correction, no amsgrad) for a LIST of tensors in one launch.
+// Table: per tensor {p, g, m, v, numel, first_chunk}; block b owns chunk b of 4096 elements of the concatenated index space and finds
+// its tensor by bisection over first_chunk (uniform: scalar loads).
+struct AdamwTensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  unsigned long long numel;
+  unsigned first_chunk;      // index of this tensor's first 4096-element chunk
+  unsigned pad;
+};
+constexpr int ADAMW_CHUNK = 4096;
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwTensor* __restrict__ tab, int n_tensors, float lr, float beta1, float beta2,
+                                                          float eps, float weight_decay, float bias_c1, float bias_c2_sqrt, float grad_scale) {
+  int lo = 0, hi = n_tensors - 1;
+  while (lo < hi) {                                   // last tensor whose first chunk is <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_chunk <= blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const AdamwTensor t = tab[lo];
+  const size_t base = (size_t)(blockIdx.x - t.first_chunk) * ADAMW_CHUNK;
+  const size_t left = t.numel - base;
+  const int n = left < (size_t)ADAMW_CHUNK ? (int)left : ADAMW_CHUNK;
+  const float step_size = lr / bias_c1, decay = 1.f - lr * weight_decay, omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  auto upd = [&](float& p, float g, float& m, float& v) {
+    g *= grad_scale;
+    p *= decay;                                       // param.mul_(1 - lr * weight_decay)
+    m = m + (g - m) * omb1;                           // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * beta2 + omb2 * g * g;                     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    const float denom = sqrtf(v) / bias_c2_sqrt + eps;
+    p -= step_size * (m / denom);                     // param.addcdiv_(exp_avg, denom, value = -step_size)
+  };
+  float* pp = t.p + base;
+  const float* gp = t.g + base;
+  float* mp = t.m + base;
+  float* vp = t.v + base;
+  const bool vec = ((((uintptr_t)pp | (uintptr_t)gp | (uintptr_t)mp | (uintptr_t)vp) & 15) == 0);
+  const int n4 = vec ? n >> 2 : 0;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    float4 p = ((float4*)pp)[i], m = ((float4*)mp)[i], v = ((float4*)vp)[i];
+    const float4 g = ((const float4*)gp)[i];
+    upd(p.x, g.x, m.x, v.x);
+    upd(p.y, g.y, m.y, v.y);
+    upd(p.z, g.z, m.z, v.z);
+    upd(p.w, g.w, m.w, v.w);
+    ((float4*)pp)[i] = p;
+    ((float4*)mp)[i] = m;
+    ((float4*)vp)[i] = v;
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+    float p = pp[i], m = mp[i], v = vp[i];
+    upd(p, gp[i], m, v);
+    pp[i] = p;
+    mp[i] = m;
+    vp[i] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int mvd_transpose_planes(const void* x, int src_planes, int rows, int cols, int ldx, void* out_sp, int ldo,
@@ -666,5 +764,26 @@ extern "C" int mvd_pixel_cross_attn_backward(const float* q, const float* k, con
   hipLaunchKernelGGL(pixel_xattn_bwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, dout, P, D,
                      heads, dhead, dq, dk, dv);
   MVD_CHECK_LAUNCH("mvd_pixel_cross_attn_backward");
+  return 0;
+}
+
+
+extern "C" int mvd_pow2_scale(const float* x, size_t n, float* out2, unsigned* scratch2, mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && out2 && scratch2 && n > 0 && ((uintptr_t)x & 15) == 0, "mvd_pow2_scale: null / misaligned argument");
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out2, scratch2);
+  MVD_CHECK_LAUNCH("mvd_pow2_scale");
+  return 0;
+}
+
+extern "C" int mvd_adamw_multi(const void* tensors, int n_tensors, int n_chunks, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float bias_c1, float bias_c2_sqrt, float grad_scale, mvd_stream_t stream) {
+  MVD_CHECK_ARG(tensors != nullptr && n_tensors >= 0 && n_chunks >= 0, "mvd_adamw_multi: null table");
+  if (n_tensors == 0 || n_chunks == 0) return 0;
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamwTensor*)tensors, n_tensors, lr, beta1,
+                     beta2, eps, weight_decay, bias_c1, bias_c2_sqrt, grad_scale);
+  MVD_CHECK_LAUNCH("mvd_adamw_multi");
   return 0;
 }

@@ -115,6 +115,8 @@ SIGNATURES = {
     "mvd_groupnorm_from_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_fill_zero": (_i, [_vp, _sz, _vp]),
+    "mvd_pow2_scale": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "mvd_adamw_multi": (_i, [_vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "mvd_weight_prefetch": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "mvd_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "mvd_advance_iter": (_i, [_vp, _vp]),

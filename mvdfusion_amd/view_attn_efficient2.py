@@ -24,71 +24,94 @@ from .cameras import pack_cameras
 _G4_VEC_BLOCK, _G4_VEC_MISC = 3328, 3 * 3328
 
 
+_MT_INDEX = {}
+
+
+def _microtile_index(dev):
+    """Index tensors of _microtiles on `dev` (built once per device)."""
+    t = _MT_INDEX.get(str(dev))
+    if t is None:
+        perm = torch.tensor([(4 * c + j) if j < 4 else (16 + 4 * c + j - 4) for c in range(4) for j in range(8)], device=dev)
+        R, c8 = torch.arange(16, device=dev), torch.arange(8, device=dev)
+        gran = (R >> 3)[:, None].expand(16, 8)
+        pos = ((R & 7) * 8)[:, None] + (c8[None, :] ^ ((R >> 1) & 7)[:, None])
+        t = _MT_INDEX[str(dev)] = (perm, gran, pos)
+    return t
+
+
 def _microtiles(W, scale, bf16):
     """(N, K) fp32 -> (N/16, K/32, 1024) int16: every (16 weight rows x 32 k) micro-tile as its 2 KiB LDS image --
     x*scale ~= hi + lo in the MFMA operand type, k inside the 32-block permuted to the fragment order of the kernel's
     register-resident activations (slot (c, j): k = 4c + j for j < 4, 16 + 4c + j - 4 otherwise), 16-byte chunk c (0-3 hi,
-    4-7 lo) of row R at position (R & 7) * 8 + (c ^ ((R >> 1) & 7)) of granule R >> 3 (the swizzle of csrc/gemm.hip)."""
+    4-7 lo) of row R at position (R & 7) * 8 + (c ^ ((R >> 1) & 7)) of granule R >> 3 (the swizzle of csrc/gemm_device.hpp).
+    Runs on W's device with torch indexing only -- no host copy: a training step re-packs the stream after every optimizer step."""
     N, K = W.shape
     assert N % 16 == 0 and K % 32 == 0, (N, K)
-    w = (W.detach().double().cpu() * scale).float()
+    w = (W.detach().double() * scale).float()
     dt = torch.bfloat16 if bf16 else torch.float16
     hi = w.to(dt)
     lo = (w - hi.float()).to(dt)
-    perm = torch.tensor([(4 * c + j) if j < 4 else (16 + 4 * c + j - 4) for c in range(4) for j in range(8)])
+    perm, gran, pos = _microtile_index(W.device)
 
     def chunks(t):
         return t.contiguous().view(torch.int16).view(N // 16, 16, K // 32, 32)[..., perm].reshape(N // 16, 16, K // 32, 4, 8)
 
     data = torch.cat([chunks(hi), chunks(lo)], dim=3).permute(0, 2, 1, 3, 4)            # (nt, ks, R, c8, 8)
-    R, c8 = torch.arange(16), torch.arange(8)
-    gran = (R >> 3)[:, None].expand(16, 8)
-    pos = ((R & 7) * 8)[:, None] + (c8[None, :] ^ ((R >> 1) & 7)[:, None])
-    img = torch.empty(N // 16, K // 32, 2, 64, 8, dtype=torch.int16)
+    img = torch.empty(N // 16, K // 32, 2, 64, 8, dtype=torch.int16, device=W.device)
     img[:, :, gran, pos, :] = data
     return img.reshape(N // 16, K // 32, 1024)
 
 
 def pack_fused_stream(ga, bf16=False):
     """GridAttn parameters -> (stream int16 (215 * 16, 1024) = 215 slots of 32 KiB in the kernel's consumption order,
-    vecs fp32 (11264,) with everything but the per-step adaLN modulation filled in)."""
+    vecs fp32 (11264,) with everything but the per-step adaLN modulation filled in), both on the parameters' device.  The only host
+    values are the power-of-two scales, which come from the parameter-maximum registry when it knows the tensors (hip._pack_scale(like=):
+    training) and from one reduction per weight otherwise (inference packs once)."""
     C = ga.hidden_size
     blocks = list(ga.aggregation_transformer.layer_list)
     assert C == 256 and len(blocks) == 3 and all(b.num_heads == 8 and b.mlp.fc1.out_features == 512 for b in blocks)
-    vecs = torch.zeros(hip.lib().mvd_gridattn_fused_vec_floats(), dtype=torch.float32)
+    dev = ga.pre_layer_b[0].weight.device
+    vecs = torch.zeros(hip.lib().mvd_gridattn_fused_vec_floats(), dtype=torch.float32, device=dev)
     tiles = []
 
-    def scaled(Wt):
-        sc = hip._pack_scale(Wt.detach())
+    def scaled(Wt, like):
+        sc = hip._pack_scale(Wt.detach(), like=like)
         return _microtiles(Wt, sc, bf16), 1.0 / sc
 
-    wpre = torch.zeros(C, 736)
-    wpre[:, :723] = ga.pre_layer_b[0].weight.detach().float().cpu()
-    pre, s_pre = scaled(wpre)
+    def put(o, t):
+        t = t.detach().float().reshape(-1)
+        vecs[o:o + t.numel()] = t
+
+    wpre = torch.zeros(C, 736, device=dev)
+    wpre[:, :723] = ga.pre_layer_b[0].weight.detach().float()
+    pre, s_pre = scaled(wpre, ga.pre_layer_b[0].weight)
     tiles.append(pre.permute(1, 0, 2).reshape(-1, 1024))                                # for ks: for nt
-    vecs[_G4_VEC_MISC:_G4_VEC_MISC + 256] = ga.pre_layer_b[0].bias.detach().float().cpu()
+    put(_G4_VEC_MISC, ga.pre_layer_b[0].bias)
     wl = ga.aggregation_transformer.weight_layer
-    vecs[_G4_VEC_MISC + 256:_G4_VEC_MISC + 512] = wl.weight.detach().float().cpu().reshape(-1)
-    vecs[_G4_VEC_MISC + 512] = float(wl.bias.detach().float().cpu())
-    vecs[_G4_VEC_MISC + 520] = s_pre
+    put(_G4_VEC_MISC + 256, wl.weight)
+    put(_G4_VEC_MISC + 512, wl.bias)
+    host = {_G4_VEC_MISC + 520: s_pre}
     for bi, blk in enumerate(blocks):
-        q, s_q = scaled(blk.attn.qkv.weight.float().cpu())          # (48, 8, 1024)
-        pj, s_p = scaled(blk.attn.proj.weight.float().cpu())        # (16, 8, 1024)
-        f1, s_1 = scaled(blk.mlp.fc1.weight.float().cpu())         # (32, 8, 1024)
-        f2, s_2 = scaled(blk.mlp.fc2.weight.float().cpu())         # (16, 16, 1024)
+        q, s_q = scaled(blk.attn.qkv.weight.detach().float(), blk.attn.qkv.weight)          # (48, 8, 1024)
+        pj, s_p = scaled(blk.attn.proj.weight.detach().float(), blk.attn.proj.weight)      # (16, 8, 1024)
+        f1, s_1 = scaled(blk.mlp.fc1.weight.detach().float(), blk.mlp.fc1.weight)          # (32, 8, 1024)
+        f2, s_2 = scaled(blk.mlp.fc2.weight.detach().float(), blk.mlp.fc2.weight)          # (16, 16, 1024)
         for hd in range(8):
-            rows = torch.tensor([2 * hd, 2 * hd + 1, 16 + 2 * hd, 16 + 2 * hd + 1, 32 + 2 * hd, 32 + 2 * hd + 1])
+            rows = [2 * hd, 2 * hd + 1, 16 + 2 * hd, 16 + 2 * hd + 1, 32 + 2 * hd, 32 + 2 * hd + 1]
             tiles.append(q[rows].permute(1, 0, 2).reshape(-1, 1024))                    # mt = 6 ks + tile
             tiles.append(pj[:, hd])                                                     # 16 output tiles of k-step hd
         for ch in range(8):
             tiles.append(f1[4 * ch:4 * ch + 4].permute(1, 0, 2).reshape(-1, 1024))      # for ks: the chunk's 4 tiles
             tiles.append(f2[:, 2 * ch:2 * ch + 2].permute(1, 0, 2).reshape(-1, 1024))   # for u: for nt
         o = bi * _G4_VEC_BLOCK
-        vecs[o + 1536:o + 2304] = blk.attn.qkv.bias.detach().float().cpu()
-        vecs[o + 2304:o + 2560] = blk.attn.proj.bias.detach().float().cpu()
-        vecs[o + 2560:o + 3072] = blk.mlp.fc1.bias.detach().float().cpu()
-        vecs[o + 3072:o + 3328] = blk.mlp.fc2.bias.detach().float().cpu()
-        vecs[_G4_VEC_MISC + 521 + 4 * bi:_G4_VEC_MISC + 525 + 4 * bi] = torch.tensor([s_q, s_p, s_1, s_2])
+        put(o + 1536, blk.attn.qkv.bias)
+        put(o + 2304, blk.attn.proj.bias)
+        put(o + 2560, blk.mlp.fc1.bias)
+        put(o + 3072, blk.mlp.fc2.bias)
+        for k, v in enumerate((s_q, s_p, s_1, s_2)):
+            host[_G4_VEC_MISC + 521 + 4 * bi + k] = v
+    idx = sorted(host)                                                                  # the scales: one small host -> device copy
+    vecs[torch.tensor(idx, device=dev)] = torch.tensor([host[k] for k in idx], dtype=torch.float32).to(dev)
     stream = torch.cat(tiles, 0).contiguous()
     assert stream.shape[0] == 16 * hip.lib().mvd_gridattn_fused_slots(), stream.shape
     return stream, vecs

@@ -242,7 +242,11 @@ class _HipTrainingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        outs = [torch.zeros(s, dtype=grad_out.dtype, device=grad_out.device) if g is None else (g.reshape(s) * grad_out)
+        # the gradients are this step's own buffers: scale them in place with multi-tensor launches (994 separate multiplies were 15 ms)
+        live = [g for g in ctx.grads if g is not None]
+        if live:
+            torch._foreach_mul_(live, grad_out.to(live[0].dtype))
+        outs = [torch.zeros(s, dtype=grad_out.dtype, device=grad_out.device) if g is None else g.reshape(s)
                 for g, s in zip(ctx.grads, ctx.shapes)]
         return (None, None, None, None, *outs)
 
@@ -667,4 +671,5 @@ class ViewFusion(nn.Module):
         groups.append({"params": self.unet_model.get_trainable_parameters(), "lr": lr})
         groups.append({"params": self.time_embed.parameters(), "lr": lr})
         groups.append({"params": self.view_attn.parameters(), "lr": lr})
-        return torch.optim.AdamW(groups, lr=lr)
+        from .optim import HipAdamW
+        return HipAdamW(groups, lr=lr)          # a torch.optim.AdamW whose step() is one HIP launch (mvdfusion_amd/optim.py)

@@ -176,3 +176,67 @@ def test_pixel_cross_attn_backward(hip, D):
     assert rel_err(dq.cpu(), q.grad) < 5e-6
     assert rel_err(dk.cpu(), k.grad) < 5e-6
     assert rel_err(dv.cpu(), v.grad) < 5e-6
+
+
+def test_pow2_scale_one_launch(hip):
+    """mvd_pow2_scale against the torch formula it replaced (max|t| -> power of two into [1024, 2048); 1 for zero / non-finite input)."""
+    from mvdfusion_amd import backward as bw
+
+    def ref(t):
+        mx = torch.linalg.vector_norm(t.reshape(-1), ord=float("inf")).float()
+        ok = torch.isfinite(mx) & (mx > 0)
+        e = torch.floor(torch.log2(torch.where(ok, mx, torch.ones_like(mx))))
+        return torch.where(ok, torch.exp2(10.0 - e), torch.ones_like(mx))
+
+    cases = [torch.randn(1000, 37, generator=g(1)) * 1e-6, torch.randn(7, generator=g(2)) * 3e-5, torch.randn(1 << 20, generator=g(3)) * 40.0,
+             torch.zeros(513), torch.full((5,), float("nan")), torch.tensor([1.0, float("inf"), -2.0]), torch.tensor([-1024.0]),
+             torch.tensor([2047.99, -1.0e-30]), torch.randn(4097, generator=g(4)) * 2.0 ** -60]
+    for i, t in enumerate(cases * 2):            # twice: the scratch words must come back zeroed
+        td = t.cuda()
+        s, inv = bw._pow2_scale(td)
+        want = float(ref(td))
+        assert float(s) == want and float(inv) == 1.0 / want, (i, float(s), want)
+        if want != 1.0 or i % len(cases) == 6:
+            assert 1024.0 <= float(td.abs().max()) * float(s) < 2048.0
+    x = torch.randn(300, 300, generator=g(9)).cuda()[:, :299]          # a non-contiguous view is reduced over its own elements only
+    assert float(bw._pow2_scale(x)[0]) == float(ref(x.contiguous()))
+
+
+def test_hip_adamw_matches_torch_adamw(hip):
+    """mvdfusion_amd.optim.HipAdamW (one mvd_adamw_multi launch) against torch.optim.AdamW on the same parameters and gradients over
+    several steps, odd sizes and a second parameter group; state dicts interchange (train.py:150,178)."""
+    from mvdfusion_amd.optim import HipAdamW
+    shapes = [(5,), (4097,), (320, 320, 3, 3), (1280, 77), (3,), (8192,)]
+    ps = [torch.nn.Parameter((torch.randn(*s, generator=g(20 + i)) * 0.05).cuda()) for i, s in enumerate(shapes)]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+
+    def groups(lst):
+        return [{"params": lst[:4], "lr": 1e-3}, {"params": lst[4:], "lr": 3e-4, "weight_decay": 0.1}]
+
+    a, b = HipAdamW(groups(ps), lr=1e-3), torch.optim.AdamW(groups(qs), lr=1e-3)
+    assert isinstance(a, torch.optim.AdamW)
+    for step in range(4):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            gr = (torch.randn(*p.shape, generator=g(100 + 10 * step + i)) * 1e-3).cuda()
+            p.grad, q.grad = gr.clone(), gr.clone()
+        if step == 2:
+            ps[1].grad = None                    # a parameter without a gradient this step is skipped (its step count stays behind)
+            qs[1].grad = None
+        a.step()
+        b.step()
+        for p, q in zip(ps, qs):
+            assert float((p - q).abs().max()) <= 2e-7 * max(1.0, float(q.abs().max())), step
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa["param_groups"][1]["weight_decay"] == sb["param_groups"][1]["weight_decay"] and len(sa["state"]) == len(sb["state"])
+    for k in sb["state"]:
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+        assert float((sa["state"][k]["exp_avg_sq"] - sb["state"][k]["exp_avg_sq"]).abs().max()) <= 1e-12
+    a2 = HipAdamW(groups(ps), lr=1e-3)
+    a2.load_state_dict(sb)                        # a torch.optim.AdamW checkpoint resumes under HipAdamW
+    for p, q in zip(ps, qs):
+        gr = torch.ones_like(p) * 1e-3
+        p.grad, q.grad = gr.clone(), gr.clone()
+    a2.step()
+    b.step()
+    for p, q in zip(ps, qs):
+        assert float((p - q).abs().max()) <= 4e-7 * max(1.0, float(q.abs().max()))
