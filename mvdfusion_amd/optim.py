@@ -72,3 +72,10 @@ class HipAdamW(torch.optim.AdamW):
                                                 float(group["eps"]), float(group["weight_decay"]), 1.0 - beta1 ** step,
                                                 math.sqrt(1.0 - beta2 ** step), 1.0, hip.stream()))
         self._keep = (table, keep)                      # alive until the next step (the launch is asynchronous)
+        # the kernel wrote through raw pointers: tell autograd / every cache keyed on tensor versions (hip.params_signature: packed weight
+        # images, hip._PARAM_MAX) that parameters and moments changed
+        for p in params:
+            st = self.state[p]
+            torch.autograd.graph.increment_version(p)
+            torch.autograd.graph.increment_version(st["exp_avg"])
+            torch.autograd.graph.increment_version(st["exp_avg_sq"])

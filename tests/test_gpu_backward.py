@@ -231,12 +231,15 @@ def test_hip_adamw_matches_torch_adamw(hip):
     for k in sb["state"]:
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
         assert float((sa["state"][k]["exp_avg_sq"] - sb["state"][k]["exp_avg_sq"]).abs().max()) <= 1e-12
+    import copy
     a2 = HipAdamW(groups(ps), lr=1e-3)
-    a2.load_state_dict(sb)                        # a torch.optim.AdamW checkpoint resumes under HipAdamW
+    a2.load_state_dict(copy.deepcopy(sb))         # a torch.optim.AdamW checkpoint resumes under HipAdamW (state_dict() hands out references)
+    v0 = ps[0]._version
     for p, q in zip(ps, qs):
         gr = torch.ones_like(p) * 1e-3
         p.grad, q.grad = gr.clone(), gr.clone()
     a2.step()
     b.step()
+    assert ps[0]._version > v0                     # the raw-pointer update is visible to version-keyed caches (packed weight images)
     for p, q in zip(ps, qs):
         assert float((p - q).abs().max()) <= 4e-7 * max(1.0, float(q.abs().max()))
