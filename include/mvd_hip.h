@@ -223,7 +223,8 @@ typedef struct mvd_gemm_desc {
    * instruction (one device-scope atomic by one thread), so that a concurrently running prefetch kernel knows how far the step's GEMM
    * sequence has come.  NULL = off. */
   int* progress;
-  /* In-kernel weight prefetch (gemm_ws_kernel only, cfg loop 7; ignored by the other kernels): pf_n entries of a device table of weights
+  /* In-kernel weight prefetch (hosts: gemm_ws_kernel, cfg loop 7, and the fused reduce + GroupNorm kernel of a split GEMM with gna_out_sp;
+   * ignored by every other kernel): pf_n entries of a device table of weights
    * that LATER launches of the step will read (mvd_prefetch_item: ptr, bytes; the other fields unused).  The launch's consumer wavefronts
    * request every 128-byte line of them once at kernel start and drop the data: see mvd_weight_prefetch below for the why.  NULL = off. */
   const struct mvd_prefetch_item_s* pf_items;

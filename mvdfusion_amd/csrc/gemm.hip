@@ -281,6 +281,22 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
       }
     }
   }
+  // Weight prefetch for the launches that follow (mvd_gemm_desc.pf_items, as in gemm_ws_kernel): this kernel's own loads have all been
+  // consumed above and the rest of it (statistics, normalise, store) issues none, so the requests ride along for their issue slots; the
+  // wave ends behind them (s_endpgm waits for outstanding memory instructions), by which time the stores of phase 2 are on their way too.
+  unsigned pf_sink = 0;
+  if (d.pf_items != nullptr) {
+    const __attribute__((address_space(4))) mvd_prefetch_item* tab = (const __attribute__((address_space(4))) mvd_prefetch_item*)d.pf_items;
+    const int gw = blockIdx.x * NWV + wave, GW = gridDim.x * NWV;
+    for (int it = 0; it < d.pf_n; ++it) {
+      const unsigned char* base = (const unsigned char*)tab[it].ptr;
+      const long lines = (long)((tab[it].bytes + 127) >> 7);
+      for (long l = (long)gw * 64 + lane; l < lines; l += (long)GW * 64) {
+        const unsigned char* a = base + (l << 7);
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(a) : "memory");
+      }
+    }
+  }
   {
     const double sd = wave_sum_d((double)s), qd = wave_sum_d((double)q);
     if (lane == 0) {
@@ -336,6 +352,7 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
       }
     }
   }
+  asm volatile("" ::"v"(pf_sink));      // (the prefetch requests' landing register stays reserved to the end)
 }
 
 // Tile configurations (mvd_gemm_desc.cfg = 1 + MVD_GEMM_CFG_STRIDE * tile + 2 * loop + order; 0 = built-in heuristic).
@@ -579,6 +596,7 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
       MVD_CHECK_ARG(e == hipSuccess, "mvd_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
     }
     p.d.gn_stats = gna_stats;      // (the slot of the normalised tensor -- of the concatenation in concat mode)
+    if (loop == 7) p.d.pf_items = nullptr;      // (the role-split kernel's consumer wavefronts already requested this launch's prefetch share)
     hipLaunchKernelGGL(splitk_gn_kernel, dim3((d.M / d.gn_hw) * d.gn_groups), dim3(MVD_GNK_THREADS), gna_lds, s, p);
     MVD_CHECK_LAUNCH("mvd_gemm/splitk_gn");
     return 0;

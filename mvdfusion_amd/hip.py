@@ -527,10 +527,14 @@ class WeightPrefetcher:
                        bump (mvd_gemm_desc.progress).  Measured 12 % SLOWER than no prefetch: kept for the record.
     """
 
-    def __init__(self, progress, mode="ws", window=24 << 20, lead=6, blocks=32, spin_limit=30000, max_items=24):
+    def __init__(self, progress, mode="ws", window=24 << 20, lead=6, blocks=32, spin_limit=30000, max_items=24, gn_hosts=0):
         self.progress = progress          # int32 device counter, zeroed by the engine at the start of every step (engine.Ctx.begin_step)
         self.mode = mode
         self.window, self.lead, self.blocks, self.spin_limit, self.max_items = int(window), int(lead), int(blocks), int(spin_limit), int(max_items)
+        # gn_hosts: the fused reduce + GroupNorm kernels of split GEMMs host prefetch shares too.  Measured (profiles/r05_prefetch_ab.log):
+        # 8.25 - 8.27 ms against 8.21 - 8.24 with the role-split hosts alone (8.33 - 8.38 without any prefetch): the requests lengthen the tail
+        # of a 10 us kernel by about what they save the next one.  Off by default.
+        self.gn_hosts = bool(gn_hosts)
         self.seq, self.recording, self.table, self.n, self.launch_idx, self.shares = [], False, None, 0, 0, {}
 
     class _Following:
@@ -561,14 +565,17 @@ class WeightPrefetcher:
         """Called by hip.gemm right before the launch (d.cfg is final)."""
         j = self.launch_idx
         self.launch_idx += 1
+        # hosts of the in-kernel prefetch: 1 = the role-split kernel (certain); 2 = a GEMM whose GroupNorm is applied behind it and that MAY
+        # split K -- then its fused reduce + GroupNorm kernel hosts (the library decides the split; an unsplit launch ignores its share)
         is_ws = bool(d.cfg) and _cfg_parts(d.cfg)[1] == WS_LOOP
+        host = 1 if is_ws else (2 if (d.gna_out_sp and d.splitk != 1 and self.gn_hosts) else 0)
         if self.recording:
             packed = not isinstance(W, PlanesOperand)
-            self.seq.append((W.data.data_ptr(), W.data.numel() * W.data.element_size(), is_ws) if packed else (0, 0, is_ws))
+            self.seq.append((W.data.data_ptr(), W.data.numel() * W.data.element_size(), host) if packed else (0, 0, host))
             return
         if self.mode == "branch":
             d.progress = self.progress.data_ptr()
-        elif is_ws and j in self.shares:
+        elif host and j in self.shares:
             first, n = self.shares[j]
             d.pf_items, d.pf_n = self.table.data_ptr() + first * C.sizeof(PrefetchItem), n
 
@@ -587,10 +594,13 @@ class WeightPrefetcher:
                     d += 1
                 items.append((ptr_, nbytes, max(j - d + 1, 0), j))
         else:
-            # role-split launch j takes the weights of launches j + 1 .. (next role-split launch), first come first served inside `window`
+            # host j takes the weights of launches j + 1 .. (next CERTAIN host), first come first served inside `window`; the shares of
+            # "maybe" hosts overlap those of the certain host before them (a second request of a resident line is cheap)
             hosts = [j for j, e in enumerate(self.seq) if e[2]]
-            for h, j in enumerate(hosts):
-                end = hosts[h + 1] if h + 1 < len(hosts) else len(self.seq) - 1
+            sure = [j for j, e in enumerate(self.seq) if e[2] == 1]
+            for j in hosts:
+                nxt = [k for k in sure if k > j]
+                end = nxt[0] if nxt else len(self.seq) - 1
                 first, acc, seen = len(items), 0, set()
                 for k in range(j + 1, end + 1):
                     ptr_, nbytes, _ = self.seq[k]

@@ -90,6 +90,7 @@ class StepEngine:
         dev = self.ctx.device
         if self.steps.shape != steps_table.shape:
             self.graphs.clear()                # table buffers are re-allocated: captured pointers go stale
+            self.prefetchers.clear()
             self.steps = steps_table.to(dev).contiguous()
             self.steps_nodiv = self.steps.clone()
             self.depth_noise = depth_noise.to(dev).contiguous()
@@ -336,6 +337,7 @@ class ViewFusion(nn.Module):
         if keep_engines:
             for e in self._engines.values():
                 e.graphs.clear()
+                e.prefetchers.clear()
         else:
             self._engines.clear()
 
