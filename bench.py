@@ -51,6 +51,17 @@ def tree_fingerprint():
     return h.hexdigest()[:16]
 
 
+def weight_prefetch_label():
+    """How the captured step prefetches weights (mvdfusion_amd/viewfusion_zero_depth_rgb.py: MVD_PREFETCH)."""
+    from mvdfusion_amd import viewfusion_zero_depth_rgb as vf
+    mode = vf.PREFETCH_WEIGHTS
+    if mode not in ("ws", "branch"):
+        return "off"
+    opts = ",".join(f"{k}={v}" for k, v in sorted(vf.PREFETCH_OPTIONS.items()))
+    return {"ws": "in-kernel (role-split consumer wavefronts request the following launches' weights)",
+            "branch": "prefetch kernel on a parallel graph branch"}[mode] + (f" [{opts}]" if opts else "")
+
+
 def build(V, S, D, precision, sd=None):
     from mvdfusion_amd import synthetic as syn
     from mvdfusion_amd.configs import model_config
@@ -431,7 +442,7 @@ def main():
                        "parallelism": "single GPU, CFG pair batched as 2V" if N == 1 else
                        f"view-parallel: {V} views over {N} GPUs, 1 all-gather of latent rows per step over "
                        f"{'RCCL (torch.distributed backend nccl)' if backend == 'nccl' else 'torch.distributed backend ' + str(backend)}",
-                       "hipgraph": graph},
+                       "hipgraph": graph, "weight_prefetch": weight_prefetch_label()},
             "gpu_ms_per_step_hip_events": gpu_ms,
             "algorithmic_tflop_per_step": step_flops / 1e12,
             "algorithmic_tflops": step_flops / (dt / a.steps) / 1e12,
