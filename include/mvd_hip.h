@@ -219,6 +219,9 @@ typedef struct mvd_gemm_desc {
   const float* cat_b;
   int cat_cb;
   void* cat_raw_sp;
+  /* Optional DEVICE scalar multiplied into acc_scale (NULL = 1): the backward GEMMs undo the power-of-two scale of their gradient operand
+   * (mvd_pow2_scale) with it, without the host ever reading the scale. */
+  const float* acc_scale_dev;
   /* Launch-order progress counter for mvd_weight_prefetch (below): when non-NULL the GEMM kernel adds 1 to *progress as its first
    * instruction (one device-scope atomic by one thread), so that a concurrently running prefetch kernel knows how far the step's GEMM
    * sequence has come.  NULL = off. */
@@ -252,6 +255,8 @@ int mvd_weight_prefetch(const mvd_prefetch_item* items, int n_items, const int* 
 /* fp32 (rows, cols) matrix with leading dim ldx -> split planes (rows, ldp), ldp % 32 == 0; columns [cols, ldp) are 0.
  * Used where a GEMM consumes a tensor that only exists in fp32 (residual stream into the 1x1 skip / up / down convs). */
 int mvd_split_planes(const float* x, void* sp, size_t rows, int cols, int ldx, int ldp, mvd_stream_t stream);
+/* ... of x * (*scale_dev): the power-of-two gradient scale of mvd_pow2_scale applied on the way into the planes (scale_dev NULL = 1). */
+int mvd_split_planes_scaled(const float* x, void* sp, size_t rows, int cols, int ldx, int ldp, const float* scale_dev, mvd_stream_t stream);
 
 /* fp32 matrix-vector products for the M<=16 cases (exact fp32 FMA):
  *   y[m, n] = act_out( sum_k W[n,k] * act_in(x[m,k]) + bias[n] ),  W (N,K) row-major fp32.
@@ -423,6 +428,9 @@ int mvd_event_destroy(void* ev);
 /* x: fp32 (rows, ldx) [src_planes = 0] or split planes (rows, 2*ldx) [1]  ->  out_sp: split planes of x^T, (cols, 2*ldo),
  * ldo % 32 == 0, ldo >= rows rounded up to 32 (columns [rows, ceil32(rows)) are written as zeros). */
 int mvd_transpose_planes(const void* x, int src_planes, int rows, int cols, int ldx, void* out_sp, int ldo, mvd_stream_t stream);
+/* ... of an fp32 source multiplied by *scale_dev first (see mvd_split_planes_scaled). */
+int mvd_transpose_planes_scaled(const float* x, int rows, int cols, int ldx, void* out_sp, int ldo, const float* scale_dev,
+                                mvd_stream_t stream);
 /* x_sp: channels-last (B,H,W,Cin) activation in split planes, Cin % 32 == 0  ->  out_sp (9*Cin, 2*ldo): row ci*9 + ky*3 + kx,
  * column = output pixel of the 3x3 / stride 1 / pad 1 conv (F.unfold order, transposed). */
 int mvd_im2col3x3_t_planes(const void* x_sp, int B, int H, int W, int Cin, void* out_sp, int ldo, mvd_stream_t stream);

@@ -32,14 +32,19 @@ def _pad16(n):
     return (n + 15) // 16 * 16
 
 
-def transpose_planes(x, rows, cols, src_planes=False, ldx=None):
+def transpose_planes(x, rows, cols, src_planes=False, ldx=None, scale=None):
     """(rows, cols) matrix -- fp32 tensor, or split planes when `src_planes` -- to the split planes of its transpose:
-    int16 (cols rounded up to 16, 2 * rows rounded up to 32); rows past `cols` stay zero (they are GEMM padding)."""
+    int16 (cols rounded up to 16, 2 * rows rounded up to 32); rows past `cols` stay zero (they are GEMM padding).  scale: device scalar an
+    fp32 source is multiplied with on the way (the power-of-two gradient scale)."""
     ldo = _pad32(rows)
     out = torch.zeros(_pad16(cols), 2 * ldo, dtype=torch.int16, device=x.device)
     if ldx is None:
         ldx = x.shape[-1] // 2 if src_planes else x.shape[-1]
-    hip.check(hip.lib().mvd_transpose_planes(hip.ptr(x), int(bool(src_planes)), rows, cols, ldx, hip.ptr(out), ldo, hip.stream()))
+    if scale is None:
+        hip.check(hip.lib().mvd_transpose_planes(hip.ptr(x), int(bool(src_planes)), rows, cols, ldx, hip.ptr(out), ldo, hip.stream()))
+    else:
+        assert not src_planes
+        hip.check(hip.lib().mvd_transpose_planes_scaled(hip.ptr(x), rows, cols, ldx, hip.ptr(out), ldo, hip.ptr(scale), hip.stream()))
     return out
 
 
@@ -69,9 +74,9 @@ def _pow2_scale(t):
     return out[0], out[1]
 
 
-def _planes_padded(x, cols):
-    """fp32 (rows, cols) -> split planes (rows, 2 * ceil32(cols)), padded columns zero."""
-    return hip.split_planes(x.contiguous(), ldp=_pad32(cols))
+def _planes_padded(x, cols, scale=None):
+    """fp32 (rows, cols) -> split planes (rows, 2 * ceil32(cols)) of x [* scale], padded columns zero."""
+    return hip.split_planes(x.contiguous(), ldp=_pad32(cols), scale=scale)
 
 
 def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True, prec=hip.PREC_X4, need_dw=True):
@@ -80,23 +85,22 @@ def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True,
     M, N = dy.shape
     K = weight.shape[1]
     dev = dy.device
+    # dY * s on its way into the operand planes and 1 / s in the GEMM's accumulator scale: both exact (powers of two), no extra pass
     sc, isc = _pow2_scale(dy)
-    dys = dy * sc                                                             # exact (power of two)
+    dyc = dy if dy.is_contiguous() else dy.contiguous()
     dx = None
     if need_dx:
         wt = hip.pack_linear(weight.detach().t().contiguous(), like=weight)   # (K, N): dX = dY W  (same elements: the registered max|w| serves)
         dx_full = torch.empty(M, wt.N, dtype=torch.float32, device=dev)
-        hip.gemm(_planes_padded(dys, N), wt, dx_full, prec=prec, bias=False, workspace=workspace)
-        dx_full *= isc
+        hip.gemm(_planes_padded(dyc, N, scale=sc), wt, dx_full, prec=prec, bias=False, workspace=workspace, acc_scale_dev=isc)
         dx = dx_full[:, :K]
     dW = None
     if need_dw:                                                               # (frozen parameters: only the dgrad is needed)
         # dW = dY^T X : both operands activations, reduction over the M rows
-        a = transpose_planes(dys, M, N)                                       # (ceil16(N), M) planes
+        a = transpose_planes(dyc, M, N, scale=sc)                             # (ceil16(N), M) planes
         b = transpose_planes(x_planes, M, K, src_planes=True)                 # (ceil16(K), M) planes
         dw_full = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=dev)
-        hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M)), dw_full, prec=prec, bias=False, workspace=workspace)
-        dw_full *= isc
+        hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M)), dw_full, prec=prec, bias=False, workspace=workspace, acc_scale_dev=isc)
         dW = dw_full[:N, :K]
     db = col_sum(dy, M, N) if need_db else None
     return dx, dW, db
@@ -110,26 +114,24 @@ def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, nee
     cin_p = x_planes.shape[-1] // 2
     dev = dy.device
     assert M == B * H * W and cin_p % 32 == 0 and cin_p >= Cin
-    sc, isc = _pow2_scale(dy)
-    dys = dy * sc
+    sc, isc = _pow2_scale(dy)          # (applied inside the plane conversions and the GEMMs' accumulator scale: linear_backward)
+    dyc = dy if dy.is_contiguous() else dy.contiguous()
     dx = None
     if need_dx:
         # dX = conv3x3(dY, W') with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]  (full correlation with the rotated filter)
         wr = hip.pack_conv3x3(weight.detach().flip(2, 3).transpose(0, 1).contiguous(), like=weight)
         dx_full = torch.empty(M, wr.N, dtype=torch.float32, device=dev)
-        hip.gemm(_planes_padded(dys, Cout), wr, dx_full, prec=prec, bias=False, workspace=workspace,
+        hip.gemm(_planes_padded(dyc, Cout, scale=sc), wr, dx_full, prec=prec, bias=False, workspace=workspace, acc_scale_dev=isc,
                  conv=dict(B=B, Hin=H, Win=W, Cin=_pad32(Cout), Hout=H, Wout=W, stride=1, upsample=0))
-        dx_full *= isc
         dx = dx_full[:, :Cin]
     dW = None
     if need_dw:
-        a = transpose_planes(dys, M, Cout)                                    # (ceil16(Cout), M)
+        a = transpose_planes(dyc, M, Cout, scale=sc)                          # (ceil16(Cout), M)
         ldo = _pad32(M)
         cols_t = torch.zeros(9 * cin_p, 2 * ldo, dtype=torch.int16, device=dev)     # (im2col X)^T, rows ci*9 + tap
         hip.check(hip.lib().mvd_im2col3x3_t_planes(hip.ptr(x_planes), B, H, W, cin_p, hip.ptr(cols_t), ldo, hip.stream()))
         dw_full = torch.empty(a.shape[0], 9 * cin_p, dtype=torch.float32, device=dev)
-        hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo), dw_full, prec=prec, bias=False, workspace=workspace)
-        dw_full *= isc
+        hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo), dw_full, prec=prec, bias=False, workspace=workspace, acc_scale_dev=isc)
         dW = dw_full[:Cout, :9 * Cin].reshape(Cout, Cin, 3, 3)
     db = col_sum(dy, M, Cout) if need_db else None
     return dx, dW, db

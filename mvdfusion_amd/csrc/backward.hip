@@ -17,8 +17,9 @@ namespace {
 // (rows, cols) -> split planes of the transpose: out row c, k-block rb holds rows 32 rb .. 32 rb + 31 of column c.
 // src_planes == 0: x is fp32 with leading dimension ldx; 1: x is split planes (rows, 2 * ldx).
 __global__ __launch_bounds__(256) void transpose_planes_kernel(const void* __restrict__ x, int src_planes, int rows, int cols, int ldx,
-                                                               u16* __restrict__ out, int ldo) {
+                                                               u16* __restrict__ out, int ldo, const float* __restrict__ scale) {
   __shared__ unsigned int tile[32][33];
+  const float sc = scale != nullptr ? *scale : 1.f;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
 #pragma unroll
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const void* __res
         hi = p[0];
         lo = p[32];
       } else {
-        split_op16(((const float*)x)[(size_t)r * ldx + c], hi, lo);
+        split_op16(((const float*)x)[(size_t)r * ldx + c] * sc, hi, lo);
       }
     }
     tile[ty + 8 * i][tx] = (unsigned int)hi | ((unsigned int)lo << 16);
@@ -651,16 +652,25 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwTensor* __r
 
 }  // namespace
 
-extern "C" int mvd_transpose_planes(const void* x, int src_planes, int rows, int cols, int ldx, void* out_sp, int ldo,
-                                    mvd_stream_t stream) {
+static int transpose_planes_impl(const void* x, int src_planes, int rows, int cols, int ldx, void* out_sp, int ldo, const float* scale_dev,
+                                 mvd_stream_t stream) {
   MVD_CHECK_ARG(x && out_sp && rows > 0 && cols > 0 && ldx >= cols, "mvd_transpose_planes: bad arguments");
   MVD_CHECK_ARG(ldo % 32 == 0 && ldo >= (rows + 31) / 32 * 32 && ((uintptr_t)out_sp & 127) == 0,
                 "mvd_transpose_planes: ldo=%d must be a multiple of 32 covering %d rows, 128-byte aligned output", ldo, rows);
   if (src_planes) MVD_CHECK_ARG(ldx % 32 == 0, "mvd_transpose_planes: plane source needs ldx %% 32 == 0");
   hipLaunchKernelGGL(transpose_planes_kernel, dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, src_planes,
-                     rows, cols, ldx, (u16*)out_sp, ldo);
+                     rows, cols, ldx, (u16*)out_sp, ldo, scale_dev);
   MVD_CHECK_LAUNCH("mvd_transpose_planes");
   return 0;
+}
+
+extern "C" int mvd_transpose_planes(const void* x, int src_planes, int rows, int cols, int ldx, void* out_sp, int ldo, mvd_stream_t stream) {
+  return transpose_planes_impl(x, src_planes, rows, cols, ldx, out_sp, ldo, nullptr, stream);
+}
+
+extern "C" int mvd_transpose_planes_scaled(const float* x, int rows, int cols, int ldx, void* out_sp, int ldo, const float* scale_dev,
+                                           mvd_stream_t stream) {
+  return transpose_planes_impl(x, 0, rows, cols, ldx, out_sp, ldo, scale_dev, stream);
 }
 
 extern "C" int mvd_im2col3x3_t_planes(const void* x_sp, int B, int H, int W, int Cin, void* out_sp, int ldo, mvd_stream_t stream) {

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
   if (d.epi == MVD_EPI_STORE) {   // 4 columns per thread: 16-byte slab reads, vector epilogue
     const size_t MN4 = MN >> 2;
-    const float inv = 1.0f / d.acc_scale;   // epi_store4 re-applies acc_scale; slabs hold raw accumulators
+    const float inv = 1.0f / gemm_acc_scale(d);   // epi_store4 re-applies acc_scale; slabs hold raw accumulators
     (void)inv;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < MN4; e += (size_t)gridDim.x * 256) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
   const int r0 = tid < total ? rs : 0, j0 = tid < total ? js : 0; // ... which is also its safe address for the unconditional loads
   const float* const zero2 = (const float*)g_zero_page;
   const bool has_bias = d.bias != nullptr, has_bb = d.bias_b != nullptr, has_res = d.res != nullptr;
+  const float ascale = gemm_acc_scale(d);
   float s = 0.f, q = 0.f;
   {
     int r = rs, j = js;
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float2 v = acc[u];
-        v.x = v.x * d.acc_scale + tb[u].x + tbb[u].x + tr[u].x;
-        v.y = v.y * d.acc_scale + tb[u].y + tbb[u].y + tr[u].y;
+        v.x = v.x * ascale + tb[u].x + tbb[u].x + tr[u].x;
+        v.y = v.y * ascale + tb[u].y + tbb[u].y + tr[u].y;
         if (!own[u]) v = tc[u];
         if (ok[u]) {
           const int m = m0 + rr[u], n = c0 + 2 * jj[u];
@@ -667,7 +668,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
 
 // fp32 (rows, cols) with leading dim ldx -> split planes (rows, ldp); columns [cols, ldp) are zero filled
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u16* __restrict__ sp, size_t rows, int cols,
-                                                           int ldx, int ldp) {
+                                                           int ldx, int ldp, const float* __restrict__ scale) {
+  const float sc = scale != nullptr ? *scale : 1.f;
   const int c4 = ldp >> 2;
   const size_t total = rows * c4;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     const int c = (int)(e - r * c4) * 4;
     float v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (c + j) < cols ? x[r * ldx + c + j] : 0.f;
+    for (int j = 0; j < 4; ++j) v[j] = (c + j) < cols ? x[r * ldx + c + j] * sc : 0.f;
     store_sp4(sp, r, ldp, c, v[0], v[1], v[2], v[3]);
   }
 }
@@ -716,13 +718,18 @@ extern "C" int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int ci
   return 0;
 }
 
-extern "C" int mvd_split_planes(const float* x, void* sp, size_t rows, int cols, int ldx, int ldp, mvd_stream_t stream) {
+extern "C" int mvd_split_planes_scaled(const float* x, void* sp, size_t rows, int cols, int ldx, int ldp, const float* scale_dev,
+                                       mvd_stream_t stream) {
   MVD_CHECK_ARG(x && sp && rows > 0 && cols > 0 && ldx >= cols && ldp >= cols && ldp % 32 == 0,
                 "mvd_split_planes: bad arguments (ldp must be a multiple of 32)");
   const size_t total = rows * (size_t)(ldp / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (u16*)sp, rows, cols, ldx, ldp);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (u16*)sp, rows, cols, ldx, ldp, scale_dev);
   MVD_CHECK_LAUNCH("mvd_split_planes");
   return 0;
+}
+
+extern "C" int mvd_split_planes(const float* x, void* sp, size_t rows, int cols, int ldx, int ldp, mvd_stream_t stream) {
+  return mvd_split_planes_scaled(x, sp, rows, cols, ldx, ldp, nullptr, stream);
 }

@@ -15,6 +15,11 @@ struct GemmParams {
   int m_fastest;
 };
 
+// acc_scale of the descriptor times its optional device scalar (mvd_gemm_desc.acc_scale_dev)
+__device__ __forceinline__ float gemm_acc_scale(const mvd_gemm_desc& d) {
+  return d.acc_scale_dev != nullptr ? d.acc_scale * *d.acc_scale_dev : d.acc_scale;
+}
+
 // mvd_gemm_desc.progress: "this GEMM has started" for the weight prefetcher (prefetch.hip) -- one device-scope atomic by one thread of the launch.
 __device__ __forceinline__ void gemm_note_progress(const mvd_gemm_desc& d) {
   if (d.progress != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)

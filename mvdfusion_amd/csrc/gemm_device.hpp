@@ -28,7 +28,7 @@ __device__ __forceinline__ void store_out(const mvd_gemm_desc& d, int m, int n, 
 // scalar element path (split-K reduce kernel, ragged n_store edge)
 __device__ __forceinline__ float epi_store_elem(const mvd_gemm_desc& d, int m, int n, float v) {
   if (d.epi == MVD_EPI_STORE && n >= d.n_store) return 0.f;  // padded columns (bias / res have n_store entries)
-  v *= d.acc_scale;
+  v *= gemm_acc_scale(d);
   if (d.bias) v += d.bias[n];
   if (d.bias_b) v += d.bias_b[(size_t)(m / d.rows_per_batch) * d.ldbb + n];
   if (d.epi == MVD_EPI_QKV) {
@@ -62,8 +62,8 @@ __device__ __forceinline__ float epi_store_elem(const mvd_gemm_desc& d, int m, i
 __device__ __forceinline__ void epi_geglu_elem(const mvd_gemm_desc& d, int m, int p_value, float v, float g) {
   const int col = (p_value >> 5) * 16 + (p_value & 15);
   const int half = d.N >> 1;
-  v *= d.acc_scale;
-  g *= d.acc_scale;
+  v *= gemm_acc_scale(d);
+  g *= gemm_acc_scale(d);
   if (d.bias) {
     v += d.bias[col];
     g += d.bias[half + col];
@@ -75,7 +75,7 @@ __device__ __forceinline__ void epi_geglu_elem(const mvd_gemm_desc& d, int m, in
 // (epi_value4: operands + arithmetic, epi_put4: the stores -- callers with several rows per thread run all the values before the first store:
 //  a load behind a conditional store waits for its acknowledgement)
 __device__ __forceinline__ float4 epi_value4(const mvd_gemm_desc& d, int m, int n, float4 v) {
-  v.x *= d.acc_scale; v.y *= d.acc_scale; v.z *= d.acc_scale; v.w *= d.acc_scale;
+  v.x *= gemm_acc_scale(d); v.y *= gemm_acc_scale(d); v.z *= gemm_acc_scale(d); v.w *= gemm_acc_scale(d);
   if (d.bias) {
     const float4 b = *(const float4*)(d.bias + n);
     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
@@ -233,7 +233,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     // own LDS reads.
     constexpr int NCH = WTM / 16;
     float4 gv[NCH];
-    const float scale = d.acc_scale;
+    const float scale = gemm_acc_scale(d);
     auto geglu_values = [&](auto lnf_c) {
       constexpr bool LNF = decltype(lnf_c)::value;
 #pragma unroll
@@ -284,7 +284,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       // (values of every chunk first, then all the stores: see the GEGLU epilogue above)
       constexpr int NCQ = WTM / 8;
       float4 qv[NCQ];
-      const float scale = d.acc_scale;
+      const float scale = gemm_acc_scale(d);
       auto qk_values = [&](auto lnf_c) {
         constexpr bool LNF = decltype(lnf_c)::value;
 #pragma unroll
@@ -319,7 +319,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       const float csv = lnf ? d.ln_colsum[wn0 + col] : 0.f;
       constexpr int NCV = WTM / 8;
       float4 vv[NCV];
-      const float scale = d.acc_scale;
+      const float scale = gemm_acc_scale(d);
       auto vt_values = [&](auto lnf_c) {
         constexpr bool LNF = decltype(lnf_c)::value;
 #pragma unroll
@@ -384,7 +384,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     // batch and count them: a load under a branch forces vmcnt(0).  No value is carried from one group to the next (a register pipeline
     // across the back edge of the rolled loop makes the compiler rotate registers behind a vmcnt(0)).
     constexpr int GRP = NPS <= 11 ? NPS : (NPS + 1) / 2, NGRP = (NPS + GRP - 1) / GRP;
-    const float scale = d.acc_scale;
+    const float scale = gemm_acc_scale(d);
     const bool has_bias = d.bias != nullptr, has_cs = d.colscale != nullptr;
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f);
     if (has_bias && lane_ok) b = *(const float4*)(d.bias + n);

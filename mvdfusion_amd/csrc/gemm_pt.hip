@@ -582,7 +582,7 @@ __device__ __forceinline__ void pt_epi_store(const GemmParams& p, const PtUnit& 
   const bool col_ok = n < d.n_store;
   const int mrow = u.m0u + rsel;
   const float* const zero = (const float*)g_pt_zero_page;
-  const float scale = d.acc_scale;
+  const float scale = gemm_acc_scale(d);
   const bool has_bias = d.bias != nullptr, has_cs = d.colscale != nullptr;
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f);
   if (has_bias && col_ok) b = ld4(d.bias + n);
@@ -736,7 +736,7 @@ __device__ __forceinline__ void pt_epi_geglu(const GemmParams& p, const PtUnit& 
     bv = ld4(d.bias + col);
     bg = ld4(d.bias + half + col);
   }
-  const float scale = d.acc_scale;
+  const float scale = gemm_acc_scale(d);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     float4 v = vv[t], g = gg[t];
@@ -770,7 +770,7 @@ template <bool LNF>
 __device__ __forceinline__ void pt_epi_qkv(const GemmParams& p, const PtUnit& u, int lane, float2 lnrow, unsigned ecnt_addr) {
   const mvd_gemm_desc& d = p.d;
   const int C = d.heads * d.dhead;
-  const float scale = d.acc_scale;
+  const float scale = gemm_acc_scale(d);
   float4 x[4][2];
   int which[4];
 #pragma unroll

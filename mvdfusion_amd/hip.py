@@ -68,7 +68,7 @@ class GemmDesc(C.Structure):
         ("ln_stats", _vp), ("ln_count", _vp), ("ln_colsum", _vp), ("ln_ld", _i), ("ln_dim", _i), ("ln_eps", _f),
         ("gna_out_sp", _vp), ("gna_gamma", _vp), ("gna_beta", _vp), ("gna_eps", _f), ("gna_flags", _i),
         ("cat_b", _vp), ("cat_cb", _i), ("cat_raw_sp", _vp),
-        ("progress", _vp), ("pf_items", _vp), ("pf_n", _i),
+        ("acc_scale_dev", _vp), ("progress", _vp), ("pf_items", _vp), ("pf_n", _i),
     ]
 
 
@@ -116,6 +116,8 @@ SIGNATURES = {
     "mvd_area_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mvd_fill_zero": (_i, [_vp, _sz, _vp]),
     "mvd_pow2_scale": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "mvd_split_planes_scaled": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _vp]),
+    "mvd_transpose_planes_scaled": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "mvd_adamw_multi": (_i, [_vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "mvd_weight_prefetch": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "mvd_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
@@ -398,19 +400,24 @@ def sp_cols(p):
     return p.shape[-1] // 2
 
 
-def split_planes(x, out=None, ldp=None):
-    """fp32 (rows, cols) -> split planes (rows, ldp) with zero-padded columns (mvd_split_planes)."""
+def split_planes(x, out=None, ldp=None, scale=None):
+    """fp32 (rows, cols) -> split planes (rows, ldp) with zero-padded columns (mvd_split_planes); scale: device scalar the values are
+    multiplied with on the way (mvd_split_planes_scaled: the power-of-two gradient scale of the backward)."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     ldp = (cols + 31) // 32 * 32 if ldp is None else ldp
     if out is None:
         out = planes_like(rows, ldp, x.device)
-    check(lib().mvd_split_planes(ptr(x), ptr(out), rows, cols, cols, ldp, stream()))
+    if scale is None:
+        check(lib().mvd_split_planes(ptr(x), ptr(out), rows, cols, cols, ldp, stream()))
+    else:
+        check(lib().mvd_split_planes_scaled(ptr(x), ptr(out), rows, cols, cols, ldp, ptr(scale), stream()))
     return out
 
 
 def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_NONE, res=None, colscale=None,
          bias_b=None, rows_per_batch=0, epi=EPI_STORE, conv=None, qkv=None, workspace=None, splitk=0, ldo=None,
-         out_planes=None, out_planes_col=0, cfg=None, gn_stats=None, gn_hw=0, gn_groups=32, row_stats=None, ln=None, gn_apply=None, cat=None):
+         out_planes=None, out_planes_col=0, cfg=None, gn_stats=None, gn_hw=0, gn_groups=32, row_stats=None, ln=None, gn_apply=None, cat=None,
+         acc_scale_dev=None):
     """out = epilogue(A @ W^T).  A: split planes (M, 2*K) int16 (dense) or the NHWC image rows (B*H*W, 2*C) with
     conv=dict(B, Hin, Win, Cin, Hout, Wout, stride, upsample).  qkv = dict(planes=(qh,ql,kh,kl,vh,vl), heads, dhead, L).
     out: fp32 tensor or None; out_planes: split-planes tensor or None (feeds the next GEMM); out_planes_col: first column
@@ -423,6 +430,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     gn_apply = (gamma, beta, eps, flags, planes): the GroupNorm consuming `out` is applied behind the GEMM (needs gn_stats): `planes`
     receives act(GroupNorm(out)) -- fused with the split-K reduce when the GEMM splits (mvd_gemm_desc.gna_out_sp; flags GNA_*).
     cat = (skip (M, cb) fp32, raw planes (M, 2 * (N + cb)) or None): the GroupNorm of gn_apply runs over [out | skip] (mvd_gemm_desc.cat_b).
+    acc_scale_dev: device scalar multiplied into the accumulator scale (mvd_gemm_desc.acc_scale_dev: the backward's 1 / gradient scale).
     """
     assert A.dtype == torch.int16, "A must be in split-planes format (see hip.split_planes)"
     d = GemmDesc()
@@ -432,6 +440,8 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
     if isinstance(W, PlanesOperand):
         d.b_mode, d.ldb = 1, W.ld
     d.acc_scale = W.acc_scale
+    if acc_scale_dev is not None:
+        d.acc_scale_dev = acc_scale_dev.data_ptr()
     d.prec = prec
     if conv is not None:
         d.a_mode = A_CONV3X3

@@ -2,7 +2,7 @@
 # Round artefacts on the GPU box -> gpurun_out/<tag>/ (copied into profiles/ by hand afterwards):
 #   bench lines (V=4 default with cpu_baseline; V=8; V=8 x 64^2), rocprofv3 kernel-trace stats of the default command,
 #   PMC traffic / MFMA passes per workload, shard emulation, step trace summary.
-tag=${1:-r04}
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -29,6 +29,27 @@ rocprofv3 --kernel-trace --stats -d $out -o bench --output-format csv -- python 
 cp $out/bench_kernel_stats.csv $O/bench_n1_kernel_stats.csv
 python $R/tools/trace_summary.py $out $O/step_trace_v4.json > $O/step_trace_v4.txt
 rm -rf $out
+# the rank share of the emulated 8-way view-parallel job: per-kernel table of ITS steps (the shard steps are the last ones of the run)
+cd /tmp
+rocprofv3 --kernel-trace -d $out -o bench --output-format csv -- python $R/bench.py --views 8 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --shard-emulate 0/8 --tune-cache $T8 > $O/prof_shard.log 2>&1
+python $R/tools/trace_summary.py $out $O/step_trace_v8_shard0of8.json > $O/step_trace_v8_shard0of8.txt
+rm -rf $out
+# weight prefetch on / off, alternating, same box
+cd $R
+for i in 1 2; do
+  for m in ws 0; do
+    MVD_PREFETCH=$m python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --tune-cache $T4 > $O/prefetch_${m}_$i.json 2> /dev/null
+  done
+done
+python - <<PY > $O/prefetch_ab.txt
+import json
+for m in ("ws", "0"):
+    for i in (1, 2):
+        d = json.loads(open("$O/prefetch_%s_%d.json" % (m, i)).read().strip().splitlines()[-1])
+        print("MVD_PREFETCH=%s run %d: %.2f steps/s %.3f ms/step" % (m, i, d["value"], d["ms_per_step"]))
+PY
+bash $R/tools/prof_train.sh $tag/train > $O/prof_train.log 2>&1
+cd /tmp
 bash $R/tools/pmc_traffic.sh ${tag}_v4_s32_d1 --tune-cache $T4 > $O/pmc_traffic_v4.log 2>&1
 bash $R/tools/pmc_traffic.sh ${tag}_v8_s32_d1 --views 8 --tune-cache $T8 > $O/pmc_traffic_v8.log 2>&1
 bash $R/tools/pmc_traffic.sh ${tag}_v8_s64_d1 --views 8 --latent 64 --tune-cache $T864 > $O/pmc_traffic_v8s64.log 2>&1
