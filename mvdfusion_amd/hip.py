@@ -760,7 +760,7 @@ def release_tuning_buffers():
 _TUNE_STATS = {}
 
 
-def _autotune(d, A=None, reps=4, trials=3, W_data=None):
+def _autotune(d, A=None, reps=4, trials=int(os.environ.get("MVD_TUNE_TRIALS", "3")), W_data=None):
     """Time the kernel configurations (tile x loop variant x tile order; split-K follows from the library's model)
     on the actual operands -- the op is idempotent -- and return the fastest.
 
