@@ -31,7 +31,9 @@ def main():
     pols = a.policies or (["f16x4", "f16x3"] + [f"f16x4:{k}=3" for k in kinds] +
                           ["f16x4:conv=3,geglu=3", "f16x4:conv=3,geglu=3,ffproj=3", "f16x3:attn=4,out=4,proj=4,qkv=4"])
     gd, g32 = load_golden("traj_mc320_v4_d1_50steps_f64"), load_golden("traj_mc320_v4_d1_50steps")
-    m = build_model(320, precision="f16x4")
+    fmts = {hip.parse_precision(pol)[0] for pol in pols}
+    assert len(fmts) == 1, f"one operand format per process (library flavour): {fmts}"
+    m = build_model(320, precision="bf16x3" if fmts == {"bf16"} else "f16x4")
     rows = []
     for pol in pols:
         _, m.precision, m.precision_policy = hip.parse_precision(pol)
