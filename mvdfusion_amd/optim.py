@@ -4,7 +4,7 @@
 written by either load into the other (train.py:150,178); only `step()` differs: instead of torch's multi-tensor passes over the 1 G trainable
 parameters (~8 kernel kinds, 25 ms) one `mvd_adamw_multi` launch applies the same update (include/mvd_hip.h) -- weight decay, lerp of
 exp_avg, exp_avg_sq, bias corrections, addcdiv -- reading parameter, gradient and both moments once and writing three.  Parameters that are
-not fp32 CUDA tensors, sparse gradients, amsgrad / maximize / capturable / differentiable settings fall back to torch's own step."""
+not fp32 CUDA tensors, sparse gradients, amsgrad / maximize / capturable / differentiable settings: the whole step falls back to torch's."""
 import ctypes as C
 import math
 
@@ -30,15 +30,19 @@ class HipAdamW(torch.optim.AdamW):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        def plain(group):
+            return self._plain(group) and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and not p.grad.is_sparse and
+                                              p.grad.dtype == torch.float32 for p in group["params"] if p.grad is not None)
+
+        if not all(plain(g) for g in self.param_groups):
+            # anything the one-launch kernel does not cover (CPU tensors, another dtype, amsgrad / maximize / capturable, sparse gradients):
+            # torch's own step for the whole optimizer -- same state layout, so the two can alternate
+            super().step()
+            return loss
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
-            ok = self._plain(group) and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and not p.grad.is_sparse and
-                                            p.grad.dtype == torch.float32 for p in params)
-            if not ok:
-                raise RuntimeError("HipAdamW: a parameter group is not plain fp32 CUDA AdamW (amsgrad / maximize / capturable / sparse "
-                                   "gradients / another dtype): use torch.optim.AdamW for it")
             steps = set()
             for p in params:
                 st = self.state[p]

@@ -244,7 +244,11 @@ class _HipTrainingLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         # the gradients are this step's own buffers: scale them in place with multi-tensor launches (994 separate multiplies were 15 ms)
-        live = [g for g in ctx.grads if g is not None]
+        live, seen = [], set()
+        for g in ctx.grads:
+            if g is not None and g.data_ptr() not in seen:      # (a buffer shared by two names is scaled once)
+                seen.add(g.data_ptr())
+                live.append(g)
         if live:
             torch._foreach_mul_(live, grad_out.to(live[0].dtype))
         outs = [torch.zeros(s, dtype=grad_out.dtype, device=grad_out.device) if g is None else g.reshape(s)

@@ -682,6 +682,27 @@ def test_gemm_configuration_table_and_tuner_cache(tmp_path):
         hip._TUNED.update(saved)
 
 
+def test_hip_adamw_is_a_torch_adamw_and_falls_back_off_gpu():
+    """mvdfusion_amd.optim.HipAdamW: the class ViewFusion.configure_optimizers returns.  On CPU tensors (or any group its one-launch kernel does
+    not cover) the step is torch's own, bit for bit, and the state dict is torch's."""
+    from mvdfusion_amd.optim import HipAdamW
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(7, 5, generator=g)), torch.nn.Parameter(torch.randn(11, generator=g))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a, b = HipAdamW(ps, lr=1e-2), torch.optim.AdamW(qs, lr=1e-2)
+    assert isinstance(a, torch.optim.AdamW)
+    for step in range(3):
+        for p, q in zip(ps, qs):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad, q.grad = gr.clone(), gr.clone()
+        a.step()
+        b.step()
+    assert all(torch.equal(p, q) for p, q in zip(ps, qs))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa["param_groups"] == sb["param_groups"] and set(sa["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert all(torch.equal(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]) for k in sb["state"])
+
+
 def test_weight_prefetch_schedule():
     """hip.WeightPrefetcher._build (host logic of mvd_gemm_desc.pf_items / mvd_weight_prefetch): which launch requests which weight."""
     import ctypes
