@@ -16,6 +16,9 @@ Weights: deterministic non-zero synthetic fill of the real architecture (no chec
 Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel family, HIP-event timed, algorithmic FLOPs
 against the dense 16-bit MFMA peak), `roofline_groups` (attention, GroupNorm, LayerNorm, GridAttn aggregation) and
 `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
+Environment: MVD_PREFETCH=ws|branch|0 (weight prefetch of the captured step; `config.weight_prefetch` records it), MVD_HIP_LIB=<.so>
+(another build of the same ABI, tools/probes/ab_build.sh: same-box A/B runs), MVD_BENCH_DUMP_GEMMS=<file> (one line per mvd_gemm launch of
+the eager profile pass: kernel, shape, microseconds -- the tool that found round 5's occupancy regression).
 """
 import argparse
 import json
