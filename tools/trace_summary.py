@@ -22,7 +22,9 @@ def main():
     if not segs:
         print("no step markers")
         return
-    n_last = segs[-1][1] - segs[-1][0]
+    # the steady (graph-replayed) steps all have the same launch count: the MOST COMMON one (the very last segment may carry tear-down copies)
+    import collections
+    n_last = collections.Counter(s[1] - s[0] for s in segs).most_common(1)[0][0]
     steady = [s for s in segs if s[1] - s[0] == n_last][-20:]
     if os.environ.get("TRACE_LAST_STEPS"):          # eager workloads (tools/bench_train.py): the launch count may differ by step
         steady = segs[-int(os.environ["TRACE_LAST_STEPS"]):]
