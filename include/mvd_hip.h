@@ -86,17 +86,17 @@ int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, floa
 #define MVD_ACT_QUICKGELU 3 /* x * sigmoid(1.702 x): the MLP activation of OpenAI CLIP's vision transformer */
 
 #define MVD_GEMM_TILES 5 /* tile shapes of mvd_gemm_desc.cfg */
-#define MVD_GEMM_LOOPS 11 /* k-loop variants of mvd_gemm_desc.cfg */
+#define MVD_GEMM_LOOPS 8 /* k-loop variants of mvd_gemm_desc.cfg (0 ... 7; 3 removed) */
 #define MVD_GEMM_CFG_STRIDE 32 /* cfg = 1 + MVD_GEMM_CFG_STRIDE * tile + 2 * loop + order */
 #define MVD_B_PACKED 0   /* B: weight image of mvd_pack_linear_weight / mvd_pack_conv3x3_weight */
 #define MVD_B_PLANES 1   /* B: (N, ldb) row-major split planes (an activation), N % 16 == 0 */
 
-/* one weight (or any read-only operand) a prefetcher should pull towards the chip: mvd_gemm_desc.pf_items, mvd_weight_prefetch */
+/* one weight (or any read-only operand) a later launch of the step will read: mvd_gemm_desc.pf_items */
 typedef struct mvd_prefetch_item_s {
   const void* ptr;
   unsigned long long bytes;
-  int start_after;      /* mvd_weight_prefetch only */
-  int consumer;         /* mvd_weight_prefetch only */
+  int start_after;      /* host bookkeeping (launch index of the host kernel); not read by the device */
+  int consumer;         /* host bookkeeping (launch index of the consumer); not read by the device */
 } mvd_prefetch_item;
 
 typedef struct mvd_gemm_desc {
@@ -158,14 +158,10 @@ typedef struct mvd_gemm_desc {
    *          stride-1 padded 3x3 convolutions (tiles 1, 2, 4): the tile's pixels + halo are staged once per 32-channel block and the
    *          nine taps read shifted slots of that patch (4-6x less A traffic into LDS), 7 = the wave-specialised kernel (tiles 1, 2,
    *          4; tile 1 with every epilogue, 2 and 4 MVD_EPI_STORE): four consumer wavefronts (fragment reads + MFMAs) and four loader wavefronts (all LDS-DMAs) per
-   *          workgroup, 10 = the PERSISTENT role-split
-   *          kernel (tile 1, every epilogue; csrc/gemm_pt.hip): one 16-wave workgroup per CU walks a contiguous run of output tiles -- 8 consumer
-   *          wavefronts (MFMAs), 4 loader wavefronts (all LDS-DMAs of a 4-stage ring, across tile boundaries) and 4 epilogue wavefronts that
-   *          take a finished tile from an LDS staging tile while the consumers multiply the next one; counters in LDS instead of barriers.
-   *          Outputs bit-identical to the other loops; rs_out then holds one slot per 128 columns (rs_count says so) and the GroupNorm /
-   *          row statistics partials are summed in another order; a problem it does not take (K < 64, n_store % 4 != 0) runs loop 0 of tile 1;
-   *          3, 8, 9 = removed (a four-buffer staggered loop and two register-staged operand deliveries, rounds 3 / 4: never the
-   *          fastest on any shape); mvd_gemm rejects them, and mvd_gemm_cfg_supported() tells whether a cfg serves a problem
+   *          workgroup;
+   *          3 = removed (a four-buffer staggered loop, round 3: never the fastest on any shape; the register-staged deliveries 8 / 9 and
+   *          the persistent role-split kernel 10 of rounds 4 / 5 went the same way -- tools/probes/gemm_pt.hip keeps the latter);
+   *          mvd_gemm rejects it, and mvd_gemm_cfg_supported() tells whether a cfg serves a problem
    *   order: 0 = n-fastest, 1 = m-fastest order of the output tiles over the 8 XCDs.
    * The host mirror times the candidates once per distinct problem shape during the eager warm-up step and passes the
    * winner from then on (mvdfusion_amd/hip.py: autotune). */
@@ -222,14 +218,13 @@ typedef struct mvd_gemm_desc {
   /* Optional DEVICE scalar multiplied into acc_scale (NULL = 1): the backward GEMMs undo the power-of-two scale of their gradient operand
    * (mvd_pow2_scale) with it, without the host ever reading the scale. */
   const float* acc_scale_dev;
-  /* Launch-order progress counter for mvd_weight_prefetch (below): when non-NULL the GEMM kernel adds 1 to *progress as its first
-   * instruction (one device-scope atomic by one thread), so that a concurrently running prefetch kernel knows how far the step's GEMM
-   * sequence has come.  NULL = off. */
-  int* progress;
   /* In-kernel weight prefetch (hosts: gemm_ws_kernel, cfg loop 7, and the fused reduce + GroupNorm kernel of a split GEMM with gna_out_sp;
    * ignored by every other kernel): pf_n entries of a device table of weights
    * that LATER launches of the step will read (mvd_prefetch_item: ptr, bytes; the other fields unused).  The launch's consumer wavefronts
-   * request every 128-byte line of them once at kernel start and drop the data: see mvd_weight_prefetch below for the why.  NULL = off. */
+   * request every 128-byte line of them once at kernel start and drop the data.  Why: a denoising step streams its whole weight set (3.4 GB of
+   * packed operands at model_channels 320) through a 256 MB Infinity Cache once per step, so every GEMM meets its weights cold and its short
+   * k-loop is a chain of HBM round trips (2 - 7 us per launch of the small and medium GEMMs, profiles/r05_prefetch_probe_whole_weight.log); the
+   * role-split convolutions have idle consumer wavefronts and idle HBM bandwidth to spend on the launches behind them.  NULL = off. */
   const struct mvd_prefetch_item_s* pf_items;
   int pf_n;
 } mvd_gemm_desc;
@@ -241,16 +236,6 @@ int mvd_gemm(const mvd_gemm_desc* d, mvd_stream_t stream);
 /* 1 if kernel configuration `cfg` (see mvd_gemm_desc.cfg) serves the problem `d` describes (tile family vs epilogue, loop variant vs
  * tile, the input-patch kernel vs the convolution's geometry), else 0.  The host autotuner enumerates with it. */
 int mvd_gemm_cfg_supported(const mvd_gemm_desc* d, int cfg);
-
-/* Weight prefetch for a graph-replayed step.  A denoising step streams its whole weight set (3.4 GB of packed operands at model_channels
- * 320) through a 256 MB Infinity Cache once per step, so every GEMM meets its weights cold and its short k-loop is a chain of HBM round
- * trips (measured: 2 - 7 us per launch of the small and medium GEMMs, profiles/r05_prefetch_probe_whole_weight.log).  mvd_weight_prefetch
- * enqueues ONE long-running kernel of `blocks` small workgroups that walks `items` (device array, launch order of the step's GEMMs):
- * item j is read once -- bytes [0, bytes) of ptr, results discarded -- as soon as *progress >= start_after (the GEMM `start_after` launches
- * before its consumer has started; mvd_gemm_desc.progress), and skipped when its consumer has already started (*progress > consumer).
- * Run it on a second stream (a parallel branch of the captured graph) next to the step; it never writes anything but its own exit, and
- * gives up after `spin_limit` polls without progress (so a step that launches fewer GEMMs than the table lists cannot hang it). */
-int mvd_weight_prefetch(const mvd_prefetch_item* items, int n_items, const int* progress, int blocks, int spin_limit, mvd_stream_t stream);
 
 /* fp32 (rows, cols) matrix with leading dim ldx -> split planes (rows, ldp), ldp % 32 == 0; columns [cols, ldp) are 0.
  * Used where a GEMM consumes a tensor that only exists in fp32 (residual stream into the 1x1 skip / up / down convs). */

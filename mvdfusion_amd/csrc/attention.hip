@@ -32,13 +32,8 @@ __device__ __forceinline__ void mfma_valu_pattern() {
   }
 }
 
-#ifdef MVD_ATTN_PHASED
-#define MVD_ATTN_MIN_WAVES(DQ) ((DQ) <= 64 ? 2 : 1)      // the phased body needs the 256-register cap to keep two workgroups per CU
-#else
-#define MVD_ATTN_MIN_WAVES(DQ) 1
-#endif
 template <int DQ, int DV, int NS, int QT, int NBUF>
-__global__ __launch_bounds__(256, MVD_ATTN_MIN_WAVES(DQ)) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
+__global__ __launch_bounds__(256, 1) void attn_kernel(const u16* __restrict__ q_hi, const u16* __restrict__ q_lo,
                                                    const u16* __restrict__ k_hi, const u16* __restrict__ k_lo,
                                                    const u16* __restrict__ vt_hi, const u16* __restrict__ vt_lo,
                                                    u16* __restrict__ out_sp, int ldo, int H, int L, int Lk, int Lpad, int dhead) {
@@ -149,184 +144,10 @@ __global__ __launch_bounds__(256, MVD_ATTN_MIN_WAVES(DQ)) void attn_kernel(const
     const int kv0 = t * KV_TILE, buf = NBUF == 2 ? (t & 1) : 0;
     if (t + 1 < ntiles) load_tile(kv0 + KV_TILE);      // in flight under the MFMAs below
 
-#ifdef MVD_ATTN_PHASED
-    constexpr bool PHASED = QT == 2 && DQ <= 48 && NS >= 3;
-#else
-    // Round 4 measured the phased body SLOWER than the un-phased one: attn_kernel<48,48,3,2,2> 72.4 us vs 64.3 us per launch at
-    // L = 1024 (graph-replayed step, profiles/r04_step_trace_v4.txt vs r03), 19.0 vs 16.4 ms of attention per step at L = 4096 -- two
-    // co-resident workgroups already overlap one's softmax with the other's MFMAs, and the phased form pays for its K-fragment
-    // prefetch with a second round of V^T fragment reads and a register allocation at the 256 limit.  Kept behind -DMVD_ATTN_PHASED
-    // (bit-identical, tests/test_gpu_ops.py::test_attention_phased_equals_single_tile covers whichever body is built).
-    constexpr bool PHASED = false;
-#endif
-    if constexpr (PHASED) {
-      // ---- two query tiles per wavefront, PHASED (round 4): the softmax of one query tile is VALU work (max / exp2 / sum / hi+lo split:
-      //      ~140 instructions) and the products of the other one are MFMA work, so the k-tile runs as
-      //        A: S(q0) = K Q0^T                       (MFMA)
-      //        B: S(q1) = K Q1^T   ||  softmax(q0)     (MFMA || VALU, interleaved by the scheduling hints below)
-      //        C: O(q0) += V^T P0  ||  softmax(q1)
-      //        D: O(q1) += V^T P1                      (MFMA)
-      //      with every K fragment of the tile read from LDS up front (one round trip per tile instead of one per 8 MFMAs) and the V^T
-      //      fragments requested during phase B.  Per accumulator the MFMA order is the one of the un-phased loop (k-steps in order,
-      //      lo*lo, lo*hi, hi*lo, hi*hi, then the 16-deep tail), so the results are BIT-IDENTICAL to it -- and to the one-tile-per-wave
-      //      kernel (tests/test_gpu_ops.py::test_attention_phased_equals_single_tile).  Consecutive MFMAs hit different accumulators (the
-      //      four key sub-tiles / the DT output tiles) instead of the same one back to back.
-      constexpr int QSn = QS > 0 ? QS : 1;
-      op16x8 kfh[4][QSn], kfl[4][QSn];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-        for (int ks = 0; ks < QS; ++ks) {
-          kfh[kt][ks] = *(const op16x8*)&sK[buf][0][kt * 16 + c][ks * 32 + g * 8];
-          if (NS >= 3) kfl[kt][ks] = *(const op16x8*)&sK[buf][NPL - 1][kt * 16 + c][ks * 32 + g * 8];
-        }
-      }
-      auto phased = [&](auto rag_c) __attribute__((always_inline)) {
-      constexpr bool RAG = decltype(rag_c)::value;     // the ragged last tile (keys past Lk masked) is its own copy: the common tile stays ONE basic block
-      f32x4 s[QT][4];
-      auto qk_tile = [&](auto t2c) {
-        constexpr int t2 = decltype(t2c)::value;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) s[t2][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < QS; ++ks) {
-          if (NS == 4) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x32(kfl[kt][ks], ql[t2][ks], s[t2][kt], 0, 0, 0);
-          }
-          if (NS >= 3) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x32(kfl[kt][ks], qh[t2][ks], s[t2][kt], 0, 0, 0);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x32(kfh[kt][ks], ql[t2][ks], s[t2][kt], 0, 0, 0);
-          }
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x32(kfh[kt][ks], qh[t2][ks], s[t2][kt], 0, 0, 0);
-        }
-        if (TAIL) {      // (the 16-channel tail fragments are read per query tile: 16 registers that need not live through phases A - B)
-          op4_t kh4[4], kl4[4];
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            kh4[kt] = *(const op4_t*)&sK[buf][0][kt * 16 + c][QS * 32 + g * 4];
-            if (NS >= 3) kl4[kt] = *(const op4_t*)&sK[buf][NPL - 1][kt * 16 + c][QS * 32 + g * 4];
-          }
-          if (NS == 4) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kl4[kt], qtl[t2], s[t2][kt]);
-          }
-          if (NS >= 3) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kl4[kt], qth[t2], s[t2][kt]);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kh4[kt], qtl[t2], s[t2][kt]);
-          }
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) s[t2][kt] = MVD_MFMA_16x16x16(kh4[kt], qth[t2], s[t2][kt]);
-        }
-      };
-      op16x8 ph[QT][2], pl2[QT][2];
-      auto softmax_tile = [&](auto t2c) {
-        constexpr int t2 = decltype(t2c)::value;
-        if (RAG) {
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (kv0 + kt * 16 + g * 4 + r >= Lk) s[t2][kt][r] = -INFINITY;
-        }
-        float mt = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[t2][kt][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run[t2], mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[t2] - m_new);
-        m_run[t2] = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            s[t2][kt][r] = __builtin_amdgcn_exp2f(s[t2][kt][r] - m_new);
-            psum += s[t2][kt][r];
-          }
-        l_run[t2] = l_run[t2] * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DT; ++i) o[t2][i] *= alpha;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          union { op16x8 v; u16 e[8]; uint32_t w[4]; } H8, L8;
-          if (NS >= 3) {     // packed split: v_cvt_pk + v_pk_add, 5 instructions per pair (common.hpp: split_op16x2)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const f32x4& sv = j < 2 ? s[t2][2 * u] : s[t2][2 * u + 1];
-              split_op16x2(sv[2 * (j & 1)], sv[2 * (j & 1) + 1], H8.w[j], L8.w[j]);
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) H8.e[j] = to_op_bits(j < 4 ? s[t2][2 * u][j] : s[t2][2 * u + 1][j - 4]);
-          }
-          ph[t2][u] = H8.v;
-          if (NS >= 3) pl2[t2][u] = L8.v;
-        }
-      };
-      // (the V^T fragments of a 32-key half are read right before its MFMAs, once per query tile: holding all of them across phases
-      //  B - D costs 48 registers and the second wavefront per SIMD)
-      auto pv_tile = [&](auto t2c) {
-        constexpr int t2 = decltype(t2c)::value;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          op16x8 vfh[DT][2], vfl[DT][2];
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            union { op16x8 v; uint2 h2[2]; } VH, VL;
-            VH.h2[0] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 4 * g];
-            VH.h2[1] = *(const uint2*)&sV[buf][0][dt * 16 + c][32 * u + 16 + 4 * g];
-            vfh[dt][u] = VH.v;
-            if (NS >= 3) {
-              VL.h2[0] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 4 * g];
-              VL.h2[1] = *(const uint2*)&sV[buf][NPL - 1][dt * 16 + c][32 * u + 16 + 4 * g];
-              vfl[dt][u] = VL.v;
-            }
-          }
-          if (NS == 4) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[t2][dt] = MVD_MFMA_16x16x32(vfl[dt][u], pl2[t2][u], o[t2][dt], 0, 0, 0);
-          }
-          if (NS >= 3) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[t2][dt] = MVD_MFMA_16x16x32(vfl[dt][u], ph[t2][u], o[t2][dt], 0, 0, 0);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[t2][dt] = MVD_MFMA_16x16x32(vfh[dt][u], pl2[t2][u], o[t2][dt], 0, 0, 0);
-          }
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o[t2][dt] = MVD_MFMA_16x16x32(vfh[dt][u], ph[t2][u], o[t2][dt], 0, 0, 0);
-        }
-      };
-      using std::integral_constant;
-      constexpr int NQK = 4 * (QS * NS + (TAIL ? NS : 0));      // MFMAs of one S tile
-      constexpr int NPV = DT * 2 * NS;                           // MFMAs of one O update
-      // A
-      qk_tile(integral_constant<int, 0>{});
-      __builtin_amdgcn_sched_barrier(0);
-      // B: the MFMAs of S(q1) with the softmax of q0 between them (4 VALU slots per 16-cycle MFMA), V^T fragment reads sprinkled in
-      qk_tile(integral_constant<int, 1>{});
-      softmax_tile(integral_constant<int, 0>{});
-      if (!RAG) mfma_valu_pattern<0, NQK, 4>();
-      __builtin_amdgcn_sched_barrier(0);
-      // C
-      pv_tile(integral_constant<int, 0>{});
-      softmax_tile(integral_constant<int, 1>{});
-      if (!RAG) mfma_valu_pattern<0, NPV, 5>();
-      __builtin_amdgcn_sched_barrier(0);
-      // D
-      pv_tile(integral_constant<int, 1>{});
-      };
-      if (kv0 + KV_TILE > Lk) phased(std::integral_constant<bool, true>{});
-      else phased(std::integral_constant<bool, false>{});
-    } else {
+    // (Round 4 built a PHASED form of the two-query-tile loop -- S(q0) | S(q1) with softmax(q0) | PV(q0) with softmax(q1) | PV(q1) -- and
+    //  measured it SLOWER: attn_kernel<48,48,3,2,2> 72.4 us vs 64.3 us per launch at L = 1024, 19.0 vs 16.4 ms of attention per step at
+    //  L = 4096 (profiles/r04_step_trace_v4.txt): two co-resident workgroups already overlap one's softmax with the other's MFMAs.  It
+    //  lived behind -DMVD_ATTN_PHASED until round 6 and is in the history at f2958d7.)
     // ---- S^T = K Q^T for every query tile of the wave: s[t2][kt][r] = S[q = c of tile t2][key = kv0 + kt*16 + g*4 + r].  The K
     //      fragments are read from LDS ONCE per key sub-tile and feed all QT query tiles (tiles past L compute on zero / padding rows
     //      and are never stored: no branches in the loop body, one basic block to schedule).
@@ -454,7 +275,6 @@ __global__ __launch_bounds__(256, MVD_ATTN_MIN_WAVES(DQ)) void attn_kernel(const
         for (int t2 = 0; t2 < QT; ++t2) o[t2][dt] = MVD_MFMA_16x16x32(VH.v, ph[t2][u], o[t2][dt], 0, 0, 0);
       }
     }
-    }      // (un-phased body)
     if (NBUF == 2) {
       if (t + 1 < ntiles) write_tile(buf ^ 1);         // the other buffer: its readers finished before the previous barrier
       __syncthreads();

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "gemm.hip", "gemm_plain_t0.hip", "gemm_plain_t1.hip", "gemm_plain_t2.hip", "gemm_plain_t3.hip", "gemm_plain_t4.hip",
-           "gemm_ws.hip", "gemm_patch.hip", "gemm_pt.hip", "prefetch.hip", "norm.hip", "attention.hip", "elementwise.hip", "gridattn.hip", "gridattn_fused.hip", "backward.hip"]
+           "gemm_ws.hip", "gemm_patch.hip", "norm.hip", "attention.hip", "elementwise.hip", "gridattn.hip", "gridattn_fused.hip", "backward.hip"]
 LIB = os.path.join(HERE, "libmvd_hip.so")            # fp16 MFMA operands (default)
 LIB_BF16 = os.path.join(HERE, "libmvd_hip_bf16.so")  # bf16 MFMA operands (-DMVD_OPERAND_BF16)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -2,7 +2,7 @@
 // reduce + epilogue + GroupNorm / SiLU of the output (optionally over its concatenation with a skip tensor) in one launch, a workgroup per
 // (image, group) with the group's values in LDS -- and the weight / activation packing kernels.  The GEMM kernels themselves live in
 // gemm_plain.hpp (gemm_kernel, one translation unit per block tile), gemm_ws.hip (role-split gemm_ws_kernel), gemm_patch.hip
-// (conv_patch_kernel) and gemm_pt.hip (persistent role-split gemm_pt_kernel); the device code they share is gemm_device.hpp.
+// (conv_patch_kernel); the device code they share is gemm_device.hpp.
 #include "gemm_device.hpp"
 
 namespace {
@@ -363,7 +363,9 @@ __global__ __launch_bounds__(MVD_GNK_THREADS) void splitk_gn_kernel(GemmParams p
 //   loop : 0 = plain two-buffer loop, 1 = register-pipelined loop, 2 = staggered wave groups, 3 LDS buffers (8-wave tiles 1 and
 //          4 only), 4 = register-pipelined loop over a ring of <= 4 LDS buffers, 5 = over a ring of <= 8 (4-wave tiles 0, 2, 3 only: the
 //          8-wave tiles fit 4), 6 = conv_patch_kernel (stride-1 3x3 convolutions, tiles 1, 2, 4), 7 = gemm_ws_kernel (consumer / loader
-//          wavefronts, LDS-DMA delivery), 10 = gemm_pt_kernel (persistent workgroups, consumer / loader / epilogue wavefronts; tile 1).
+//          wavefronts, LDS-DMA delivery).
+//          10 = REMOVED in round 6 (the persistent role-split kernel of round 5: bit-exact but slower than two co-resident plain workgroups and
+//          never a tuner candidate; source and measurements live on under tools/probes/gemm_pt.hip, profiles/r05_pt_*).
 //          3, 8, 9 = REMOVED in round 5 (staggered loop with four LDS buffers; register-staged delivery -- global_load -> VGPR ->
 //          ds_write_b128 -- in gemm_ws_kernel and in gemm_kernel): built and measured in rounds 3 / 4 (profiles/r04_*), never selected by
 //          the tuner on any shape of the step; mvd_gemm_cfg_supported() answers 0 for them and the numbering of the others is unchanged.
@@ -429,12 +431,12 @@ static bool cfg_supported(const mvd_gemm_desc& d, int cfg) {
   if (tile >= 2 && d.epi != MVD_EPI_STORE) return false;
   const int waves = kTiles[tile].waves;
   if ((loop == 2 || loop == 3) && waves != 8) return false;
-  if (loop == 3 || loop == 8 || loop == 9) return false;       // removed in round 5 (never selected by the tuner): the four-buffer staggered loop
-                                                                // and the two register-staged deliveries; the numbering of the others is unchanged
+  if (loop == 3 || loop >= 8) return false;                    // removed (never selected by the tuner): the four-buffer staggered loop, the two
+                                                                // register-staged deliveries (round 5), the persistent role-split kernel (round 6);
+                                                                // the numbering of the others is unchanged
   if (loop == 5 && waves != 4) return false;
   if (loop == 6) return (tile == 1 || tile == 2 || tile == 4) && patch_shares(d, kTiles[tile]) > 0;
   if (loop == 7) return tile == 1 || ((tile == 2 || tile == 4) && d.epi == MVD_EPI_STORE);   // (64x64 wave tiles: every epilogue)
-  if (loop == 10) return tile == 1 && mvd_gemm_pt_supported(d);      // gemm_pt.hip: the persistent role-split kernel (128x128 tiles, every epilogue)
   return true;
 }
 
@@ -527,9 +529,6 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
     tile = (d.cfg - 1) / MVD_GEMM_CFG_STRIDE;
     loop = ((d.cfg - 1) % MVD_GEMM_CFG_STRIDE) >> 1;
     order = (d.cfg - 1) & 1;
-    if (loop == 10 && tile == 1 && !mvd_gemm_pt_supported(d)) loop = 0;   // (a problem the persistent kernel does not take -- K < 64, ragged n_store --
-                                                                            //  runs the plain loop of the same tile; mvd_gemm_cfg_supported says so)
-    else
     MVD_CHECK_ARG(cfg_supported(d, d.cfg), "mvd_gemm: cfg %d (tile %d, loop %d) does not serve this problem (include/mvd_hip.h: cfg)", d.cfg, tile,
                   loop);
   } else {
@@ -559,14 +558,6 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
       if ((size_t)splits > cap) splits = cap < 1 ? 1 : (int)cap;
     }
   }
-  if (loop == 10) {       // gemm_pt_kernel: every split needs >= 2 k-tiles (a tile's last two ring slots become its staging tile)
-    const int need = mvd_gemm_pt_min_ktiles();
-    while (splits > 1) {
-      const int kps = cdiv(p.nk, splits), ns = cdiv(p.nk, kps);
-      if (p.nk - (ns - 1) * kps >= need) break;
-      --splits;
-    }
-  }
   p.kt_per_split = cdiv(p.nk, splits);
   if (loop == 6) p.kt_per_split = 9 * cdiv(p.nk / 9, splits);       // conv_patch_kernel: a split is a run of whole channel blocks
   p.splits = cdiv(p.nk, p.kt_per_split);
@@ -574,7 +565,6 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
   bool launched;
   if (loop == 6) launched = mvd_gemm_launch_patch(tile, p, s, patch_shares(d, ti));
   else if (loop == 7) launched = mvd_gemm_launch_ws(tile, p, s);
-  else if (loop == 10) launched = (mvd_gemm_pt_launch(p, s), true);
   else if (tile == 0) launched = mvd_gemm_launch_plain_t0(loop, p, s);
   else if (tile == 1) launched = mvd_gemm_launch_plain_t1(loop, p, s);
   else if (tile == 2) launched = mvd_gemm_launch_plain_t2(loop, p, s);

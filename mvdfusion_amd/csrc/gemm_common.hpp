@@ -1,6 +1,5 @@
 // Shared between the GEMM translation units: gemm.hip (host entry mvd_gemm, split-K reduces, packing), gemm_plain_t0 ... t4.hip
-// (gemm_kernel per block tile), gemm_ws.hip (role-split kernel), gemm_patch.hip (input-patch convolution), gemm_pt.hip (persistent
-// role-split kernel).
+// (gemm_kernel per block tile), gemm_ws.hip (role-split kernel), gemm_patch.hip (input-patch convolution).
 #pragma once
 #include "common.hpp"
 #include "../../include/mvd_hip.h"
@@ -19,18 +18,6 @@ struct GemmParams {
 __device__ __forceinline__ float gemm_acc_scale(const mvd_gemm_desc& d) {
   return d.acc_scale_dev != nullptr ? d.acc_scale * *d.acc_scale_dev : d.acc_scale;
 }
-
-// mvd_gemm_desc.progress: "this GEMM has started" for the weight prefetcher (prefetch.hip) -- one device-scope atomic by one thread of the launch.
-__device__ __forceinline__ void gemm_note_progress(const mvd_gemm_desc& d) {
-  if (d.progress != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-    __hip_atomic_fetch_add(d.progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// gemm_pt.hip: persistent 128x128 kernel (mvd_gemm_desc.cfg loop 10).  pt_supported: whether it serves the problem; pt_launch enqueues it
-// (the split-K reduce / GroupNorm kernels that may follow stay with mvd_gemm).
-bool mvd_gemm_pt_supported(const mvd_gemm_desc& d);
-int mvd_gemm_pt_min_ktiles();
-void mvd_gemm_pt_launch(const GemmParams& p, hipStream_t s);
 
 // Launchers of the tile-per-workgroup kernels, one per translation unit (grid = tiles x splits from GemmParams); false = the unit has no
 // kernel for that tile / loop (include/mvd_hip.h: cfg).

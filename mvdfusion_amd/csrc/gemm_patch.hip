@@ -23,7 +23,6 @@ namespace {
 //     and k order as gemm_kernel => bit-identical results.
 template <int BM, int BN, int WM, int WN, int NS, int PI>
 __global__ __launch_bounds__(WM * WN * 64) void conv_patch_kernel(GemmParams p) {
-  gemm_note_progress(p.d);
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;

@@ -48,7 +48,6 @@ namespace {
 template <int BM, int BN, int WM, int WN, int NS, int AMODE, int STAGES>
 __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && STAGES == 2 && AMODE == MVD_A_DENSE) ? 4 : ((BM == 64 && BN == 80 && STAGES == 3) ? 3 : 1))
 void gemm_kernel(GemmParams p) {
-  gemm_note_progress(p.d);
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;

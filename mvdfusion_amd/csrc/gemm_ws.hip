@@ -15,7 +15,6 @@ namespace {
 //                        t+2 (the NBUF-2 newer stages stay in flight); consumers read the fragments of k-tile t+1 and run the MFMAs of t.
 template <int BM, int BN, int CM, int CN, int NS, int AMODE>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
-  gemm_note_progress(p.d);
   constexpr int NC = CM * CN, NL = 4;
   static_assert(NC == 4, "four consumer wavefronts (one per SIMD) + four loader wavefronts");
   constexpr int WTM = BM / CM, WTN = BN / CN;
@@ -288,7 +287,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p) {
   if (it < nkt) step(integral_constant<int, 0>{}, it);
   if (it + 1 < nkt) step(integral_constant<int, 1>{}, it + 1);
   MVD_STAMP_AT(d, wave, 3);
-  asm volatile("" ::"v"(pf_sink));      // (the prefetch requests' landing register was reserved up to here; vmcnt: the epilogue's own waits cover them)
+  //  the prefetch requests are asm loads the compiler's waitcnt pass does not see: wait for them HERE, while their landing
+  // register is still reserved -- a late return must not land in a VGPR the epilogue has re-used (free after a k-loop of tens of us)
+  asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_sink) : "memory");
   __syncthreads();
   tile_epilogue<BM, BN, CM, CN>(p, acc, smem, m0, n0, lane, wave, AMODE == MVD_A_DENSE && d.ln_stats != nullptr ? s_rows : nullptr);
   MVD_STAMP_AT(d, wave, 8);

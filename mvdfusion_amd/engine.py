@@ -81,9 +81,7 @@ class Ctx:
         self.gemm_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 256 MB split-K slabs
         # GroupNorm statistics emitted by the producers of the normalised tensors (GEMM epilogue / split-K reduce / concat):
         # one (B, 32, 2) int64 slot per produced tensor per step, zeroed in one launch at the start of the step.
-        self.gn_arena = torch.zeros(GN_SLOTS * GN_SLOT_ELEMS + 2, dtype=torch.int64, device=self.device)
-        # (the two extra words: the GEMM launch counter of the step's weight prefetcher -- zeroed with the arena, one launch per step)
-        self.progress = self.gn_arena[GN_SLOTS * GN_SLOT_ELEMS:].view(torch.int32)
+        self.gn_arena = torch.zeros(GN_SLOTS * GN_SLOT_ELEMS, dtype=torch.int64, device=self.device)
         self._gn_next = 0
         self._gn = {}               # data_ptr of a produced tensor -> (stats slot, B, HW, C)
         self._rs = {}               # (tag, rows, width) -> hip.RowStats (static: part of the captured graph)
@@ -111,8 +109,6 @@ class Ctx:
         self._gn_next = 0
         if self.gn_from_producer:          # (one launch of the library's own fill kernel: the step contains no framework kernels)
             hip.check(hip.lib().mvd_fill_zero(hip.ptr(self.gn_arena), self.gn_arena.numel() * 2, hip.stream()))
-        else:
-            hip.check(hip.lib().mvd_fill_zero(hip.ptr(self.progress), self.progress.numel(), hip.stream()))
 
     def gn_slot(self, out, B, HW, C):
         """Reserve the statistics slot of `out` (a (B*HW, C) tensor about to be produced) and remember it for ctx.groupnorm."""

@@ -68,7 +68,7 @@ class GemmDesc(C.Structure):
         ("ln_stats", _vp), ("ln_count", _vp), ("ln_colsum", _vp), ("ln_ld", _i), ("ln_dim", _i), ("ln_eps", _f),
         ("gna_out_sp", _vp), ("gna_gamma", _vp), ("gna_beta", _vp), ("gna_eps", _f), ("gna_flags", _i),
         ("cat_b", _vp), ("cat_cb", _i), ("cat_raw_sp", _vp),
-        ("acc_scale_dev", _vp), ("progress", _vp), ("pf_items", _vp), ("pf_n", _i),
+        ("acc_scale_dev", _vp), ("pf_items", _vp), ("pf_n", _i),
     ]
 
 
@@ -119,7 +119,6 @@ SIGNATURES = {
     "mvd_split_planes_scaled": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _vp]),
     "mvd_transpose_planes_scaled": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "mvd_adamw_multi": (_i, [_vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _vp]),
-    "mvd_weight_prefetch": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "mvd_timestep_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "mvd_advance_iter": (_i, [_vp, _vp]),
     "mvd_zembed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -526,21 +525,19 @@ GEMM_SEQUENCE = None      # set by a step engine around ITS launches (WeightPref
 
 
 class WeightPrefetcher:
-    """Host side of the weight prefetch of ONE graph-captured step (include/mvd_hip.h: mvd_gemm_desc.pf_items / mvd_weight_prefetch).  While
+    """Host side of the weight prefetch of ONE graph-captured step (include/mvd_hip.h: mvd_gemm_desc.pf_items).  While
     `following(record=True)` is active (a second eager pass behind the tuned warm-up step) every hip.gemm launch appends its packed weight
-    and kernel kind to the launch-order list; `following()` during capture then hands every launch its share:
-      mode "ws"     -- in-kernel: every role-split launch (gemm_ws_kernel, the long convolutions: idle consumer wavefronts, idle HBM) requests
-                       the weights of the launches that follow it, up to and including the next role-split launch and `window` bytes
-                       (24 MB: the sweep of profiles/r05_prefetch_ab.log -- 4 ... 32 MB all gain 1.2 - 1.8 % of the step, 64 MB less, 128 MB
-                       loses: the big low-resolution weights push the step's activations out of the Infinity Cache);
-      mode "branch" -- one long-running kernel on a parallel graph branch (mvd_weight_prefetch) paced by a device launch counter the GEMMs
-                       bump (mvd_gemm_desc.progress).  Measured 12 % SLOWER than no prefetch: kept for the record.
+    and kernel kind to the launch-order list; `following()` during capture then hands every host launch its share: every role-split launch
+    (gemm_ws_kernel, the long convolutions: idle consumer wavefronts, idle HBM) requests the weights of the launches that follow it, up to
+    and including the next role-split launch and `window` bytes (24 MB: the sweep of profiles/r05_prefetch_ab.log -- 4 ... 32 MB all gain
+    1.2 - 1.8 % of the step, 64 MB less, 128 MB loses: the big low-resolution weights push the step's activations out of the Infinity Cache).
+    (Round 5 also measured a stand-alone prefetch kernel on a parallel graph branch: 12 % SLOWER than no prefetch, DESIGN.md section 6.00;
+    removed from the library in round 6, source under tools/probes/prefetch.hip.)
     """
 
-    def __init__(self, progress, mode="ws", window=24 << 20, lead=6, blocks=32, spin_limit=30000, max_items=24, gn_hosts=0):
-        self.progress = progress          # int32 device counter, zeroed by the engine at the start of every step (engine.Ctx.begin_step)
-        self.mode = mode
-        self.window, self.lead, self.blocks, self.spin_limit, self.max_items = int(window), int(lead), int(blocks), int(spin_limit), int(max_items)
+    def __init__(self, device, window=24 << 20, max_items=24, gn_hosts=0):
+        self.device = device
+        self.window, self.max_items = int(window), int(max_items)
         # gn_hosts: the fused reduce + GroupNorm kernels of split GEMMs host prefetch shares too.  Measured (profiles/r05_prefetch_ab.log):
         # 8.25 - 8.27 ms against 8.21 - 8.24 with the role-split hosts alone (8.33 - 8.38 without any prefetch): the requests lengthen the tail
         # of a 10 us kernel by about what they save the next one.  Off by default.
@@ -583,55 +580,36 @@ class WeightPrefetcher:
             packed = not isinstance(W, PlanesOperand)
             self.seq.append((W.data.data_ptr(), W.data.numel() * W.data.element_size(), host) if packed else (0, 0, host))
             return
-        if self.mode == "branch":
-            d.progress = self.progress.data_ptr()
-        elif host and j in self.shares:
+        if host and j in self.shares:
             first, n = self.shares[j]
             d.pf_items, d.pf_n = self.table.data_ptr() + first * C.sizeof(PrefetchItem), n
 
     def _build(self):
         items = []
         self.shares = {}
-        if self.mode == "branch":
-            # item j = the weight of the j-th launch: requested when launch start_after has begun -- as early as `lead` launches ahead, as
-            # long as the weights requested but not yet consumed stay inside `window` bytes (progress = launches that have started)
-            for j, (ptr_, nbytes, _) in enumerate(self.seq):
-                if not nbytes:
+        # host j takes the weights of launches j + 1 .. (next CERTAIN host), first come first served inside `window`; the shares of
+        # "maybe" hosts overlap those of the certain host before them (a second request of a resident line is cheap)
+        hosts = [j for j, e in enumerate(self.seq) if e[2]]
+        sure = [j for j, e in enumerate(self.seq) if e[2] == 1]
+        for j in hosts:
+            nxt = [k for k in sure if k > j]
+            end = nxt[0] if nxt else len(self.seq) - 1
+            first, acc, seen = len(items), 0, set()
+            for k in range(j + 1, end + 1):
+                ptr_, nbytes, _ = self.seq[k]
+                if not nbytes or ptr_ in seen or acc + nbytes > self.window or len(items) - first >= self.max_items:
                     continue
-                d, acc = 1, nbytes
-                while d < self.lead and j - d >= 0 and acc + self.seq[j - d][1] <= self.window:
-                    acc += self.seq[j - d][1]
-                    d += 1
-                items.append((ptr_, nbytes, max(j - d + 1, 0), j))
-        else:
-            # host j takes the weights of launches j + 1 .. (next CERTAIN host), first come first served inside `window`; the shares of
-            # "maybe" hosts overlap those of the certain host before them (a second request of a resident line is cheap)
-            hosts = [j for j, e in enumerate(self.seq) if e[2]]
-            sure = [j for j, e in enumerate(self.seq) if e[2] == 1]
-            for j in hosts:
-                nxt = [k for k in sure if k > j]
-                end = nxt[0] if nxt else len(self.seq) - 1
-                first, acc, seen = len(items), 0, set()
-                for k in range(j + 1, end + 1):
-                    ptr_, nbytes, _ = self.seq[k]
-                    if not nbytes or ptr_ in seen or acc + nbytes > self.window or len(items) - first >= self.max_items:
-                        continue
-                    seen.add(ptr_)
-                    acc += nbytes
-                    items.append((ptr_, nbytes, j, k))
-                if len(items) > first:
-                    self.shares[j] = (first, len(items) - first)
+                seen.add(ptr_)
+                acc += nbytes
+                items.append((ptr_, nbytes, j, k))
+            if len(items) > first:
+                self.shares[j] = (first, len(items) - first)
         self.n = len(items)
         arr = (PrefetchItem * max(self.n, 1))()
         for i, (ptr_, nbytes, sa, cons) in enumerate(items):
             arr[i].ptr, arr[i].bytes, arr[i].start_after, arr[i].consumer = ptr_, nbytes, sa, cons
-        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.progress.device)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.device)
         self.items = items
-
-    def launch(self):
-        """mode "branch": enqueue the prefetch kernel on the CURRENT stream (the caller forks a side stream inside the capture)."""
-        if self.mode == "branch" and self.table is not None and self.n:
-            check(lib().mvd_weight_prefetch(ptr(self.table), self.n, ptr(self.progress), self.blocks, self.spin_limit, stream()))
 
 
 # mvd_gemm_desc.cfg = 1 + CFG_STRIDE * tile + 2 * loop + order (include/mvd_hip.h: MVD_GEMM_CFG_STRIDE)
@@ -639,14 +617,13 @@ CFG_STRIDE = 32
 GNA_SILU, GNA_ROUND_F16, GNA_OUT_UNUSED = 1, 2, 4      # mvd_gemm_desc.gna_flags
 TUNE_CACHE_VERSION = 10            # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
-GEMM_LOOPS = (2, 3, 4, None, 6, 7, "patch", "ws", None, None, "pt")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 = staggered wave
+GEMM_LOOPS = (2, 3, 4, None, 6, 7, "patch", "ws")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 = staggered wave
                                  # groups (3 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
                                  # (stride-1 3x3 convolutions: the input patch is staged once per channel block); None = loop variants removed in
                                  # round 5 (never selected by the tuner; the numbering of the others is unchanged -- include/mvd_hip.h: cfg)
 REMOVED_LOOPS = tuple(i for i, l in enumerate(GEMM_LOOPS) if l is None)
 PATCH_LOOP = 6
 WS_LOOP = 7                      # gemm_ws_kernel: consumer / loader wavefront roles (tiles 1, 2, 4; EPI_STORE)
-PT_LOOP = 10                     # gemm_pt_kernel (csrc/gemm_pt.hip): persistent 16-wave workgroups, consumer / loader / epilogue wavefront roles (tile 1)
 
 
 def _cfg_parts(cfg):
@@ -665,7 +642,7 @@ def _cfg_valid(cfg, epi, b_mode=0):
     waves = wm * wn
     return loop not in REMOVED_LOOPS and (loop != 2 or waves == 8) and (loop != 5 or waves == 4) and \
         (loop != PATCH_LOOP or tile in (1, 2, 4)) and (tile < 2 or epi == EPI_STORE) and \
-        (loop != WS_LOOP or tile == 1 or (tile in (2, 4) and epi == EPI_STORE)) and (loop != PT_LOOP or tile == 1)
+        (loop != WS_LOOP or tile == 1 or (tile in (2, 4) and epi == EPI_STORE))
 
 
 _ALL_CONFIGS = tuple(c for c in range(1, CFG_STRIDE * len(GEMM_TILES) + 1) if _cfg_valid(c, EPI_STORE))
@@ -695,8 +672,6 @@ def kernel_symbol(cfg, prec, conv):
     bm, bn, wm, wn = GEMM_TILES[tile]
     if loop == PATCH_LOOP:
         return f"conv_patch_kernel<{bm}, {bn}, {wm}, {wn}, {prec}>"
-    if loop == PT_LOOP:
-        return f"gemm_pt_kernel<{prec}, {1 if conv else 0}>"
     if loop == WS_LOOP:
         cm, cn = {1: (2, 2), 2: (4, 1), 4: (2, 2)}[tile]
         return f"gemm_ws_kernel<{bm}, {bn}, {cm}, {cn}, {prec}, {1 if conv else 0}>"
@@ -782,9 +757,7 @@ def _autotune(d, A=None, reps=4, trials=int(os.environ.get("MVD_TUNE_TRIALS", "3
     # Loops the tuner does not time unless asked (MVD_TUNE_INCLUDE_LOOPS=8,9): the two register-staged delivery paths of round 4 were
     # candidates for a whole session and were selected for NO shape of any workload (profiles/r04_ws_variants.json);
     # they stay built, tested (test_gemm_configurations_agree) and selectable by cfg.  MVD_TUNE_EXCLUDE_LOOPS: A/B measurements.
-    # ... and the persistent role-split kernel of round 5 (loop 10, csrc/gemm_pt.hip): correct on every epilogue, but its k-loop runs at
-    # ~1 100 cycles per 128x128 k-tile against ~764 for two co-resident workgroups of the plain kernel (profiles/r05_pt_*.log).
-    skip = {PT_LOOP} - {int(t) for t in os.environ.get("MVD_TUNE_INCLUDE_LOOPS", "").split(",") if t}
+    skip = set()
     skip |= {int(t) for t in os.environ.get("MVD_TUNE_EXCLUDE_LOOPS", "").split(",") if t}      # (e.g. "7" = no role-split kernel)
     cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode, conv=d.a_mode == A_CONV3X3) if cfg_supported(d, c) and _cfg_parts(c)[1] not in skip
              for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]

@@ -26,9 +26,9 @@ from .view_attn_efficient2 import GridAttn
 
 import os
 
-# Weight prefetch next to the graph-replayed step (include/mvd_hip.h: mvd_weight_prefetch).  MVD_PREFETCH=0 turns it
-# off (A/B runs); MVD_PREFETCH_OPTS="window=100663296,lead=6,blocks=32" overrides hip.WeightPrefetcher's parameters.
-PREFETCH_WEIGHTS = os.environ.get("MVD_PREFETCH", "ws")          # "ws" (in-kernel, default) | "branch" (parallel graph branch) | "0"
+# Weight prefetch inside the graph-replayed step (include/mvd_hip.h: mvd_gemm_desc.pf_items).  MVD_PREFETCH=0 turns it
+# off (A/B runs); MVD_PREFETCH_OPTS="window=100663296,max_items=24" overrides hip.WeightPrefetcher's parameters.
+PREFETCH_WEIGHTS = os.environ.get("MVD_PREFETCH", "ws")          # "ws" (in-kernel, default) | "0"
 PREFETCH_OPTIONS = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("MVD_PREFETCH_OPTS", "").split(",") if kv)}
 
 
@@ -123,12 +123,6 @@ class StepEngine:
         ctx.B, ctx.D = B, D
         ctx.begin_step()           # eager warm-up and graph capture walk the same rotating buffers
         st = hip.stream
-        side = None
-        if prefetcher is not None and prefetcher.mode == "branch":      # (capture only) fork: the prefetch kernel runs next to the whole step and is joined at its end;
-            side = torch.cuda.Stream()         # it starts behind begin_step's fill, which zeroed the launch counter it polls
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                prefetcher.launch()
         # embed_time (:276-279): sinusoid(256) -> Linear -> SiLU -> Linear; only row 0 is used downstream (t[:1])
         ts = ctx.ws.get("vf.tsin", (1, 256))
         hip.check(L.mvd_timestep_embedding(hip.ptr(self.steps), hip.ptr(self.iter), hip.ptr(self.f256), hip.ptr(ts), 256, st()))
@@ -174,8 +168,6 @@ class StepEngine:
         hip.check(L.mvd_cfg_ddim_update(hip.ptr(y), 8, hip.ptr(xq), hip.ptr(x0q), hip.ptr(epsq),
                                         hip.ptr(self.ddim_noise[:, q0:q0 + Vq]), V * 5 * S * S, hip.ptr(self.steps),
                                         hip.ptr(self.iter), Vq, S, int(self.cfg), float(cfg_scale), int(do_update), st()))
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
         if do_update:
             hip.check(L.mvd_advance_iter(hip.ptr(self.iter), st()))
 
@@ -200,11 +192,11 @@ class StepEngine:
                 hip.AUTOTUNE = False
                 hip.release_tuning_buffers()
             torch.cuda.synchronize()
-            # weight prefetch (include/mvd_hip.h: mvd_weight_prefetch): a second eager pass with the tuned configurations records the
-            # step's GEMM launch order; the captured step then carries one long-running prefetch kernel on a parallel branch
+            # weight prefetch (include/mvd_hip.h: mvd_gemm_desc.pf_items): a second eager pass with the tuned configurations records the
+            # step's GEMM launch order; at capture every role-split launch is handed the weights of the launches behind it
             pf = None
-            if PREFETCH_WEIGHTS in ("ws", "branch"):
-                pf = hip.WeightPrefetcher(self.ctx.progress, mode=PREFETCH_WEIGHTS, **PREFETCH_OPTIONS)
+            if PREFETCH_WEIGHTS == "ws":
+                pf = hip.WeightPrefetcher(self.x.device, **PREFETCH_OPTIONS)
                 self.iter.copy_(it0)
                 self.x.copy_(x_keep)
                 self.x0.copy_(x0_keep)

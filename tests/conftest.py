@@ -16,7 +16,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
+# Order of the GPU suite: the reference-golden tests of every SURVEY section-8 row first (whole steps / UNet /
+# GridAttn, then VAE / prepare_batch / training gradients), the op-level backward and distributed tests next, the op matrices last, and
+# the bf16 flavour's subprocess at the very end -- a failure or a slow box costs the least evidence that way.
+_FILE_ORDER = ("test_gpu_model.py", "test_gpu_vae.py", "test_gpu_backward.py", "test_gpu_distributed.py", "test_gpu_ops.py",
+               "test_gpu_bf16_flavour.py")
+# MVD_TEST_FULL=1: the exhaustive cfg x split-K matrices of tests/test_gpu_ops.py (every configuration under every split mode) and the
+# whole op file in the bf16 flavour; default: every configuration once, split modes in rotation (suite budget: <= 600 s on the GPU box).
+FULL = os.environ.get("MVD_TEST_FULL") == "1"
+
+
+def cfg_splitk_matrix(cfgs, splitks=(1, 0, 1, 3)):
+    """(cfg, splitk) pairs for the GEMM configuration matrices: all of them under MVD_TEST_FULL=1, else every cfg once with the split
+    modes in rotation (1 = no split: the bit-equality leg; 0 = the library's model; 3 = forced)."""
+    cfgs = list(cfgs)
+    if FULL:
+        return [(c, s) for c in cfgs for s in sorted(set(splitks))]
+    return [(c, splitks[i % len(splitks)]) for i, c in enumerate(cfgs)]
+
+
 def pytest_collection_modifyitems(config, items):
+    rank = {name: i for i, name in enumerate(_FILE_ORDER)}
+    items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), -1))       # stable: the order inside a file is kept; CPU files first
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

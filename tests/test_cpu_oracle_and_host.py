@@ -429,8 +429,7 @@ def test_hot_kernels_compile_without_scratch_spills(tmp_path):
     reduce-and-normalise kernels hold their working sets in registers: a private (scratch) segment would mean spills in the k-loop.  hipcc
     cross-compiles the device code to assembly without a GPU (the GEMM family is one translation unit per kernel family since round 5,
     ~20 s each, compiled in parallel here); the kernel descriptors carry `.amdhsa_private_segment_fixed_size` and
-    `.amdhsa_next_free_vgpr`.  gemm_pt_kernel (cfg loop 10, NOT a tuner candidate: hip.py autotune) is allowed the 96 bytes its epilogue
-    wavefronts spill outside the k-loop, and no more."""
+    `.amdhsa_next_free_vgpr`."""
     import shutil
     import subprocess
     from concurrent.futures import ThreadPoolExecutor
@@ -438,7 +437,7 @@ def test_hot_kernels_compile_without_scratch_spills(tmp_path):
     if not (os.path.exists(hipcc) or shutil.which(hipcc)):
         pytest.skip("no hipcc")
     plan = [("gemm_plain_t%d.hip" % t, 512, 0) for t in range(5)] + [
-        ("gemm_ws.hip", 512, 0), ("gemm_patch.hip", 512, 0), ("gemm.hip", 128, 0), ("gemm_pt.hip", 128, 96),
+        ("gemm_ws.hip", 512, 0), ("gemm_patch.hip", 512, 0), ("gemm.hip", 128, 0),
         ("attention.hip", 512, 0), ("gridattn_fused.hip", 512, 0), ("elementwise.hip", 128, 0)]
 
     def compile_one(item):
@@ -648,24 +647,24 @@ def test_view_range_partition():
 
 
 def test_gemm_configuration_table_and_tuner_cache(tmp_path):
-    """hip.GEMM_CONFIGS mirrors the library's cfg encoding (include/mvd_hip.h): loops 3, 8, 9 were removed in round 5 and are not valid
-    for any tile (the library rejects them: tests/test_gpu_ops.py), the persistent kernel (loop 10) exists for the 128 x 128 tile only, and
-    a tuner cache written before the removal cannot smuggle a removed configuration back in."""
+    """hip.GEMM_CONFIGS mirrors the library's cfg encoding (include/mvd_hip.h): loop 3 (and 8, 9, 10 above the table) were removed in rounds
+    5 / 6 and are not valid for any tile (the library rejects them: tests/test_gpu_ops.py), and a tuner cache written before the removal
+    cannot smuggle a removed configuration back in."""
     import json
     from mvdfusion_amd import hip
-    assert hip.REMOVED_LOOPS == (3, 8, 9)
+    assert hip.REMOVED_LOOPS == (3,) and len(hip.GEMM_LOOPS) == 8
+    hdr = open(os.path.join(ROOT, "include", "mvd_hip.h")).read()
+    assert int(re.search(r"#define MVD_GEMM_LOOPS (\d+)", hdr).group(1)) == len(hip.GEMM_LOOPS)
     parts = [hip._cfg_parts(c) for c in hip.GEMM_CONFIGS_CONV]
     assert not [p for p in parts if p[1] in hip.REMOVED_LOOPS]
-    assert {p[0] for p in parts if p[1] == hip.PT_LOOP} == {1}
     assert {p[0] for p in parts if p[1] == hip.WS_LOOP} == {1, 2, 4} and {p[0] for p in parts if p[1] == hip.PATCH_LOOP} == {1, 2, 4}
-    assert len(hip.GEMM_CONFIGS_CONV) == 2 * (5 * 4 + 3 + 3 + 1)            # two tile orders x (4 loops per tile + ws + patch + pt)
+    assert len(hip.GEMM_CONFIGS_CONV) == 2 * (5 * 4 + 3 + 3)                # two tile orders x (4 loops per tile + ws + patch)
     assert all(c in hip.gemm_configs(hip.EPI_STORE) for c in hip.gemm_configs(hip.EPI_GEGLU))
     assert {hip._cfg_parts(c)[0] for c in hip.gemm_configs(hip.EPI_GEGLU)} == {0, 1}      # the 80-column family serves EPI_STORE only
     assert hip.kernel_symbol(hip.make_cfg(2, hip.WS_LOOP), 3, True) == "gemm_ws_kernel<128, 80, 4, 1, 3, 1>"
     assert hip.kernel_symbol(hip.make_cfg(0, 5), 3, False) == "gemm_kernel<64, 64, 2, 2, 3, 0, 7>"
-    assert hip.kernel_symbol(hip.make_cfg(1, hip.PT_LOOP), 4, False) == "gemm_pt_kernel<4, 0>"
     path = tmp_path / "tuned.json"
-    good, removed = hip.make_cfg(1, 4), hip.make_cfg(1, 8)
+    good, removed = hip.make_cfg(1, 4), hip.make_cfg(1, 10)
     doc = {"version": hip.TUNE_CACHE_VERSION, "cfg_stride": hip.CFG_STRIDE, "operand_format": hip.OPERAND_FORMAT,
            "entries": [[[1, 2, 3], [good, 1]], [[4, 5, 6], [removed, 1]], [[7, 8, 9], [0, 2]]]}
     saved = dict(hip._TUNED)
@@ -704,14 +703,14 @@ def test_hip_adamw_is_a_torch_adamw_and_falls_back_off_gpu():
 
 
 def test_weight_prefetch_schedule():
-    """hip.WeightPrefetcher._build (host logic of mvd_gemm_desc.pf_items / mvd_weight_prefetch): which launch requests which weight."""
+    """hip.WeightPrefetcher._build (host logic of mvd_gemm_desc.pf_items): which launch requests which weight."""
     import ctypes
     from mvdfusion_amd import hip
     MB = 1 << 20
     # launch order: (pointer, bytes, role-split kernel?); 0 bytes = an activation as B operand (never prefetched)
     seq = [(0x1000, 1 * MB, False), (0x2000, 4 * MB, True), (0x3000, 2 * MB, False), (0, 0, False), (0x3000, 2 * MB, False),
            (0x5000, 30 * MB, False), (0x6000, 3 * MB, True), (0x7000, 1 * MB, False)]
-    pf = hip.WeightPrefetcher(torch.zeros(4, dtype=torch.int32), mode="ws", window=8 * MB)
+    pf = hip.WeightPrefetcher("cpu", window=8 * MB)
     pf.seq = list(seq)
     pf._build()
     # host 1 takes launches 2 .. 6: the repeated pointer once, the 30 MB weight not (window), its own successor host's weight yes
@@ -721,14 +720,6 @@ def test_weight_prefetch_schedule():
     assert len(raw) == 3 * ctypes.sizeof(hip.PrefetchItem) == 72
     first = hip.PrefetchItem.from_buffer_copy(raw[:24])
     assert first.ptr == 0x3000 and first.bytes == 2 * MB
-    pb = hip.WeightPrefetcher(torch.zeros(4, dtype=torch.int32), mode="branch", window=8 * MB, lead=3)
-    pb.seq = list(seq)
-    pb._build()
-    by_consumer = {it[3]: it for it in pb.items}
-    assert sorted(by_consumer) == [0, 1, 2, 4, 5, 6, 7]
-    assert by_consumer[0][2] == 0 and by_consumer[2][2] == 0           # launches 0 .. 2 hold 7 MB: all requested at the start
-    assert by_consumer[5][2] == 5                                       # 30 MB > window: requested when its predecessor starts, alone
-    assert all(it[2] <= it[3] and it[3] - it[2] < 3 for it in pb.items)
 
 
 def test_bench_tree_fingerprint_tracks_kernel_sources(tmp_path, monkeypatch):

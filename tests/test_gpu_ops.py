@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, planes_to_float, rel_err
+from conftest import cfg_splitk_matrix, load_golden, planes_to_float, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -277,8 +277,17 @@ def test_conv3x3(hip, prec, case):
     assert served == (0 if case in ("s2", "up") else len(hip.PATCH_CONFIGS[::2])), (case, served)
 
 
-@pytest.mark.parametrize("cfg", list(_hip.GEMM_CONFIGS_CONV))
-@pytest.mark.parametrize("splitk", [0, 1, 3])
+_CASES = {}
+
+
+def _case(key, make):
+    """CPU operands / fp32 references of the configuration matrices, built once per module instead of once per parametrisation."""
+    if key not in _CASES:
+        _CASES[key] = make()
+    return _CASES[key]
+
+
+@pytest.mark.parametrize("cfg,splitk", cfg_splitk_matrix(_hip.GEMM_CONFIGS_CONV))
 def test_gemm_configurations_agree(hip, cfg, splitk):
     """Every kernel configuration the autotuner may pick (tile x loop variant x tile order, include/mvd_hip.h `cfg`), with and
     without split-K, on conv and dense problems with even and odd k-tile counts: all must match the fp32 reference AND be
@@ -287,11 +296,12 @@ def test_gemm_configurations_agree(hip, cfg, splitk):
     # nk = 18, 27, 90, 18, 9; the input-patch kernel (hip.PATCH_CONFIGS) meets tiles of 4 rows of one image, half an image, 2 images (one
     # past M), 8 whole 4x4 images and 2 rows of a 64-wide image (the last two need two patch DMAs per wave and k-tile at 128x80)
     for B, H, Cin, Cout in [(2, 32, 64, 64), (2, 16, 96, 320), (1, 8, 320, 48), (11, 4, 64, 80), (1, 64, 32, 80)]:
-        x = torch.randn(B, Cin, H, H, generator=g(40))
-        w = torch.randn(Cout, Cin, 3, 3, generator=g(41)) / math.sqrt(9 * Cin)
-        ref = F.conv2d(x, w, None, padding=1).permute(0, 2, 3, 1).reshape(B * H * H, Cout)
-        Wp = hip.pack_conv3x3(w.cuda(), None)
-        xp = hip.split_planes(x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda())
+        def make_conv():
+            x = torch.randn(B, Cin, H, H, generator=g(40))
+            w = torch.randn(Cout, Cin, 3, 3, generator=g(41)) / math.sqrt(9 * Cin)
+            ref = F.conv2d(x, w, None, padding=1).permute(0, 2, 3, 1).reshape(B * H * H, Cout)
+            return ref, hip.pack_conv3x3(w.cuda(), None), hip.split_planes(x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda())
+        ref, Wp, xp = _case(("conv", B, H, Cin, Cout), make_conv)
         outs = []
         for rep in range(3):
             out = torch.full((B * H * H, Cout), float("nan"), device="cuda")
@@ -301,18 +311,20 @@ def test_gemm_configurations_agree(hip, cfg, splitk):
         assert rel_err(outs[0], ref) < TOL[4], (B, H, Cin, Cout)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
         if splitk == 1:      # without split-K every tile / loop variant sums each output's k-tiles in the same order: bit-equal to cfg 1
-            base = torch.empty(B * H * H, Cout, device="cuda")
-            hip.gemm(xp, Wp, base, prec=4, workspace=ws, cfg=1, splitk=1,
-                     conv=dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, upsample=0))
-            assert torch.equal(base.cpu(), outs[0]), (B, H, Cin, Cout)
+            def make_base():
+                base = torch.empty(B * H * H, Cout, device="cuda")
+                hip.gemm(xp, Wp, base, prec=4, workspace=ws, cfg=1, splitk=1,
+                         conv=dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, upsample=0))
+                return base.cpu()
+            assert torch.equal(_case(("conv-base", B, H, Cin, Cout), make_base), outs[0]), (B, H, Cin, Cout)
     for M, N, K in [(2048, 320, 320), (512, 640, 2592), (100, 48, 96)]:                   # nk = 10, 81, 3
         if cfg in hip.PATCH_CONFIGS:
             break                                                                          # (convolutions only)
-        a = torch.randn(M, K, generator=g(42))
-        w = torch.randn(N, K, generator=g(43)) / math.sqrt(K)
-        ref = a @ w.t()
-        Wp = hip.pack_linear(w.cuda(), None)
-        ap = hip.split_planes(a.cuda())
+        def make_dense():
+            a = torch.randn(M, K, generator=g(42))
+            w = torch.randn(N, K, generator=g(43)) / math.sqrt(K)
+            return a @ w.t(), hip.pack_linear(w.cuda(), None), hip.split_planes(a.cuda())
+        ref, Wp, ap = _case(("dense", M, N, K), make_dense)
         outs = []
         for rep in range(3):
             out = torch.full((M, N), float("nan"), device="cuda")
@@ -321,13 +333,14 @@ def test_gemm_configurations_agree(hip, cfg, splitk):
         assert rel_err(outs[0], ref) < TOL[4], (M, N, K)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
         if splitk == 1:
-            base = torch.empty(M, N, device="cuda")
-            hip.gemm(ap, Wp, base, prec=4, workspace=ws, cfg=1, splitk=1)
-            assert torch.equal(base.cpu(), outs[0]), (M, N, K)
+            def make_dbase():
+                base = torch.empty(M, N, device="cuda")
+                hip.gemm(ap, Wp, base, prec=4, workspace=ws, cfg=1, splitk=1)
+                return base.cpu()
+            assert torch.equal(_case(("dense-base", M, N, K), make_dbase), outs[0]), (M, N, K)
 
 
-@pytest.mark.parametrize("cfg", [0] + list(_hip.gemm_configs(_hip.EPI_STORE)))
-@pytest.mark.parametrize("splitk", [0, 1, 3])
+@pytest.mark.parametrize("cfg,splitk", cfg_splitk_matrix([0] + list(_hip.gemm_configs(_hip.EPI_STORE)), (0, 1, 3)))
 def test_gemm_groupnorm_statistics(hip, cfg, splitk):
     """mvd_gemm_desc.gn_stats: the GEMM (tile epilogue or split-K reduce) emits the GroupNorm statistics of its output as integer
     atomics; mvd_groupnorm_from_stats must then reproduce F.group_norm of the stored output, and the statistics must be identical
@@ -335,13 +348,15 @@ def test_gemm_groupnorm_statistics(hip, cfg, splitk):
     ws = torch.empty(16 * 1024 * 1024, device="cuda")
     for B, HW, N, K in [(2, 256, 320, 320), (3, 64, 640, 1344), (2, 16, 1280, 96), (1, 1024, 96, 64), (4, 16, 32, 32)]:
         M = B * HW
-        a = torch.randn(M, K, generator=g(50)) + 0.1
-        w = torch.randn(N, K, generator=g(51)) / math.sqrt(K)
-        b = torch.randn(N, generator=g(52))
-        r = torch.randn(M, N, generator=g(53))
-        gm, bt = torch.randn(N, generator=g(54)), torch.randn(N, generator=g(55))
-        Wp = hip.pack_linear(w.cuda(), b.cuda())
-        ap, rc, gc, bc = hip.split_planes(a.cuda()), r.cuda(), gm.cuda(), bt.cuda()
+
+        def make_gn():
+            a = torch.randn(M, K, generator=g(50)) + 0.1
+            w = torch.randn(N, K, generator=g(51)) / math.sqrt(K)
+            b = torch.randn(N, generator=g(52))
+            r = torch.randn(M, N, generator=g(53))
+            gm, bt = torch.randn(N, generator=g(54)), torch.randn(N, generator=g(55))
+            return (a @ w.t() + b + r, gm, bt, hip.pack_linear(w.cuda(), b.cuda()), hip.split_planes(a.cuda()), r.cuda(), gm.cuda(), bt.cuda())
+        lin, gm, bt, Wp, ap, rc, gc, bc = _case(("gn", B, HW, N, K), make_gn)
         stats = []
         for rep in range(2):
             out = torch.full((M, N), float("nan"), device="cuda")
@@ -349,7 +364,7 @@ def test_gemm_groupnorm_statistics(hip, cfg, splitk):
             hip.gemm(ap, Wp, out, prec=4, workspace=ws, cfg=cfg, splitk=splitk, res=rc, gn_stats=st, gn_hw=HW)
             stats.append(st.cpu())
         assert torch.equal(stats[0], stats[1])
-        assert rel_err(out, a @ w.t() + b + r) < TOL[4]
+        assert rel_err(out, lin) < TOL[4]
         x = out.cpu().view(B, HW, N)
         xg = x.double().view(B, HW, 32, N // 32)
         sums = torch.stack([xg.sum(dim=(1, 3)), (xg * xg).sum(dim=(1, 3))], -1)
@@ -857,9 +872,8 @@ def test_cfg_ddim_update_golden(hip):
 
 
 def test_weight_prefetch_requests_change_nothing():
-    """mvd_gemm_desc.pf_items (the role-split kernel's consumer wavefronts request the weights of later launches) and mvd_weight_prefetch
-    (the same from a kernel of its own, paced by mvd_gemm_desc.progress): both only READ -- outputs bit-identical with and without, the
-    weights untouched, the launch counter = number of GEMM launches, and the stand-alone kernel terminates when the step stops early."""
+    """mvd_gemm_desc.pf_items (the role-split kernel's consumer wavefronts request the weights of later launches) only READS: outputs
+    bit-identical with and without, the weights untouched."""
     from mvdfusion_amd import hip
     M, N, K = 1024, 320, 640
     A = hip.split_planes(torch.randn(M, K, generator=g(1)).cuda())
@@ -876,28 +890,13 @@ def test_weight_prefetch_requests_change_nothing():
         return [o.clone() for o in outs]
 
     ref = run()
-    progress = torch.zeros(4, dtype=torch.int32, device="cuda")
-    for mode in ("ws", "branch"):
-        pf = hip.WeightPrefetcher(progress, mode=mode, blocks=4, spin_limit=2000)
-        with pf.following(record=True):
-            run()
-        assert len(pf.seq) == 4 and [e[2] for e in pf.seq] == [True, False, False, True]
-        if mode == "ws":       # launch 0 hosts the weights of launches 1 .. 3, launch 3 (the last) nothing
-            assert pf.shares == {0: (0, 3)} and [it[3] for it in pf.items] == [1, 2, 3]
-        else:
-            assert [it[3] for it in pf.items] == [0, 1, 2, 3] and all(it[2] <= it[3] for it in pf.items)
-        progress.zero_()
-        side = torch.cuda.Stream()
-        if mode == "branch":
-            with torch.cuda.stream(side):
-                pf.launch()
-        with pf.following():
-            got = run()
-        side.synchronize()
-        assert all(torch.equal(a, b) for a, b in zip(got, ref)), mode
-        assert all(torch.equal(w.data, k) for w, k in zip(Ws, keep)), mode
-        assert int(progress[0]) == (4 if mode == "branch" else 0)
-    # a step that launches fewer GEMMs than the table lists: the kernel gives up after spin_limit polls instead of hanging
-    progress.zero_()
-    pf.launch()
-    torch.cuda.synchronize()
+    pf = hip.WeightPrefetcher(A.device)
+    with pf.following(record=True):
+        run()
+    assert len(pf.seq) == 4 and [e[2] for e in pf.seq] == [True, False, False, True]
+    # launch 0 hosts the weights of launches 1 .. 3, launch 3 (the last) nothing
+    assert pf.shares == {0: (0, 3)} and [it[3] for it in pf.items] == [1, 2, 3]
+    with pf.following():
+        got = run()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    assert all(torch.equal(w.data, k) for w, k in zip(Ws, keep))

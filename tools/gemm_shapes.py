@@ -8,7 +8,7 @@ from mvdfusion_amd import hip
 
 def main():
     V, S, D, cfg_scale = int(os.environ.get("V", 4)), int(os.environ.get("S", 32)), 1, 2.5
-    m, sd = bench.build(V, S, D, "f16x4")
+    m, sd = bench.build(V, S, D, os.environ.get("PREC", "f16x3"))
     eng, inp, dn, sn = bench.prepare(m, V, S, D, cfg_scale)
     bench.run_steps(eng, 2, cfg_scale, None, True)      # tunes + captures
     torch.cuda.synchronize()
