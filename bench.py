@@ -16,7 +16,7 @@ Weights: deterministic non-zero synthetic fill of the real architecture (no chec
 Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel family, HIP-event timed, algorithmic FLOPs
 against the dense 16-bit MFMA peak), `roofline_groups` (attention, GroupNorm, LayerNorm, GridAttn aggregation) and
 `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
-Environment: MVD_PREFETCH=ws|branch|0 (weight prefetch of the captured step; `config.weight_prefetch` records it), MVD_HIP_LIB=<.so>
+Environment: MVD_PREFETCH=ws|0 (weight prefetch of the captured step; `config.weight_prefetch` records it), MVD_HIP_LIB=<.so>
 (another build of the same ABI, tools/probes/ab_build.sh: same-box A/B runs), MVD_BENCH_DUMP_GEMMS=<file> (one line per mvd_gemm launch of
 the eager profile pass: kernel, shape, microseconds -- the tool that found round 5's occupancy regression).
 """
@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_16BIT_DENSE_PEAK = 2.5e15  # FLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (dense; not the 2:1-sparse figure)
 HBM_PEAK = 8.0e12               # B/s (spec; ~6.3 TB/s achievable), same guide
-ROUND = "r05"
+ROUND = "r06"
 
 
 def log(*a):
@@ -58,11 +58,10 @@ def weight_prefetch_label():
     """How the captured step prefetches weights (mvdfusion_amd/viewfusion_zero_depth_rgb.py: MVD_PREFETCH)."""
     from mvdfusion_amd import viewfusion_zero_depth_rgb as vf
     mode = vf.PREFETCH_WEIGHTS
-    if mode not in ("ws", "branch"):
+    if mode != "ws":
         return "off"
     opts = ",".join(f"{k}={v}" for k, v in sorted(vf.PREFETCH_OPTIONS.items()))
-    return {"ws": "in-kernel (role-split consumer wavefronts request the following launches' weights)",
-            "branch": "prefetch kernel on a parallel graph branch"}[mode] + (f" [{opts}]" if opts else "")
+    return "in-kernel (role-split consumer wavefronts request the following launches' weights)" + (f" [{opts}]" if opts else "")
 
 
 def build(V, S, D, precision, sd=None):
@@ -301,6 +300,8 @@ def spawn_ranks(n):
     import socket
     import subprocess
     ndev = torch.cuda.device_count()
+    if "--dry-run" in sys.argv:
+        ndev = n
     if ndev < n and not os.environ.get("MVD_DIST_SHARE_GPU"):      # (MVD_DIST_SHARE_GPU=1: ranks share devices -- functional tests only, never a measurement)
         print(f"bench.py: --gpus {n} needs {n} GPUs on this node, found {ndev}; refusing to measure fewer devices than requested",
               file=sys.stderr, flush=True)
@@ -315,9 +316,71 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def dry_run(a):
+    """`bench.py --gpus N --dry-run`: the PLUMBING of the N-rank job without a GPU -- rank environment, process group
+    (gloo), view partition (uniform or ragged), the per-step exchange, the barrier-bracketed timed region, max over ranks, rank 0's JSON line
+    with the contract's keys.  The per-rank compute is a toy update of the rank's own latent rows; the printed value is NOT a measurement
+    (`data` says so).  tests/test_cpu_distributed.py runs it at N = 8 so that the first real 8-GPU launch cannot fail on plumbing."""
+    from mvdfusion_amd import synthetic as syn
+    from mvdfusion_amd.parallel import ViewExchange
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if a.gpus > 1 and a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.set_num_threads(1)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = max(a.gpus, world) if world > 1 else 1
+    V = a.views or (4 if N == 1 else 8)
+    S, D = a.latent, a.depth_samples
+    ex = ViewExchange(V) if world > 1 else None
+    q0, Vq = (ex.q0, ex.Vq) if ex else (0, V)
+    inp = syn.make_inputs(V, S, seed=0)
+    dn, sn = syn.step_noise(V, S, D, 50, seed=0)
+    x = inp["x_T"].clone()
+
+    def steps(n, i0):
+        for i in range(i0, i0 + n):
+            new = 0.5 * x + 0.25 * torch.tanh(x.mean(dim=0, keepdim=True)) + 0.1 * sn[i % 50]
+            x[q0:q0 + Vq] = new[q0:q0 + Vq]
+            if ex is not None:
+                ex.gather(x)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+    steps(a.warmup, 0)
+    sync()
+    t0 = time.perf_counter()
+    steps(a.steps, a.warmup)
+    sync()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    chk = x.double().sum().reshape(1)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert float(lo) == float(hi), "ranks disagree on the replicated latents"
+    dt = float(t)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "denoising-steps/sec", "value": a.steps / dt, "unit": "steps/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "rccl_ranks": 0, "scaling": "strong", "vs_baseline": None,
+            "dtype": "none (dry run)", "data": "DRY RUN: no GPU work, plumbing rehearsal on gloo -- not a measurement",
+            "dry_run": True, "checksum": float(chk),
+            "config": {"workload": workload_label(V, S, D, N, 2.5), "views": V, "latent": S, "depth_samples": D,
+                       "parallelism": f"view-parallel: {V} views over {N} ranks " + str([r[1] for r in ex.ranges] if ex else [V]) +
+                                      ", 1 all-gather of latent rows per step over torch.distributed backend gloo"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-run", action="store_true", help="plumbing rehearsal of the N-rank job on CPU / gloo (no GPU, no measurement)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--views", type=int, default=None)
@@ -350,6 +413,8 @@ def main():
                     "--steps", str(min(a.steps, 5))]
         return bench_train.main()
 
+    if a.dry_run and (a.gpus == 1 or "WORLD_SIZE" in os.environ):
+        return dry_run(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU, RCCL) -- never measure one GPU and call it N
         return spawn_ranks(a.gpus)
@@ -445,7 +510,8 @@ def main():
                        "parallelism": "single GPU, CFG pair batched as 2V" if N == 1 else
                        f"view-parallel: {V} views over {N} GPUs, 1 all-gather of latent rows per step over "
                        f"{'RCCL (torch.distributed backend nccl)' if backend == 'nccl' else 'torch.distributed backend ' + str(backend)}",
-                       "hipgraph": graph, "weight_prefetch": weight_prefetch_label()},
+                       "hipgraph": graph, "weight_prefetch": weight_prefetch_label(),
+                       "gemm_tuning": f"{hip.TUNED_SOURCE}; {hip.TUNED_IN_RUN} problems tuned in this run"},
             "gpu_ms_per_step_hip_events": gpu_ms,
             "algorithmic_tflop_per_step": step_flops / 1e12,
             "algorithmic_tflops": step_flops / (dt / a.steps) / 1e12,
@@ -483,7 +549,7 @@ def main():
                         "omitted (re-run tools/pmc_traffic.sh)")
         # family figure: every GEMM-family kernel of the PMC passes (same workload; the tuner's per-shape picks differ a little from run to
         # run, so the per-variant match below may be partial -- `traffic_launch_coverage` -- while the family average stays comparable)
-        fam = [v for kk, v in pmc.items() if kk.startswith(("gemm_kernel", "gemm_ws_kernel", "conv_patch_kernel", "gemm_pt_kernel"))]
+        fam = [v for kk, v in pmc.items() if kk.startswith(("gemm_kernel", "gemm_ws_kernel", "conv_patch_kernel"))]
         fam_n = sum(v["launches_profiled"] for v in fam)
         fam_traffic = sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in fam) / fam_n if fam_n else None
         variants, tr_sum, tr_n = [], 0.0, 0

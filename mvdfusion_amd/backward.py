@@ -65,7 +65,11 @@ def _pow2_scale(t):
     scaled into the normal range before the split and the result is scaled back -- both exact (powers of two), both on the device:
     no host synchronisation.  One launch (mvd_pow2_scale; it was eight small torch kernels, 984 times per training step)."""
     t = t if t.is_contiguous() else t.contiguous()
-    key = str(t.device)
+    if t.data_ptr() % 16:           # (ADVICE r05) a contiguous slice at a storage offset that is not a multiple of 4 floats: the kernel reads float4
+        t = t.clone()
+    # the {running maximum, arrival counter} words are shared by the calls of ONE stream (the kernel re-zeroes them when it finishes and a
+    # stream runs its kernels in order); another stream of the same device gets its own pair (ADVICE r05)
+    key = (str(t.device), torch.cuda.current_stream(t.device).cuda_stream)
     scratch = _POW2_SCRATCH.get(key)
     if scratch is None:
         scratch = _POW2_SCRATCH[key] = torch.zeros(2, dtype=torch.int32, device=t.device)

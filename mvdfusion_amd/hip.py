@@ -158,6 +158,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         assert l.mvd_operand_format() == {"f16": 0xf16, "bf16": 0xbf16}[OPERAND_FORMAT]
         _lib = l
+        load_default_tuned()
     return _lib
 
 
@@ -510,6 +511,8 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
         if tuned is None and AUTOTUNE and 2.0 * d.M * d.N * d.K >= AUTOTUNE_MIN_FLOPS:
             tuned = _autotune(d, A if A.is_contiguous() else None, W_data=W.data if not isinstance(W, PlanesOperand) else None)
             _TUNED[key] = tuned
+            global TUNED_IN_RUN
+            TUNED_IN_RUN += 1
         if tuned is not None:
             cfg, d.splitk = tuned
     d.cfg = cfg or 0
@@ -615,7 +618,7 @@ class WeightPrefetcher:
 # mvd_gemm_desc.cfg = 1 + CFG_STRIDE * tile + 2 * loop + order (include/mvd_hip.h: MVD_GEMM_CFG_STRIDE)
 CFG_STRIDE = 32
 GNA_SILU, GNA_ROUND_F16, GNA_OUT_UNUSED = 1, 2, 4      # mvd_gemm_desc.gna_flags
-TUNE_CACHE_VERSION = 10            # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
+TUNE_CACHE_VERSION = 11            # bump when the cfg encoding or the tuner's problem key changes (save_tuned / load_tuned)
 GEMM_TILES = ((64, 64, 2, 2), (128, 128, 2, 4), (128, 80, 4, 1), (64, 80, 4, 1), (128, 160, 4, 2))     # BM, BN, WM, WN
 GEMM_LOOPS = (2, 3, 4, None, 6, 7, "patch", "ws")  # template STAGES of gemm_kernel: 2 = plain, 3 = register-pipelined, 4 = staggered wave
                                  # groups (3 LDS buffers), 6 / 7 = register-pipelined over a ring of <= 4 / <= 8 LDS buffers; "patch" = conv_patch_kernel
@@ -678,23 +681,78 @@ def kernel_symbol(cfg, prec, conv):
     return f"gemm_kernel<{bm}, {bn}, {wm}, {wn}, {prec}, {1 if conv else 0}, {GEMM_LOOPS[loop]}>"
 
 
-def save_tuned(path):
+def gemm_fingerprint():
+    """sha256 over the sources that decide how fast each GEMM configuration runs (the GEMM kernels, their shared device code, the header's
+    cfg encoding): a tuner cache records it, and a cache measured on other kernels is not used (the problems are re-tuned in the run)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    pats = ("mvdfusion_amd/csrc/gemm*.hip", "mvdfusion_amd/csrc/gemm*.hpp", "mvdfusion_amd/csrc/common.hpp", "include/mvd_hip.h")
+    for f in sorted(f for pat in pats for f in glob.glob(os.path.join(root, pat))):
+        h.update(os.path.relpath(f, root).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def default_tuned_path(fmt=None):
+    """The COMMITTED tuner choices of the BASELINE workloads (tools/tune_all.py writes them on a GPU box): loaded when the library is, so
+    that the driver's bench run, the step traces and the counter passes of profiles/ all launch ONE kernel mix."""
+    return os.path.join(_HERE, "tuned", f"gemm_{fmt or OPERAND_FORMAT}.json")
+
+
+TUNED_IN_RUN = 0          # problems the tuner timed in this process (0 = every problem came from the cache)
+TUNED_SOURCE = None       # what load_default_tuned() did (bench.py prints it: config.gemm_tuning)
+
+
+def load_default_tuned():
+    """MVD_TUNE_CACHE=0: none (every problem is tuned in the run); MVD_TUNE_CACHE=<file>: that file; default: default_tuned_path()."""
+    global TUNED_SOURCE
+    env = os.environ.get("MVD_TUNE_CACHE", "")
+    if env == "0":
+        TUNED_SOURCE = "none (MVD_TUNE_CACHE=0): tuned in this run"
+        return 0
+    path = env or default_tuned_path()
+    if not os.path.exists(path):
+        TUNED_SOURCE = f"none ({os.path.relpath(path, os.path.dirname(_HERE))} missing): tuned in this run"
+        return 0
+    n = load_tuned(path, require_fingerprint=True)
+    rel = os.path.relpath(path, os.path.dirname(_HERE))
+    TUNED_SOURCE = f"{rel}: {n} problems" if n else f"none ({rel} was tuned on other GEMM sources or another cfg encoding): tuned in this run"
+    return n
+
+
+def save_tuned(path, merge=False):
     """Persist the autotuner's choices (problem key -> (cfg, splitk)) so that separate processes -- the bench run and the rocprofv3
-    counter passes of one profiling session -- launch identical kernels."""
+    counter passes of one profiling session -- launch identical kernels.  merge: keep the entries of an existing file of the same
+    encoding AND the same GEMM sources for problems this process did not meet."""
     import json
+    entries = {}
+    if merge and os.path.exists(path):
+        doc = json.load(open(path))
+        if _tuned_doc_ok(doc) and doc.get("gemm_fingerprint") == gemm_fingerprint():
+            entries = {tuple(k): tuple(v) for k, v in doc["entries"]}
+    entries.update(_TUNED)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
         json.dump({"version": TUNE_CACHE_VERSION, "cfg_stride": CFG_STRIDE, "operand_format": OPERAND_FORMAT,
-                   "entries": [[list(k), list(v)] for k, v in _TUNED.items()]}, f)
+                   "gemm_fingerprint": gemm_fingerprint(),
+                   "entries": sorted([list(k), list(v)] for k, v in entries.items())}, f, indent=0)
 
 
-def load_tuned(path):
+def _tuned_doc_ok(doc):
+    return isinstance(doc, dict) and doc.get("version") == TUNE_CACHE_VERSION and doc.get("cfg_stride") == CFG_STRIDE and \
+        doc.get("operand_format") == OPERAND_FORMAT
+
+
+def load_tuned(path, require_fingerprint=False):
     """Load a cache written by save_tuned.  A file of another encoding (version / cfg stride / operand format) is REJECTED as a whole,
     and entries whose cfg is not a valid configuration of this build are dropped (an old cache must never launch the wrong
-    kernels silently).  Returns the number of entries taken."""
+    kernels silently).  require_fingerprint: also reject a file measured on other GEMM sources (gemm_fingerprint).  Returns the number of
+    entries taken."""
     import json
     doc = json.load(open(path))
-    if not isinstance(doc, dict) or doc.get("version") != TUNE_CACHE_VERSION or doc.get("cfg_stride") != CFG_STRIDE or \
-            doc.get("operand_format") != OPERAND_FORMAT:
+    if not _tuned_doc_ok(doc) or (require_fingerprint and doc.get("gemm_fingerprint") != gemm_fingerprint()):
         return 0
     n = 0
     for k, v in doc["entries"]:
@@ -714,6 +772,7 @@ _TUNED = {}
 
 
 _TRASH = None
+TUNE_SPLITS = os.environ.get("MVD_TUNE_SPLITS") == "1"      # the tuner also times explicit split-K counts (see _autotune)
 TUNE_COLD = True          # time the candidates with COLD weights (see _autotune)
 
 
@@ -759,8 +818,10 @@ def _autotune(d, A=None, reps=4, trials=int(os.environ.get("MVD_TUNE_TRIALS", "3
     # they stay built, tested (test_gemm_configurations_agree) and selectable by cfg.  MVD_TUNE_EXCLUDE_LOOPS: A/B measurements.
     skip = set()
     skip |= {int(t) for t in os.environ.get("MVD_TUNE_EXCLUDE_LOOPS", "").split(",") if t}      # (e.g. "7" = no role-split kernel)
+    fixed_split = d.splitk
     cands = [(c, sk) for c in gemm_configs(d.epi, d.b_mode, conv=d.a_mode == A_CONV3X3) if cfg_supported(d, c) and _cfg_parts(c)[1] not in skip
              for sk in ((0, 1) if d.splitk == 0 else (d.splitk,))]
+    timed, second_pass = [], False
     # three cold copies of the packed weight, launched back to back between one pair of events: the eager launch latency (a few us
     # of jitter, the size of the differences being ranked) is paid once per three kernels and hides behind the first one
     wp0 = d.Wp
@@ -795,8 +856,17 @@ def _autotune(d, A=None, reps=4, trials=int(os.environ.get("MVD_TUNE_TRIALS", "3
         # launches does not see): it has to win by that margin
         if sk != 1:
             ms += 0.0015
+        timed.append((ms, cfg, sk))
         if ms < best_ms * 0.99:
             best, best_ms = (cfg, sk), ms
+        if len(timed) == len(cands) and TUNE_SPLITS and fixed_split == 0 and not second_pass:
+            second_pass = True
+            # second pass (tools/tune_all.py: the committed cache): explicit split-K counts around the library's model for the three fastest
+            # configurations -- the model is analytic (csrc/gemm.hip: choose_splits) and the low-resolution levels live on it
+            nk = d.K // 32
+            extra = [s_ for s_ in (2, 3, 4, 6, 8, 12, 16, 24, 32) if s_ <= max(1, nk // 2)]
+            top = sorted(timed)[:3]
+            cands.extend((c, s_) for _, c, _ in top for s_ in extra if (c, s_) not in cands)
     d.gn_stats = stats_ptr
     return best
 

@@ -4,7 +4,9 @@
 written by either load into the other (train.py:150,178); only `step()` differs: instead of torch's multi-tensor passes over the 1 G trainable
 parameters (~8 kernel kinds, 25 ms) one `mvd_adamw_multi` launch applies the same update (include/mvd_hip.h) -- weight decay, lerp of
 exp_avg, exp_avg_sq, bias corrections, addcdiv -- reading parameter, gradient and both moments once and writing three.  Parameters that are
-not fp32 CUDA tensors, sparse gradients, amsgrad / maximize / capturable / differentiable settings: the whole step falls back to torch's."""
+not fp32 CUDA tensors, sparse gradients, amsgrad / maximize / capturable / differentiable / fused / foreach=True settings: the whole step
+falls back to torch's.  "The same update" = the same formula; the kernel evaluates lr / bias_correction1 and the decay factor in fp32 where
+torch's single-tensor path uses Python doubles, so the two agree to a few ulp (tests/test_gpu_backward.py: 2e-7 relative), not bitwise."""
 import ctypes as C
 import math
 
@@ -22,7 +24,10 @@ class _AdamwTensor(C.Structure):
 
 class HipAdamW(torch.optim.AdamW):
     def _plain(self, group):
-        return not (group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable"))
+        # (fused=True keeps state['step'] on the device and foreach=True asks for torch's multi-tensor path by name: both are
+        #  torch's to run)
+        return not (group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable") or
+                    group.get("fused") or group.get("foreach"))
 
     @torch.no_grad()
     def step(self, closure=None):

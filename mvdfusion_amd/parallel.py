@@ -34,6 +34,7 @@ class ViewExchange:
             raise ValueError(f"view-parallel sharding needs world_size <= V (world {self.world}, V {V}): rank {self.rank} "
                              "would own no view")
         self.uniform = len({n for _, n in self.ranges}) == 1
+        self._stage = None          # ragged shards: (world, max Vq, ...) staging buffer of the one padded all-gather
 
     def gather(self, x_full, force=False):
         """x_full (V, ...) holds this rank's fresh rows at [q0, q0+Vq); on return every rank holds all rows.
@@ -47,11 +48,20 @@ class ViewExchange:
         assert x_full.is_contiguous()
         if self.uniform:
             dist.all_gather_into_tensor(x_full, x_full[self.q0:self.q0 + self.Vq], group=self.group)
-        else:                                                      # ragged: broadcast each block from its owner
+        else:
+            # ragged (V = 15 over 8 ranks: 2,2,2,2,2,2,2,1): still ONE collective -- every rank's rows padded to the largest shard in a
+            # (world, max Vq, ...) staging buffer, gathered in place, then the peers' rows copied to their places (round 6; it was one
+            # broadcast per rank: 8 latency-bound collectives per step)
+            vmax = max(n for _, n in self.ranges)
+            shape = (self.world, vmax) + tuple(x_full.shape[1:])
+            if self._stage is None or self._stage.shape != shape or self._stage.device != x_full.device or self._stage.dtype != x_full.dtype:
+                self._stage = torch.zeros(shape, dtype=x_full.dtype, device=x_full.device)
+            st = self._stage
+            st[self.rank, :self.Vq].copy_(x_full[self.q0:self.q0 + self.Vq])
+            dist.all_gather_into_tensor(st.view((self.world * vmax,) + tuple(x_full.shape[1:])), st[self.rank], group=self.group)
             for r, (a, n) in enumerate(self.ranges):
-                if n:
-                    dist.broadcast(x_full[a:a + n], src=dist.get_global_rank(self.group, r) if self.group else r,
-                                   group=self.group)
+                if r != self.rank:
+                    x_full[a:a + n].copy_(st[r, :n])
         return x_full
 
 

@@ -235,15 +235,33 @@ class _HipTrainingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        # the gradients are this step's own buffers: scale them in place with multi-tensor launches (994 separate multiplies were 15 ms)
-        live, seen = [], set()
+        # the gradients are this step's own buffers: scale them in place with multi-tensor launches (994 separate multiplies were 15 ms).
+        #  in place is only safe ONCE and only over disjoint buffers: a second backward over the same node (retain_graph=True)
+        # must not scale again, and two gradients that overlap without being the same view take the out-of-place path.
+        if getattr(ctx, "_scaled", False):
+            raise RuntimeError("_HipTrainingLoss.backward ran twice on one node: the step's gradient buffers were already scaled in place "
+                               "(call model(batch, cfg) again instead of retain_graph=True)")
+        ctx._scaled = True
+        live, seen, spans = [], set(), []
         for g in ctx.grads:
-            if g is not None and g.data_ptr() not in seen:      # (a buffer shared by two names is scaled once)
-                seen.add(g.data_ptr())
-                live.append(g)
-        if live:
+            if g is None:
+                continue
+            key = (g.untyped_storage().data_ptr(), g.storage_offset(), tuple(g.shape), tuple(g.stride()))
+            if key in seen:                                      # (a buffer shared by two names is scaled once)
+                continue
+            seen.add(key)
+            live.append(g)
+            spans.append((g.data_ptr(), g.data_ptr() + g.numel() * g.element_size()) if g.is_contiguous() else None)
+        disjoint = all(sp is not None for sp in spans)
+        if disjoint:
+            srt = sorted(spans)
+            disjoint = all(srt[i][1] <= srt[i + 1][0] for i in range(len(srt) - 1))
+        if live and disjoint:
             torch._foreach_mul_(live, grad_out.to(live[0].dtype))
-        outs = [torch.zeros(s, dtype=grad_out.dtype, device=grad_out.device) if g is None else g.reshape(s)
+            pick = lambda g: g
+        else:                                                     # overlapping / strided views: the safe out-of-place multiply per name
+            pick = lambda g: g * grad_out.to(g.dtype)
+        outs = [torch.zeros(s, dtype=grad_out.dtype, device=grad_out.device) if g is None else pick(g).reshape(s)
                 for g, s in zip(ctx.grads, ctx.shapes)]
         return (None, None, None, None, *outs)
 

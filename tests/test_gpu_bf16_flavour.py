@@ -22,13 +22,19 @@ def _run(args, timeout=1500):
 
 
 def test_bf16_flavour_op_tests():
+    """Every kernel of libmvd_hip_bf16.so against the op references (the whole op file: 40 s; the cfg matrices are thinned like the default
+    flavour's unless MVD_TEST_FULL=1)."""
     out = _run([os.path.join("tests", "test_gpu_ops.py")])
     assert " passed" in out and "failed" not in out, out[-800:]
 
 
 def test_bf16_flavour_denoise_step_and_gridattn_goldens():
-    out = _run([os.path.join("tests", "test_gpu_model.py"), "-k",
-                "test_denoise_step_vs_reference_golden or test_gridattn_vs_reference_golden or test_graph_replay_equals_eager"])
+    """One full-width and one reduced-width denoising step, the fused GridAttn at V = 4 and V = 15 and the graph replay, against the
+    reference's goldens in the bf16 flavour (MVD_TEST_FULL=1: every step / GridAttn golden, 95 s)."""
+    from conftest import FULL
+    k = "test_denoise_step_vs_reference_golden or test_gridattn_vs_reference_golden or test_graph_replay_equals_eager" if FULL else \
+        "step_mc320_v4_d1-320 or step_mc32_v4_d1-32 or gridattn_v4_d1-4 or gridattn_v15_d1 or test_graph_replay_equals_eager"
+    out = _run([os.path.join("tests", "test_gpu_model.py"), "-k", k])
     assert " passed" in out and "failed" not in out, out[-800:]
     import ctypes
     from mvdfusion_amd import hip
