@@ -69,7 +69,8 @@ def build(V, S, D, precision, sd=None):
     from mvdfusion_amd.configs import model_config
     from mvdfusion_amd.viewfusion_zero_depth_rgb import ViewFusion
     t0 = time.time()
-    m = ViewFusion(**model_config(320, D=D, S=S, precision=precision))
+    with syn.skip_default_init():      # (the fill / load_state_dict below overwrites every parameter)
+        m = ViewFusion(**model_config(320, D=D, S=S, precision=precision))
     if sd is None:      # deterministic non-zero fill keyed by the parameter names (the reference zero-inits every residual branch: SURVEY T1)
         syn.fill_module_(m)
         sd = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.startswith("scheduler.")}

@@ -442,6 +442,12 @@ int mvd_groupnorm_backward(const float* x, const float* dy, const float* gamma, 
  * dw = mvd_col_sum(dyxhat), db = mvd_col_sum(dy).  dyxhat may be null. */
 int mvd_layernorm_backward(const float* x, const float* dy, const float* w, int rows, int C, float eps, float* dx, float* dyxhat,
                            mvd_stream_t stream);
+/* Activations of the training step (viewfusion_zero_depth_rgb.py:362-397 -> view_attn_efficient2.py:42-67 DiTBlock / Mlp, pre_layer_b):
+ * mvd_act_planes: y = act(x), act = MVD_ACT_GELU (exact erf) or MVD_ACT_SILU, of the fp32 matrix x (rows, cols; leading dim ldx) as split
+ * planes (sp, ldp % 32 == 0, padded columns zero; NULL = none) and / or fp32 (y, leading dim ldy; NULL = none) in one pass.
+ * mvd_act_backward: dx[i] = dy[i] * act'(x[i]) over n elements (dx may alias dy). */
+int mvd_act_planes(const float* x, void* sp, float* y, size_t rows, int cols, int ldx, int ldp, int ldy, int act, mvd_stream_t stream);
+int mvd_act_backward(const float* dy, const float* x, float* dx, size_t n, int act, mvd_stream_t stream);
 /* Backward of GEGLU y = a * gelu(g), [a | g] = h (rows, 2*half) (sd1 attention.py:43-44): dh (rows, 2*half). */
 int mvd_geglu_backward(const float* h, const float* dy, int rows, int half, float* dh, mvd_stream_t stream);
 /* Backward of the self-attention core softmax(Q K^T / sqrt(d)) V per (batch, head); q, k, v, dout, dq, dk, dv: token-major

@@ -56,6 +56,28 @@ def col_sum(x, rows, cols):
     return out
 
 
+def act_planes(x, act, planes=True, f32=False):
+    """act(x) of the fp32 matrix x (rows, cols) in one pass: (split planes (rows, 2 * ceil32(cols)) | None, fp32 (rows, cols) | None)
+    (mvd_act_planes; act = hip.ACT_GELU / hip.ACT_SILU)."""
+    x = x if x.is_contiguous() else x.contiguous()
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    ldp = _pad32(cols)
+    sp = hip.planes_like(rows, ldp, x.device) if planes else None
+    y = torch.empty(rows, cols, dtype=torch.float32, device=x.device) if f32 else None
+    hip.check(hip.lib().mvd_act_planes(hip.ptr(x), hip.ptr(sp), hip.ptr(y), rows, cols, cols, ldp, cols, int(act), hip.stream()))
+    return sp, y
+
+
+def act_backward(dy, x, act):
+    """dy * act'(x), elementwise, one pass (mvd_act_backward)."""
+    dy = dy if dy.is_contiguous() else dy.contiguous()
+    x = x if x.is_contiguous() else x.contiguous()
+    assert dy.shape == x.shape and dy.dtype == x.dtype == torch.float32
+    out = torch.empty_like(dy)
+    hip.check(hip.lib().mvd_act_backward(hip.ptr(dy), hip.ptr(x), hip.ptr(out), dy.numel(), int(act), hip.stream()))
+    return out
+
+
 _POW2_SCRATCH = {}
 
 

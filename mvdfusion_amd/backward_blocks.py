@@ -31,11 +31,13 @@ class Tape:
     def planes(self, x):
         return hip.split_planes(x.contiguous())
 
-    def linear(self, a_planes, weight, bias=None, res=None, M=None):
+    def linear(self, a_planes, weight, bias=None, res=None, M=None, colscale=None):
+        """res + colscale * (A W^T + bias) (colscale: per-column gate, e.g. adaLN's g1 / g2; needs N % 16 == 0)."""
         w = hip.pack_linear(weight, bias)
         M = a_planes.shape[0] if M is None else M
         out = torch.empty(M, w.N, dtype=torch.float32, device=self.device)
-        hip.gemm(a_planes, w, out, prec=self.prec, res=res, workspace=self.ws)
+        assert colscale is None or w.N == weight.shape[0]
+        hip.gemm(a_planes, w, out, prec=self.prec, res=res, workspace=self.ws, colscale=colscale)
         return out[:, :weight.shape[0]] if w.N != weight.shape[0] else out
 
     def conv3x3(self, a_planes, weight, bias, B, H, W, res=None):

@@ -52,13 +52,13 @@ def _dit_block_backward(tape, blk, h, c, dh2, T, V):
     m2 = hip.planes_like(T, C, dev)
     hip.layernorm(h1, m2, s2, sh2, T, C, eps=1e-6, w_plus_one=True)
     f1 = tape.linear(m2, blk.mlp.fc1.weight, blk.mlp.fc1.bias)              # pre-activation (T, hidden)
-    gel = tape.planes(F.gelu(f1))
+    gel, _ = bw.act_planes(f1, hip.ACT_GELU)                               # GELU + operand split in one pass (mvd_act_planes)
     f2 = tape.linear(gel, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
     # ---- backward
     g = {}
     dg2 = bw.col_sum((dh2 * f2).contiguous(), T, C)
     dgel, g["mlp.fc2.weight"], g["mlp.fc2.bias"] = tape.linear_bwd(gel, blk.mlp.fc2.weight, dh2 * g2)
-    dm2, g["mlp.fc1.weight"], g["mlp.fc1.bias"] = tape.linear_bwd(m2, blk.mlp.fc1.weight, dgel * _gelu_grad(f1))
+    dm2, g["mlp.fc1.weight"], g["mlp.fc1.bias"] = tape.linear_bwd(m2, blk.mlp.fc1.weight, bw.act_backward(dgel, f1, hip.ACT_GELU))
     dx, ds2, dsh2 = bw.layernorm_backward(h1.contiguous(), dm2.contiguous(), (1.0 + s2).contiguous(), 1e-6)
     dh1 = dh2 + dx
     dg1 = bw.col_sum((dh1 * a_out).contiguous(), T, C)
@@ -99,7 +99,7 @@ def gridattn_backward(ga, tape, eng, c, dvol, V, S, D):
                                     S, D, float(ga.depth_scale), float(ga.depth_shift), hip.stream()))
     pre = ga.pre_layer_b[0]
     z0 = tape.linear(tokens, pre.weight, pre.bias)                             # (T, 256) pre-activation
-    hs = [F.gelu(z0)]
+    hs = [bw.act_planes(z0, hip.ACT_GELU, planes=False, f32=True)[1]]
     for blk in agg.layer_list:
         hcur = hs[-1]
         # block output via the inference path's own kernels (DiTBlock.run mutates its buffers: use the unfused algebra here)
@@ -124,7 +124,7 @@ def gridattn_backward(ga, tape, eng, c, dvol, V, S, D):
         dh, gb, dcb = _dit_block_backward(tape, agg.layer_list[bi], hs[bi], c, dh.contiguous(), T, V)
         g.update({f"aggregation_transformer.layer_list.{bi}.{k}": v for k, v in gb.items()})
         dc += dcb
-    dtok, g["pre_layer_b.0.weight"], g["pre_layer_b.0.bias"] = tape.linear_bwd(tokens, pre.weight, dh * _gelu_grad(z0))
+    dtok, g["pre_layer_b.0.weight"], g["pre_layer_b.0.bias"] = tape.linear_bwd(tokens, pre.weight, bw.act_backward(dh, z0, hip.ACT_GELU))
     # ---- grid_sample backward into the z-embedded feature maps, then the 5 -> 256 z-embedding
     dtok = dtok.contiguous() if dtok.is_contiguous() else dtok
     base = dtok if dtok.storage_offset() == 0 else dtok.contiguous()
@@ -160,11 +160,11 @@ def _dit_forward(tape, blk, h, c, T, V):
     qkv = tape.linear(m1, blk.attn.qkv.weight, blk.attn.qkv.bias)
     att = hip.planes_like(T, C, dev)
     hip.check(hip.lib().mvd_view_mha(hip.ptr(qkv), hip.ptr(att), T // V, V, H, C // H, hip.stream()))
-    h1 = h + g1 * tape.linear(att, blk.attn.proj.weight, blk.attn.proj.bias)
+    h1 = tape.linear(att, blk.attn.proj.weight, blk.attn.proj.bias, res=h, colscale=g1)        # h + g1 * proj(att): the GEMM's own epilogue
     m2 = hip.planes_like(T, C, dev)
     hip.layernorm(h1, m2, s2, sh2, T, C, eps=1e-6, w_plus_one=True)
     f1 = tape.linear(m2, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
-    return h1 + g2 * tape.linear(tape.planes(F.gelu(f1)), blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+    return tape.linear(bw.act_planes(f1, hip.ACT_GELU)[0], blk.mlp.fc2.weight, blk.mlp.fc2.bias, res=h1, colscale=g2)
 
 
 def time_embed_backward(time_embed, t_sin, dc):

@@ -286,6 +286,50 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------- activations of the training step
+// act_planes_kernel: y = act(x) (exact erf GELU as in the forward's epilogues, or SiLU) written as split planes and / or fp32 in ONE pass
+// (the backward recomputes the DiT / pre-layer activations from the kept pre-activations: it was F.gelu + a split pass, 3 full-size
+// tensors of traffic instead of 1 read + 1 write).  act_bwd_kernel: dx = dy * act'(x) in one pass (it was ~8 torch kernels per call:
+// erf, exp, four multiplies, two adds over (T, 1024) tensors).  gelu'(x) = Phi(x) + x phi(x);  silu'(x) = s (1 + x (1 - s)).
+template <int ACT>
+__global__ __launch_bounds__(256) void act_planes_kernel(const float* __restrict__ x, u16* __restrict__ sp, float* __restrict__ y, size_t rows,
+                                                         int cols, int ldx, int ldp, int ldy) {
+  const int c4 = ldp >> 2;
+  const size_t total = rows * c4;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t r = e / c4;
+    const int c = (int)(e - r * c4) * 4;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t = (c + j) < cols ? x[r * ldx + c + j] : 0.f;
+      v[j] = ACT == MVD_ACT_GELU ? gelu_erf(t) : t / (1.0f + __expf(-t));
+    }
+    if (sp != nullptr) store_sp4(sp, r, ldp, c, v[0], v[1], v[2], v[3]);
+    if (y != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < cols) y[r * ldy + c + j] = v[j];
+    }
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const float t = x[e], d = dy[e];
+    float g;
+    if (ACT == MVD_ACT_GELU) {
+      const float cdf = 0.5f * (1.0f + erf_nobranch(t * 0.70710678118654752440f));
+      g = cdf + t * (0.3989422804014327f * __expf(-0.5f * t * t));
+    } else {
+      const float sg = 1.0f / (1.0f + __expf(-t));
+      g = sg * (1.0f + t * (1.0f - sg));
+    }
+    dx[e] = d * g;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- self-attention backward (fp32 VALU)
 // CrossAttention(context=None) core (attention.py:170-193): per (batch, head), O = softmax(Q K^T * scale) V over L tokens of width d.
 // q, k, v, o-grad are token-major (B*L, heads*d) fp32 as the forward's projections produce them.  One LDS-tiled kernel, three modes:
@@ -741,6 +785,32 @@ extern "C" int mvd_geglu_backward(const float* h, const float* dy, int rows, int
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h, dy, rows, half, dh);
   MVD_CHECK_LAUNCH("mvd_geglu_backward");
+  return 0;
+}
+
+extern "C" int mvd_act_planes(const float* x, void* sp, float* y, size_t rows, int cols, int ldx, int ldp, int ldy, int act, mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && (sp || y) && rows > 0 && cols > 0 && ldx >= cols && ldp >= cols && ldp % 32 == 0 && (!y || ldy >= cols),
+                "mvd_act_planes: bad arguments");
+  MVD_CHECK_ARG(act == MVD_ACT_GELU || act == MVD_ACT_SILU, "mvd_act_planes: act %d (GELU or SiLU)", act);
+  const size_t total = rows * (size_t)(ldp >> 2);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (act == MVD_ACT_GELU)
+    hipLaunchKernelGGL(act_planes_kernel<MVD_ACT_GELU>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (u16*)sp, y, rows, cols, ldx, ldp, ldy);
+  else
+    hipLaunchKernelGGL(act_planes_kernel<MVD_ACT_SILU>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (u16*)sp, y, rows, cols, ldx, ldp, ldy);
+  MVD_CHECK_LAUNCH("mvd_act_planes");
+  return 0;
+}
+
+extern "C" int mvd_act_backward(const float* dy, const float* x, float* dx, size_t n, int act, mvd_stream_t stream) {
+  MVD_CHECK_ARG(dy && x && dx && n > 0, "mvd_act_backward: bad arguments");
+  MVD_CHECK_ARG(act == MVD_ACT_GELU || act == MVD_ACT_SILU, "mvd_act_backward: act %d (GELU or SiLU)", act);
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (act == MVD_ACT_GELU) hipLaunchKernelGGL(act_bwd_kernel<MVD_ACT_GELU>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n);
+  else hipLaunchKernelGGL(act_bwd_kernel<MVD_ACT_SILU>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n);
+  MVD_CHECK_LAUNCH("mvd_act_backward");
   return 0;
 }
 

@@ -109,6 +109,8 @@ SIGNATURES = {
     "mvd_gridattn_tokens_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "mvd_layernorm_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "mvd_geglu_backward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "mvd_act_planes": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
+    "mvd_act_backward": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "mvd_attention_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mvd_pixel_cross_attn_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mvd_groupnorm_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -682,13 +684,14 @@ def kernel_symbol(cfg, prec, conv):
 
 
 def gemm_fingerprint():
-    """sha256 over the sources that decide how fast each GEMM configuration runs (the GEMM kernels, their shared device code, the header's
-    cfg encoding): a tuner cache records it, and a cache measured on other kernels is not used (the problems are re-tuned in the run)."""
+    """sha256 over the sources that decide how fast each GEMM configuration runs (the GEMM kernels and their shared device code; the cfg
+    ENCODING is guarded separately by TUNE_CACHE_VERSION / CFG_STRIDE): a tuner cache records it, and a cache measured on other kernels is
+    not used (the problems are re-tuned in the run)."""
     import glob
     import hashlib
     h = hashlib.sha256()
     root = os.path.dirname(_HERE)
-    pats = ("mvdfusion_amd/csrc/gemm*.hip", "mvdfusion_amd/csrc/gemm*.hpp", "mvdfusion_amd/csrc/common.hpp", "include/mvd_hip.h")
+    pats = ("mvdfusion_amd/csrc/gemm*.hip", "mvdfusion_amd/csrc/gemm*.hpp", "mvdfusion_amd/csrc/common.hpp")
     for f in sorted(f for pat in pats for f in glob.glob(os.path.join(root, pat))):
         h.update(os.path.relpath(f, root).encode())
         h.update(open(f, "rb").read())

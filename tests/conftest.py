@@ -98,7 +98,8 @@ def build_model(mc=320, D=1, S=32, precision=None):
     precision = precision or DEFAULT_PRECISION
     key = (mc, D, S, precision)
     if key not in _MODELS:
-        m = ViewFusion(**model_config(mc, D, S, precision))
+        with syn.skip_default_init():            # (every parameter is overwritten by the fill: the default initialisers are 9 s per full-width build)
+            m = ViewFusion(**model_config(mc, D, S, precision))
         syn.fill_module_(m)
         _MODELS[key] = m.cuda().eval()
     return _MODELS[key]

@@ -243,3 +243,27 @@ def test_hip_adamw_matches_torch_adamw(hip):
     assert ps[0]._version > v0                     # the raw-pointer update is visible to version-keyed caches (packed weight images)
     for p, q in zip(ps, qs):
         assert float((p - q).detach().abs().max()) <= 4e-7 * max(1.0, float(q.detach().abs().max()))
+
+
+@pytest.mark.parametrize("act", ["gelu", "silu"])
+@pytest.mark.parametrize("rows,cols", [(1000, 1024), (37, 50), (4096, 256)])
+def test_activation_forward_planes_and_backward(hip, act, rows, cols):
+    """mvd_act_planes (act(x) as operand planes and / or fp32, one pass) and mvd_act_backward (dy * act'(x)): the training step's GELU / SiLU
+    passes (view_attn_efficient2.py:42-67 Mlp / pre_layer_b) against torch (erf GELU; autograd for the derivative), ragged column counts."""
+    from mvdfusion_amd import backward as bw
+    from mvdfusion_amd import hip as H
+    code = H.ACT_GELU if act == "gelu" else H.ACT_SILU
+    fn = F.gelu if act == "gelu" else F.silu
+    x = (torch.randn(rows, cols, generator=g(7)) * 2.5).requires_grad_(True)
+    dy = torch.randn(rows, cols, generator=g(8))
+    y = fn(x)
+    y.backward(dy)
+    sp, yf = bw.act_planes(x.detach().cuda(), code, planes=True, f32=True)
+    assert rel_err(yf, y) < 2e-6
+    got = planes_to_float(sp)
+    pl = 2e-5 if H.OPERAND_FORMAT == "bf16" else 1e-6
+    assert rel_err(got[:, :cols], y) < 2e-6 + pl and (got.shape[1] == cols or float(got[:, cols:].abs().max()) == 0.0)
+    only_planes, none = bw.act_planes(x.detach().cuda(), code)
+    assert none is None and torch.equal(only_planes, sp)
+    dx = bw.act_backward(dy.cuda(), x.detach().cuda(), code)
+    assert rel_err(dx, x.grad) < 3e-6

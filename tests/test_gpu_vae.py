@@ -161,7 +161,8 @@ def test_sample_then_decode_end_to_end(V):
     cfg = model_config(32)
     cfg["vae_config"] = dict(target="external.sd1.ldm.models.autoencoder.AutoencoderKL",
                              params=dict(embed_dim=4, ddconfig=dd, lossconfig=dict(target="torch.nn.Identity")))
-    m = ViewFusion(clip_image_encoder=syn.StubClipImageEncoder(), **cfg)
+    with syn.skip_default_init():            # (the fill overwrites every parameter)
+        m = ViewFusion(clip_image_encoder=syn.StubClipImageEncoder(), **cfg)
     syn.fill_module_(m)
     m = m.cuda().eval()
     rig = syn.gso_rig()
@@ -193,7 +194,8 @@ def _training_setup(gd, mc=32, V=4, **overrides):
     cfg.update(overrides)
     cfg["vae_config"] = dict(target="external.sd1.ldm.models.autoencoder.AutoencoderKL",
                              params=dict(embed_dim=4, ddconfig=dd, lossconfig=dict(target="torch.nn.Identity")))
-    m = ViewFusion(clip_image_encoder=syn.StubClipImageEncoder(), **cfg)
+    with syn.skip_default_init():            # (the fill overwrites every parameter)
+        m = ViewFusion(clip_image_encoder=syn.StubClipImageEncoder(), **cfg)
     syn.fill_module_(m)
     m = m.cuda().train()
     assert m.drop_conditions

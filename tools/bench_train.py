@@ -37,7 +37,8 @@ def main():
     V, D, S = a.views, a.depth_samples, 32
     cfg = model_config(a.width, D=D, S=S)
     cfg["finetune_unet"] = not a.frozen_unet
-    m = ViewFusion(**cfg)
+    with syn.skip_default_init():
+        m = ViewFusion(**cfg)
     syn.fill_module_(m)
     m = m.cuda().train()
     for n, p in m.named_parameters():
