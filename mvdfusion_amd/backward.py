@@ -91,7 +91,11 @@ def _pow2_scale(t):
         t = t.clone()
     # the {running maximum, arrival counter} words are shared by the calls of ONE stream (the kernel re-zeroes them when it finishes and a
     # stream runs its kernels in order); another stream of the same device gets its own pair
-    key = (str(t.device), torch.cuda.current_stream(t.device).cuda_stream)
+    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    try:
+        key = (idx, torch._C._cuda_getCurrentRawStream(idx))          # (one C call: this runs ~1000 times per training step)
+    except AttributeError:
+        key = (idx, torch.cuda.current_stream(t.device).cuda_stream)
     scratch = _POW2_SCRATCH.get(key)
     if scratch is None:
         scratch = _POW2_SCRATCH[key] = torch.zeros(2, dtype=torch.int32, device=t.device)

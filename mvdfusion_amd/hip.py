@@ -527,6 +527,7 @@ def gemm(A, W, out=None, *, prec=PREC_X4, M=None, lda=None, bias=True, act=ACT_N
 
 
 GEMM_SEQUENCE = None      # set by a step engine around ITS launches (WeightPrefetcher.following())
+SELF_PREFETCH_MIN = int(os.environ.get("MVD_SELF_PREFETCH_MIN", "0"))      # bytes; see WeightPrefetcher (0 = off)
 
 
 class WeightPrefetcher:
@@ -540,9 +541,14 @@ class WeightPrefetcher:
     removed from the library in round 6, source under tools/probes/prefetch.hip.)
     """
 
-    def __init__(self, device, window=24 << 20, max_items=24, gn_hosts=0):
+    def __init__(self, device, window=24 << 20, max_items=24, gn_hosts=0, self_min=None):
         self.device = device
         self.window, self.max_items = int(window), int(max_items)
+        # SELF prefetch (round 6): a role-split launch whose own packed weight is at least `self_min` bytes also requests ITS OWN weight at
+        # kernel start (first item of its share, outside the window: those bytes pass through the caches in this launch anyway) -- the
+        # consumers' requests run ahead of the loaders' k-tile-by-k-tile DMAs, which then meet their lines in L2 / Infinity Cache instead
+        # of paying an HBM round trip per k-tile (the "cold weight" penalty of the low-resolution levels).  0 = off.
+        self.self_min = int(SELF_PREFETCH_MIN if self_min is None else self_min)
         # gn_hosts: the fused reduce + GroupNorm kernels of split GEMMs host prefetch shares too.  Measured (profiles/r05_prefetch_ab.log):
         # 8.25 - 8.27 ms against 8.21 - 8.24 with the role-split hosts alone (8.33 - 8.38 without any prefetch): the requests lengthen the tail
         # of a 10 us kernel by about what they save the next one.  Off by default.
@@ -600,6 +606,9 @@ class WeightPrefetcher:
             nxt = [k for k in sure if k > j]
             end = nxt[0] if nxt else len(self.seq) - 1
             first, acc, seen = len(items), 0, set()
+            if self.self_min > 0 and self.seq[j][2] == 1 and self.seq[j][1] >= self.self_min:
+                items.append((self.seq[j][0], self.seq[j][1], j, j))
+                seen.add(self.seq[j][0])
             for k in range(j + 1, end + 1):
                 ptr_, nbytes, _ = self.seq[k]
                 if not nbytes or ptr_ in seen or acc + nbytes > self.window or len(items) - first >= self.max_items:

@@ -710,7 +710,7 @@ def test_weight_prefetch_schedule():
     # launch order: (pointer, bytes, role-split kernel?); 0 bytes = an activation as B operand (never prefetched)
     seq = [(0x1000, 1 * MB, False), (0x2000, 4 * MB, True), (0x3000, 2 * MB, False), (0, 0, False), (0x3000, 2 * MB, False),
            (0x5000, 30 * MB, False), (0x6000, 3 * MB, True), (0x7000, 1 * MB, False)]
-    pf = hip.WeightPrefetcher("cpu", window=8 * MB)
+    pf = hip.WeightPrefetcher("cpu", window=8 * MB, self_min=0)
     pf.seq = list(seq)
     pf._build()
     # host 1 takes launches 2 .. 6: the repeated pointer once, the 30 MB weight not (window), its own successor host's weight yes
@@ -720,6 +720,11 @@ def test_weight_prefetch_schedule():
     assert len(raw) == 3 * ctypes.sizeof(hip.PrefetchItem) == 72
     first = hip.PrefetchItem.from_buffer_copy(raw[:24])
     assert first.ptr == 0x3000 and first.bytes == 2 * MB
+    # self prefetch: a host whose own weight is at least self_min bytes requests it first, outside the window
+    ps = hip.WeightPrefetcher("cpu", window=8 * MB, self_min=4 * MB)
+    ps.seq = list(seq)
+    ps._build()
+    assert ps.shares == {1: (0, 3), 6: (3, 1)} and [(it[0], it[3]) for it in ps.items] == [(0x2000, 1), (0x3000, 2), (0x6000, 6), (0x7000, 7)]
 
 
 def test_bench_tree_fingerprint_tracks_kernel_sources(tmp_path, monkeypatch):
