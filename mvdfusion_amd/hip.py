@@ -728,7 +728,8 @@ def load_default_tuned():
     if not os.path.exists(path):
         TUNED_SOURCE = f"none ({os.path.relpath(path, os.path.dirname(_HERE))} missing): tuned in this run"
         return 0
-    n = load_tuned(path, require_fingerprint=True)
+    # (MVD_TUNE_CACHE_ANY=1: same-box A/B runs of an edited kernel against the committed choices -- both legs launch one kernel mix)
+    n = load_tuned(path, require_fingerprint=os.environ.get("MVD_TUNE_CACHE_ANY") != "1")
     rel = os.path.relpath(path, os.path.dirname(_HERE))
     TUNED_SOURCE = f"{rel}: {n} problems" if n else f"none ({rel} was tuned on other GEMM sources or another cfg encoding): tuned in this run"
     return n
