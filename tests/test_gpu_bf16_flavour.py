@@ -22,9 +22,12 @@ def _run(args, timeout=1500):
 
 
 def test_bf16_flavour_op_tests():
-    """Every kernel of libmvd_hip_bf16.so against the op references (the whole op file: 40 s; the cfg matrices are thinned like the default
-    flavour's unless MVD_TEST_FULL=1)."""
-    out = _run([os.path.join("tests", "test_gpu_ops.py")])
+    """Every kernel of libmvd_hip_bf16.so against the op references (the op file without its two cfg matrices; MVD_TEST_FULL=1: all of it)."""
+    from conftest import FULL
+    # (default: every op test except the two cfg matrices -- a property of the templates, exercised by the default flavour, and every
+    #  tuner-selected cfg of the bf16 library still runs inside the step goldens below; MVD_TEST_FULL=1: the whole file)
+    sel = [] if FULL else ["-k", "not (test_gemm_configurations_agree or test_gemm_groupnorm_statistics)"]
+    out = _run([os.path.join("tests", "test_gpu_ops.py")] + sel)
     assert " passed" in out and "failed" not in out, out[-800:]
 
 
