@@ -451,7 +451,9 @@ int mvd_act_backward(const float* dy, const float* x, float* dx, size_t n, int a
 /* Backward of GEGLU y = a * gelu(g), [a | g] = h (rows, 2*half) (sd1 attention.py:43-44): dh (rows, 2*half). */
 int mvd_geglu_backward(const float* h, const float* dy, int rows, int half, float* dh, mvd_stream_t stream);
 /* Backward of the self-attention core softmax(Q K^T / sqrt(d)) V per (batch, head); q, k, v, dout, dq, dk, dv: token-major
- * (B*L, heads*dhead) fp32.  stats: B*heads*L*3 floats of scratch.  fp32 VALU (training path), deterministic. */
+ * (B*L, heads*dhead) fp32.  stats: B*heads*L*3 floats of scratch ({max, sum, delta} per query row).  Training path, deterministic.
+ * Sequences longer than 16 run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: fp32 operands and accumulation, two kernels -- dQ +
+ * row statistics, then dK / dV); the L <= 16 sequences over GridAttn's reference views stay on the VALU kernel. */
 int mvd_attention_backward(const float* q, const float* k, const float* v, const float* dout, int B, int heads, int L, int dhead,
                            float* dq, float* dk, float* dv, float* stats, size_t stats_floats, mvd_stream_t stream);
 /* Backward of mvd_pixel_cross_attn (D context tokens per pixel): q, dout, dq (P, C); k, v, dk, dv (P*D, C). */

@@ -543,6 +543,210 @@ void launch_attn_bwd(const float* q, const float* k, const float* v, const float
   hipLaunchKernelGGL((attn_bwd_tile_kernel<TQ, TK, DMAX, 1>), grid, dim3(256), 0, s, q, k, v, dout, stats, L, H, d, scale, dk, dv);
 }
 
+// ---------------------------------------------------------------------------------------------- self-attention backward (fp32 MFMA)
+// Round 6: the same mathematics as attn_bwd_tile_kernel above on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: fp32 operands, fp32
+// accumulate -- no operand splitting, 157 TFLOP/s peak; the VALU kernel reached ~8).  Two kernels, 8 wavefronts per workgroup, a wavefront
+// owns 16 "stationary" rows whose operands live in registers as MFMA B fragments; the other side streams through LDS in tiles of KT rows
+// (fp32, odd pitch: conflict-free for both fragment patterns).  Every product is arranged so that the D layout of one MFMA (a lane holds rows
+// 4g .. 4g + 3 of column c; g = lane / 16, c = lane % 16) IS the B fragment of the next (k-slot (g, i) <-> row 4g + i), the trick of the
+// forward's attn_kernel: no score tile ever goes through LDS.
+//   attn_bwd_q_mfma_kernel  (a wave = 16 queries): sweep 1 over the keys: S^T = K Q^T and dP^T = V dO^T per 16-key block, online
+//       m_i, l_i = sum_j e^(s_ij - m_i), and sum_j e^(s_ij - m_i) dP_ij (rescaled like l) -> delta_i = sum_j P_ij dP_ij without O;
+//       sweep 2: dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T; writes {m, l, delta} to `stats` for the second kernel;
+//   attn_bwd_kv_mfma_kernel (a wave = 16 keys): streams the queries: S = Q K^T, dP = dO V^T, P from the stored statistics,
+//       dV^T += dO^T P, dK^T += Q^T dS.
+// Fixed summation order: deterministic.  d % 4 == 0, d <= 160; DB = 16-wide blocks of the head dim (zero padded in LDS).
+template <int DB, int KT, int NT>
+__device__ __forceinline__ void ab_stage_rows(float* tile, const float* __restrict__ src, int r0, int L, int C, int d, int tid) {
+  constexpr int P = 16 * DB + 1;
+  const int c4 = d >> 2;
+  for (int idx = tid; idx < KT * c4; idx += NT) {
+    const int r = idx / c4, c = (idx - r * c4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < L) v = *(const float4*)(src + (size_t)(r0 + r) * C + c);
+    float* t = tile + r * P + c;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  }
+}
+
+template <int DB, int KT>
+__global__ __launch_bounds__(512) void attn_bwd_q_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                             const float* __restrict__ dout, float* __restrict__ stats, int L, int H, int d,
+                                                             float scale, float* __restrict__ dq) {
+  constexpr int DPAD = 16 * DB, P = DPAD + 1, NT = 512, KS = DPAD / 4;
+  __shared__ float sK[KT * P], sV[KT * P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int hd = blockIdx.y, b = blockIdx.z, C = H * d, ks = d >> 2;
+  const size_t base = (size_t)b * L * C + (size_t)hd * d;
+  const int qrow = blockIdx.x * 128 + wave * 16 + c;
+  const bool qok = qrow < L;
+  for (int i = tid; i < KT * P; i += NT) sK[i] = sV[i] = 0.f;      // (the padding columns [d, DPAD) stay zero)
+  float qb[KS], dob[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const int e = 4 * j + g;
+    const bool ok = qok && e < d;
+    qb[j] = ok ? q[base + (size_t)qrow * C + e] : 0.f;
+    dob[j] = ok ? dout[base + (size_t)qrow * C + e] : 0.f;
+  }
+  f32x4 dqT[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) dqT[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f, dl_run = 0.f, inv_l = 0.f, delta = 0.f;
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    for (int kt0 = 0; kt0 < L; kt0 += KT) {
+      __syncthreads();
+      ab_stage_rows<DB, KT, NT>(sK, k + base, kt0, L, C, d, tid);
+      ab_stage_rows<DB, KT, NT>(sV, v + base, kt0, L, C, d, tid);
+      __syncthreads();
+#pragma unroll 1
+      for (int sub = 0; sub < KT / 16; ++sub) {
+        if (kt0 + sub * 16 >= L) break;                     // (uniform: no key of this block exists)
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = s;
+        const float* rk = sK + (sub * 16 + c) * P + g;
+        const float* rv = sV + (sub * 16 + c) * P + g;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          if (j < ks) {
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(rk[4 * j], qb[j], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(rv[4 * j], dob[j], dp, 0, 0, 0);
+          }
+        }
+        float sv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[i] = kt0 + sub * 16 + 4 * g + i < L ? s[i] * scale : -INFINITY;
+        if (sweep == 0) {
+          float mt = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+          mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+          mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+          const float m_new = fmaxf(m_run, mt);              // (finite: key kt0 + 16 sub exists)
+          const float alpha = __expf(m_run - m_new);
+          float ps = 0.f, pd = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float pe = __expf(sv[i] - m_new);
+            ps += pe;
+            pd += pe * dp[i];
+          }
+          l_run = l_run * alpha + ps;
+          dl_run = dl_run * alpha + pd;
+          m_run = m_new;
+        } else {
+          const float* rkt = sK + (sub * 16 + 4 * g) * P + c;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float pr = __expf(sv[i] - m_run) * inv_l;
+            const float ds = pr * (dp[i] - delta) * scale;
+#pragma unroll
+            for (int blk = 0; blk < DB; ++blk) dqT[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(rkt[i * P + blk * 16], ds, dqT[blk], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (sweep == 0) {
+      float lt = l_run + __shfl_xor(l_run, 16, 64);
+      lt += __shfl_xor(lt, 32, 64);
+      float dt = dl_run + __shfl_xor(dl_run, 16, 64);
+      dt += __shfl_xor(dt, 32, 64);
+      inv_l = 1.0f / lt;
+      delta = dt * inv_l;
+      if (g == 0 && qok) {
+        float* st = stats + (((size_t)b * H + hd) * L + qrow) * 3;
+        st[0] = m_run;
+        st[1] = lt;
+        st[2] = delta;
+      }
+    }
+  }
+  if (qok) {
+#pragma unroll
+    for (int blk = 0; blk < DB; ++blk) {
+      const int dd = blk * 16 + 4 * g;
+      if (dd < d) *(float4*)(dq + base + (size_t)qrow * C + dd) = make_float4(dqT[blk][0], dqT[blk][1], dqT[blk][2], dqT[blk][3]);
+    }
+  }
+}
+
+template <int DB, int KT>
+__global__ __launch_bounds__(512) void attn_bwd_kv_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                              const float* __restrict__ dout, const float* __restrict__ stats, int L, int H, int d,
+                                                              float scale, float* __restrict__ dk, float* __restrict__ dv) {
+  constexpr int DPAD = 16 * DB, P = DPAD + 1, NT = 512, KS = DPAD / 4;
+  __shared__ float sQ[KT * P], sO[KT * P], sS[KT * 3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int hd = blockIdx.y, b = blockIdx.z, C = H * d, ks = d >> 2;
+  const size_t base = (size_t)b * L * C + (size_t)hd * d;
+  const int krow = blockIdx.x * 128 + wave * 16 + c;
+  const bool kok = krow < L;
+  for (int i = tid; i < KT * P; i += NT) sQ[i] = sO[i] = 0.f;
+  float kb[KS], vb[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const int e = 4 * j + g;
+    const bool ok = kok && e < d;
+    kb[j] = ok ? k[base + (size_t)krow * C + e] : 0.f;
+    vb[j] = ok ? v[base + (size_t)krow * C + e] : 0.f;
+  }
+  f32x4 dkT[DB], dvT[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) dkT[i] = dvT[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* stb = stats + ((size_t)b * H + hd) * L * 3;
+  for (int qt0 = 0; qt0 < L; qt0 += KT) {
+    __syncthreads();
+    ab_stage_rows<DB, KT, NT>(sQ, q + base, qt0, L, C, d, tid);
+    ab_stage_rows<DB, KT, NT>(sO, dout + base, qt0, L, C, d, tid);
+    for (int i = tid; i < KT * 3; i += NT) sS[i] = qt0 + i / 3 < L ? stb[(size_t)qt0 * 3 + i] : 0.f;
+    __syncthreads();
+#pragma unroll 1
+    for (int sub = 0; sub < KT / 16; ++sub) {
+      if (qt0 + sub * 16 >= L) break;
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = s;
+      const float* rq = sQ + (sub * 16 + c) * P + g;
+      const float* ro = sO + (sub * 16 + c) * P + g;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        if (j < ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(rq[4 * j], kb[j], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ro[4 * j], vb[j], dp, 0, 0, 0);
+        }
+      }
+      const float* rqt = sQ + (sub * 16 + 4 * g) * P + c;
+      const float* rot = sO + (sub * 16 + 4 * g) * P + c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ql = sub * 16 + 4 * g + i;
+        const bool ok = qt0 + ql < L;
+        const float m = sS[ql * 3], l = sS[ql * 3 + 1], de = sS[ql * 3 + 2];
+        const float pr = ok ? __expf(s[i] * scale - m) / l : 0.f;
+        const float ds = pr * (dp[i] - de) * scale;
+#pragma unroll
+        for (int blk = 0; blk < DB; ++blk) {
+          dvT[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(rot[i * P + blk * 16], pr, dvT[blk], 0, 0, 0);
+          dkT[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(rqt[i * P + blk * 16], ds, dkT[blk], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (kok) {
+#pragma unroll
+    for (int blk = 0; blk < DB; ++blk) {
+      const int dd = blk * 16 + 4 * g;
+      if (dd < d) {
+        *(float4*)(dk + base + (size_t)krow * C + dd) = make_float4(dkT[blk][0], dkT[blk][1], dkT[blk][2], dkT[blk][3]);
+        *(float4*)(dv + base + (size_t)krow * C + dd) = make_float4(dvT[blk][0], dvT[blk][1], dvT[blk][2], dvT[blk][3]);
+      }
+    }
+  }
+}
+
+template <int DB, int KT>
+void launch_attn_bwd_mfma(const float* q, const float* k, const float* v, const float* dout, int B, int H, int L, int d, float scale, float* dq,
+                          float* dk, float* dv, float* stats, hipStream_t s) {
+  const dim3 grid((L + 127) / 128, H, B);
+  hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<DB, KT>), grid, dim3(512), 0, s, q, k, v, dout, stats, L, H, d, scale, dq);
+  hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<DB, KT>), grid, dim3(512), 0, s, q, k, v, dout, stats, L, H, d, scale, dk, dv);
+}
+
 // ---------------------------------------------------------------------------------------------- per-pixel cross-attention backward
 // DualAttnetionBlock.attn2 with D context tokens per pixel (mvdfusion/attention.py:52-62; forward: pixel_xattn_kernel): one wave per
 // (pixel, head).  q (P, C), k / v (P*D, C), dout (P, C) -> dq (P, C), dk / dv (P*D, C).  D <= 8.
@@ -824,8 +1028,18 @@ extern "C" int mvd_attention_backward(const float* q, const float* k, const floa
   MVD_CHECK_ARG(B <= 65535 && heads <= 65535, "mvd_attention_backward: batch / heads exceed the grid limits");
   const float scale = 1.0f / sqrtf((float)dhead);
   hipStream_t s = (hipStream_t)stream;
-  if (L <= 16 && dhead <= 48)            // the sequences over the V reference views of GridAttn
+  // MVD_ATTN_BWD_VALU=1: the round-5 fp32 VALU kernels for every shape (A/B runs, cross-check in tests/test_gpu_backward.py)
+  static const bool valu_only = getenv("MVD_ATTN_BWD_VALU") != nullptr && getenv("MVD_ATTN_BWD_VALU")[0] == '1';
+  if (L <= 16 && dhead <= 48)            // the sequences over the V reference views of GridAttn (huge batch of tiny problems): VALU
     launch_attn_bwd<16, 16, 48>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
+  else if (!valu_only && dhead <= 16)
+    launch_attn_bwd_mfma<1, 64>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
+  else if (!valu_only && dhead <= 48)
+    launch_attn_bwd_mfma<3, 64>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
+  else if (!valu_only && dhead <= 80)
+    launch_attn_bwd_mfma<5, 64>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
+  else if (!valu_only)
+    launch_attn_bwd_mfma<10, 32>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
   else if (dhead <= 48)
     launch_attn_bwd<64, 32, 48>(q, k, v, dout, B, heads, L, dhead, scale, dq, dk, dv, stats, s);
   else if (dhead <= 96)

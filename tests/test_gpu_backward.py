@@ -144,7 +144,8 @@ def test_geglu_backward(hip):
     assert rel_err(dh.cpu(), h.grad) < 3e-6
 
 
-@pytest.mark.parametrize("B,H,L,d", [(2, 8, 256, 40), (1, 8, 1024, 4), (2, 4, 64, 160), (2, 8, 100, 80)])
+@pytest.mark.parametrize("B,H,L,d", [(2, 8, 256, 40), (1, 8, 1024, 4), (2, 4, 64, 160), (2, 8, 100, 80), (1, 8, 1024, 40), (3, 2, 300, 16), (5, 8, 15, 32),
+                                      (1, 3, 130, 160)])
 def test_attention_backward(hip, B, H, L, d):
     from mvdfusion_amd import backward as bw
     C = H * d
