@@ -62,6 +62,9 @@ size_t mvd_packed_weight_bytes(int N, int K);
  * the GEMM undoes it exactly through mvd_gemm_desc.acc_scale = 1/scale. */
 int mvd_pack_linear_weight(const float* w, int N, int K, int ldw, int geglu, float scale, void* packed,
                            mvd_stream_t stream);
+/* The same image from the TRANSPOSED source: wt is (K, N) row-major with leading dimension ldw, the packed weight is its transpose
+ * (N, K) -- the dgrad weight W^T of a Linear packed straight from the parameter, without a transposed copy. */
+int mvd_pack_linear_weight_t(const float* wt, int N, int K, int ldw, float scale, void* packed, mvd_stream_t stream);
 /* w: (Cout, Cin, 3, 3) fp32 (nn.Conv2d layout).  Packed K index = ((ci/32)*9 + ky*3+kx)*32 + ci%32: the nine taps of one
  * 32-channel block are consecutive k-tiles, so the implicit-GEMM kernel re-reads a pixel's 128-byte line back to back. */
 int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, float scale, void* packed,

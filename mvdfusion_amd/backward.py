@@ -37,7 +37,11 @@ def transpose_planes(x, rows, cols, src_planes=False, ldx=None, scale=None):
     int16 (cols rounded up to 16, 2 * rows rounded up to 32); rows past `cols` stay zero (they are GEMM padding).  scale: device scalar an
     fp32 source is multiplied with on the way (the power-of-two gradient scale)."""
     ldo = _pad32(rows)
-    out = torch.zeros(_pad16(cols), 2 * ldo, dtype=torch.int16, device=x.device)
+    # (the kernel writes every k-block of rows [0, cols), zeros included; only the GEMM padding rows [cols, ceil16(cols)) need a fill --
+    #  it was a torch.zeros of the whole buffer: 600 fill launches per training step)
+    out = torch.empty(_pad16(cols), 2 * ldo, dtype=torch.int16, device=x.device)
+    if out.shape[0] > cols:
+        out[cols:].zero_()
     if ldx is None:
         ldx = x.shape[-1] // 2 if src_planes else x.shape[-1]
     if scale is None:
@@ -120,7 +124,11 @@ def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True,
     dyc = dy if dy.is_contiguous() else dy.contiguous()
     dx = None
     if need_dx:
-        wt = hip.pack_linear(weight.detach().t().contiguous(), like=weight)   # (K, N): dX = dY W  (same elements: the registered max|w| serves)
+        w2 = weight.detach().reshape(weight.shape[0], -1)                     # (a view for nn.Linear and 1x1 nn.Conv2d parameters)
+        if w2.is_contiguous() and w2.dtype == torch.float32:
+            wt = hip.pack_linear_t(w2, like=weight)                           # image of W^T (K, N): dX = dY W, no transposed copy
+        else:
+            wt = hip.pack_linear(w2.t().contiguous(), like=weight)   # (same elements: the registered max|w| serves)
         dx_full = torch.empty(M, wt.N, dtype=torch.float32, device=dev)
         hip.gemm(_planes_padded(dyc, N, scale=sc), wt, dx_full, prec=prec, bias=False, workspace=workspace, acc_scale_dev=isc)
         dx = dx_full[:, :K]
@@ -158,7 +166,7 @@ def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, nee
     if need_dw:
         a = transpose_planes(dyc, M, Cout, scale=sc)                          # (ceil16(Cout), M)
         ldo = _pad32(M)
-        cols_t = torch.zeros(9 * cin_p, 2 * ldo, dtype=torch.int16, device=dev)     # (im2col X)^T, rows ci*9 + tap
+        cols_t = torch.empty(9 * cin_p, 2 * ldo, dtype=torch.int16, device=dev)     # (im2col X)^T, rows ci*9 + tap (every element written)
         hip.check(hip.lib().mvd_im2col3x3_t_planes(hip.ptr(x_planes), B, H, W, cin_p, hip.ptr(cols_t), ldo, hip.stream()))
         dw_full = torch.empty(a.shape[0], 9 * cin_p, dtype=torch.float32, device=dev)
         hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo), dw_full, prec=prec, bias=False, workspace=workspace, acc_scale_dev=isc)

@@ -620,39 +620,61 @@ extern "C" int mvd_gemm(const mvd_gemm_desc* dp, mvd_stream_t stream) {
 
 // ------------------------------------------------------------------------------------------------ packing
 namespace {
-// one thread per packed element pair (hi, lo)
+// One thread per 16-byte chunk of a fragment image: lane l of a wavefront fills lane l of one 16 (n) x 32 (k) micro-tile -- row n = 16 nt +
+// (l & 15), k = 32 kt + 8 (l >> 4) ... + 7 -- so a wavefront reads 16 rows x 128 bytes and writes the micro-tile's hi image and lo image as
+// two contiguous 1 KiB stores (round 6; it was one thread per element with 2-byte scattered stores: the weight re-pack after an optimizer
+// step, 886 launches, cost the training step 14.5 ms).
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, u16* __restrict__ out, int N, int K,
-                                                   int Np, int Kp, int ldw, int geglu, int conv_cin, int conv_cin_pad,
+                                                   int Np, int Kp, int ldw, int geglu, int conv_cin, int trans,
                                                    float scale) {
-  const size_t total = (size_t)Np * Kp;
+  const int nt16 = Np >> 4;
+  const size_t total = (size_t)(Kp >> 5) * nt16 * 64;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int n = (int)(e / Kp);   // packed row
-    const int k = (int)(e - (size_t)n * Kp);
+    const size_t mt = e >> 6;                          // micro-tile: kt * nt16 + nt
+    const int l = (int)(e & 63);
+    const int kt = (int)(mt / nt16), nt = (int)(mt - (size_t)kt * nt16);
+    const int n = nt * 16 + (l & 15);                  // packed row
+    const int k = kt * 32 + (l >> 4) * 8;
     int src_n = n;
     if (geglu) {
       const int blk = n >> 5, within = n & 31;
       src_n = within < 16 ? blk * 16 + within : (N >> 1) + blk * 16 + (within - 16);
     }
-    float v = 0.f;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
     if (src_n < N) {
       if (conv_cin > 0) {
-        const int blk = k >> 5;                      // K order: (32-channel block, tap, channel in block)
-        const int cb = blk / 9, tap = blk - cb * 9;
-        const int ci = cb * 32 + (k & 31);
-        if (ci < conv_cin) v = w[((size_t)src_n * conv_cin + ci) * 9 + tap];
-      } else if (k < K) {
-        v = w[(size_t)src_n * ldw + k];
+        const int cb = kt / 9, tap = kt - cb * 9;      // K order: (32-channel block, tap, channel in block)
+        const int ci0 = cb * 32 + (k & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (ci0 + j < conv_cin) v[j] = w[((size_t)src_n * conv_cin + ci0 + j) * 9 + tap];
+      } else if (trans) {                              // the source is the TRANSPOSE: (K, N) row-major (dgrad weights: no torch copy)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k + j < K) v[j] = w[(size_t)(k + j) * ldw + src_n];
+      } else {
+        const float* src = w + (size_t)src_n * ldw + k;
+        if (k + 7 < K && (ldw & 3) == 0 && ((uintptr_t)w & 15) == 0) {
+          const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (k + j < K) v[j] = src[j];
+        }
       }
     }
-    u16 hi, lo;
-    split_op16(v * scale, hi, lo);
     // [kt][nt][hi image | lo image]; an image is the 16x16x32 MFMA B fragment of the micro-tile as the wave holds it: lane
     // l = (n & 15) + 16 * (k-chunk of 8) owns 16 contiguous bytes -- one fully coalesced 1 KiB access per image
     // (the LDS-DMA source of a granule is contiguous, and the fragment reads from LDS are lane-contiguous: no bank conflicts)
-    const int kt = k >> 5, kk = k & 31, nt = n >> 4, nn = n & 15;
-    const size_t base = ((size_t)kt * (Np >> 4) + nt) * 1024 + (nn + 16 * (kk >> 3)) * 8 + (kk & 7);
-    out[base] = hi;
-    out[base + 512] = lo;
+    union { uint4 q; u16 h[8]; } H, Lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_op16(v[j] * scale, H.h[j], Lo.h[j]);
+    u16* o = out + mt * 1024 + l * 8;
+    *(uint4*)o = H.q;
+    *(uint4*)(o + 512) = Lo.q;
   }
 }
 
@@ -685,7 +707,7 @@ extern "C" int mvd_pack_linear_weight(const float* w, int N, int K, int ldw, int
   MVD_CHECK_ARG(w && packed && N > 0 && K > 0 && ldw >= K, "mvd_pack_linear_weight: bad arguments");
   if (geglu) MVD_CHECK_ARG(N % 32 == 0, "mvd_pack_linear_weight: geglu needs N %% 32 == 0");
   const int Np = (N + 15) & ~15, Kp = (K + 31) & ~31;
-  const size_t total = (size_t)Np * Kp;
+  const size_t total = (size_t)Np * Kp / 8;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (u16*)packed, N, K, Np, Kp, ldw,
@@ -694,16 +716,27 @@ extern "C" int mvd_pack_linear_weight(const float* w, int N, int K, int ldw, int
   return 0;
 }
 
+extern "C" int mvd_pack_linear_weight_t(const float* wt, int N, int K, int ldw, float scale, void* packed, mvd_stream_t stream) {
+  MVD_CHECK_ARG(wt && packed && N > 0 && K > 0 && ldw >= N, "mvd_pack_linear_weight_t: bad arguments");
+  const int Np = (N + 15) & ~15, Kp = (K + 31) & ~31;
+  const size_t total = (size_t)Np * Kp / 8;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, wt, (u16*)packed, N, K, Np, Kp, ldw, 0, 0, 1, scale);
+  MVD_CHECK_LAUNCH("mvd_pack_linear_weight_t");
+  return 0;
+}
+
 extern "C" int mvd_pack_conv3x3_weight(const float* w, int Cout, int Cin, int cin_pad, float scale, void* packed,
                                        mvd_stream_t stream) {
   MVD_CHECK_ARG(w && packed && Cout > 0 && Cin > 0 && cin_pad >= Cin && cin_pad % 32 == 0,
                 "mvd_pack_conv3x3_weight: bad arguments (cin_pad must be a multiple of 32)");
   const int Np = (Cout + 15) & ~15, Kp = 9 * cin_pad;
-  const size_t total = (size_t)Np * Kp;
+  const size_t total = (size_t)Np * Kp / 8;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (u16*)packed, Cout, Kp, Np, Kp, 0,
-                     0, Cin, cin_pad, scale);
+                     0, Cin, 0, scale);
   MVD_CHECK_LAUNCH("mvd_pack_conv3x3_weight");
   return 0;
 }

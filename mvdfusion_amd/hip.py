@@ -84,6 +84,7 @@ SIGNATURES = {
     "mvd_packed_weight_bytes": (_sz, [_i, _i]),
     "mvd_operand_format": (_i, []),
     "mvd_pack_linear_weight": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "mvd_pack_linear_weight_t": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "mvd_pack_conv3x3_weight": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "mvd_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "mvd_gemm_cfg_supported": (_i, [C.POINTER(GemmDesc), _i]),
@@ -328,6 +329,19 @@ def pack_linear(weight, bias=None, geglu=False, like=None):
     # (w may be a temporary: the pack kernel runs on torch's current stream, and the caching allocator re-uses a freed block only
     #  for work enqueued later on that stream -- no host synchronisation needed)
     return PackedWeight(data, Np, Kp, N, b, geglu, acc_scale=1.0 / scale)
+
+
+def pack_linear_t(weight, like=None):
+    """The packed image of weight^T -- weight (K, N) fp32 row-major, image (N, K): the dgrad operand dX = dY W of a Linear, packed straight
+    from the parameter (no transposed copy; round 6)."""
+    w = weight.detach()
+    assert w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous()
+    K, N = w.shape
+    Np, Kp = (N + 15) // 16 * 16, (K + 31) // 32 * 32
+    data = torch.empty(lib().mvd_packed_weight_bytes(N, K), dtype=torch.uint8, device=w.device)
+    scale = _pack_scale(w, like if like is not None else weight)
+    check(lib().mvd_pack_linear_weight_t(ptr(w), N, K, N, scale, ptr(data), stream()))
+    return PackedWeight(data, Np, Kp, N, None, False, acc_scale=1.0 / scale)
 
 
 def pack_linear_cat(weights):
