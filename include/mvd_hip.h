@@ -435,6 +435,10 @@ int mvd_adamw_multi(const void* tensors, int n_tensors, int n_chunks, float lr, 
 /* out[c] = sum_r x[r][c] (bias gradient): fp64 partials, fixed order.  ws: mvd_col_sum_workspace_doubles(rows, cols) doubles. */
 size_t mvd_col_sum_workspace_doubles(int rows, int cols);
 int mvd_col_sum(const float* x, int rows, int cols, int ldx, float* out, double* ws, size_t ws_doubles, mvd_stream_t stream);
+/* mvd_col_sum and mvd_pow2_scale of the same (rows, cols) matrix (ldx == cols: the scale is over exactly the summed elements) in ONE pass:
+ * out[c] = column sums, out2 = {s, 1/s}.  scratch1: one zero-initialised word per stream (left zero). */
+int mvd_col_sum_pow2(const float* x, int rows, int cols, int ldx, float* out, double* ws, size_t ws_doubles, float* out2, unsigned* scratch1,
+                     mvd_stream_t stream);
 /* Backward of y = act(GroupNorm(x)) (act = SiLU when silu != 0; torch.nn.GroupNorm semantics, openaimodel.py GroupNorm32):
  * dy = dL/dy  ->  dx (B,HW,C), dgamma (C), dbeta (C).  ws: B*groups*2 + B*C*2 floats. */
 int mvd_groupnorm_backward(const float* x, const float* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,

@@ -12,13 +12,14 @@ Every matrix product runs on the forward's split-operand MFMA GEMM (csrc/gemm.hi
 plus ``GroupNorm(+SiLU)`` backward (csrc/backward.hip).  Weights change every optimizer step, so the transposed / rotated images
 are packed per call (4 B per parameter, a fraction of the GEMM's own traffic).
 
-What exists: these ops plus LayerNorm / GEGLU / self-attention / per-pixel cross-attention backward (op-level gradient tests against
-torch autograd in fp32), the UNet output head chained on them (`unet_head_backward`: MSE -> conv3x3 head -> SiLU -> GroupNorm32) and
-the block-level backwards of mvdfusion_amd/backward_blocks.py (ResBlock, SpatialTransformer, ViewAlignedFeatureTransformer), whose
-parameter gradients are pinned to the REFERENCE's ``loss.backward()`` (tests/golden/train_grads_*.npz: the head and all of
-`output_blocks.11`).  What does not exist yet: the strided / upsampling conv backward, the GridAttn backward and the walk over the
-whole UNet with an optimizer, so ``ViewFusion.forward(...).backward()`` still raises.
+These ops, LayerNorm / GEGLU / self-attention (fp32 matrix cores) / per-pixel cross-attention backward (op-level gradient tests against
+torch autograd in fp32: tests/test_gpu_backward.py) are what the block-level backwards are made of: mvdfusion_amd/backward_blocks.py
+(ResBlock, SpatialTransformer, ViewAlignedFeatureTransformer), backward_unet.py (the walk over the whole UNet, strided / upsampling
+convolutions included) and backward_gridattn.py.  ``ViewFusion.forward(batch, cfg).backward()`` runs on them; all 994 parameter gradients
+are pinned to the REFERENCE's ``loss.backward()`` (tests/golden/train_grads_*.npz, tests/test_gpu_vae.py).
 """
+import os
+
 import torch
 
 from . import hip
@@ -108,6 +109,29 @@ def _pow2_scale(t):
     return out[0], out[1]
 
 
+def _colsum_pow2_scale(dy, rows, cols):
+    """(column sums of dy, s, 1/s): the bias gradient and the power-of-two operand scale of dy (see _pow2_scale) from ONE pass over dy
+    (mvd_col_sum_pow2; round 6: they were two passes, ~330 launches and ~7 ms of the training step)."""
+    assert dy.is_contiguous() and dy.shape[-1] == cols and dy.numel() == rows * cols
+    idx = dy.device.index if dy.device.index is not None else torch.cuda.current_device()
+    try:
+        key = (idx, torch._C._cuda_getCurrentRawStream(idx), "cs")
+    except AttributeError:
+        key = (idx, torch.cuda.current_stream(dy.device).cuda_stream, "cs")
+    scratch = _POW2_SCRATCH.get(key)
+    if scratch is None:
+        scratch = _POW2_SCRATCH[key] = torch.zeros(1, dtype=torch.int32, device=dy.device)
+    out = torch.empty(cols, dtype=torch.float32, device=dy.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=dy.device)
+    n = hip.lib().mvd_col_sum_workspace_doubles(rows, cols)
+    ws = torch.empty(n, dtype=torch.float64, device=dy.device)
+    hip.check(hip.lib().mvd_col_sum_pow2(hip.ptr(dy), rows, cols, cols, hip.ptr(out), hip.ptr(ws), n, hip.ptr(out2), hip.ptr(scratch), hip.stream()))
+    return out, out2[0], out2[1]
+
+
+FUSE_COLSUM_POW2 = os.environ.get("MVD_COLSUM_POW2", "1") != "0"      # (0: separate mvd_pow2_scale + mvd_col_sum passes, for A/B runs)
+
+
 def _planes_padded(x, cols, scale=None):
     """fp32 (rows, cols) -> split planes (rows, 2 * ceil32(cols)) of x [* scale], padded columns zero."""
     return hip.split_planes(x.contiguous(), ldp=_pad32(cols), scale=scale)
@@ -120,8 +144,13 @@ def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True,
     K = weight.shape[1]
     dev = dy.device
     # dY * s on its way into the operand planes and 1 / s in the GEMM's accumulator scale: both exact (powers of two), no extra pass
-    sc, isc = _pow2_scale(dy)
     dyc = dy if dy.is_contiguous() else dy.contiguous()
+    db = None
+    if need_db and FUSE_COLSUM_POW2:
+        db, sc, isc = _colsum_pow2_scale(dyc, M, N)
+    else:
+        sc, isc = _pow2_scale(dyc)
+        db = col_sum(dyc, M, N) if need_db else None
     dx = None
     if need_dx:
         w2 = weight.detach().reshape(weight.shape[0], -1)                     # (a view for nn.Linear and 1x1 nn.Conv2d parameters)
@@ -140,7 +169,6 @@ def linear_backward(x_planes, weight, dy, workspace, need_dx=True, need_db=True,
         dw_full = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=dev)
         hip.gemm(a, hip.PlanesOperand(b, N=b.shape[0], K=_pad32(M)), dw_full, prec=prec, bias=False, workspace=workspace, acc_scale_dev=isc)
         dW = dw_full[:N, :K]
-    db = col_sum(dy, M, N) if need_db else None
     return dx, dW, db
 
 
@@ -152,8 +180,13 @@ def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, nee
     cin_p = x_planes.shape[-1] // 2
     dev = dy.device
     assert M == B * H * W and cin_p % 32 == 0 and cin_p >= Cin
-    sc, isc = _pow2_scale(dy)          # (applied inside the plane conversions and the GEMMs' accumulator scale: linear_backward)
     dyc = dy if dy.is_contiguous() else dy.contiguous()
+    db = None
+    if need_db and FUSE_COLSUM_POW2:   # (the scale is applied inside the plane conversions and the GEMMs' accumulator scale: linear_backward)
+        db, sc, isc = _colsum_pow2_scale(dyc, M, Cout)
+    else:
+        sc, isc = _pow2_scale(dyc)
+        db = col_sum(dyc, M, Cout) if need_db else None
     dx = None
     if need_dx:
         # dX = conv3x3(dY, W') with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]  (full correlation with the rotated filter)
@@ -171,7 +204,6 @@ def conv3x3_backward(x_planes, weight, dy, B, H, W, workspace, need_dx=True, nee
         dw_full = torch.empty(a.shape[0], 9 * cin_p, dtype=torch.float32, device=dev)
         hip.gemm(a, hip.PlanesOperand(cols_t, N=9 * cin_p, K=ldo), dw_full, prec=prec, bias=False, workspace=workspace, acc_scale_dev=isc)
         dW = dw_full[:Cout, :9 * Cin].reshape(Cout, Cin, 3, 3)
-    db = col_sum(dy, M, Cout) if need_db else None
     return dx, dW, db
 
 

@@ -85,27 +85,52 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const u16* __restrict__ x
   }
 }
 
-// column sums (bias gradient): grid (cols / 32, splits); thread = (8 row lanes, 32 columns), fp64 partials, fixed-order combine
+// column sums (bias gradient): grid (cols / 32, splits); thread = (8 row lanes, 32 columns), fp64 partials, fixed-order combine.
+// amax != null (round 6, mvd_col_sum_pow2): the same pass also forms max|x| -- block maxima meet in an atomicMax on the bit pattern (non-negative
+// floats order like their bits) -- and the FINAL kernel turns it into the power-of-two gradient scale {s, 1/s} of mvd_pow2_scale and re-zeroes
+// the word: the bias gradient and the operand scale of a layer's dY cost one pass over dY instead of two.
 __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, int rows, int cols, int ldx,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, unsigned* __restrict__ amax) {
   __shared__ double s[8][32];
+  __shared__ unsigned s_m[4];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + tx;
   const int per = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double a = 0.0;
+  unsigned m = 0;
   if (c < cols)
-    for (int r = r0 + ty; r < r1; r += 8) a += (double)x[(size_t)r * ldx + c];
+    for (int r = r0 + ty; r < r1; r += 8) {
+      const float v = x[(size_t)r * ldx + c];
+      a += (double)v;
+      m = max(m, __float_as_uint(v) & 0x7fffffffu);
+    }
   s[ty][tx] = a;
+  if (amax != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  }
   __syncthreads();
   if (ty == 0 && c < cols) {
     double t = 0.0;
     for (int k = 0; k < 8; ++k) t += s[k][tx];
     part[(size_t)blockIdx.y * cols + c] = t;
   }
+  if (amax != nullptr && threadIdx.x == 0)
+    __hip_atomic_fetch_max(amax, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ __launch_bounds__(256) void col_sum_final_kernel(const double* __restrict__ part, int splits, int cols, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void col_sum_final_kernel(const double* __restrict__ part, int splits, int cols, float* __restrict__ out,
+                                                            unsigned* __restrict__ amax, float* __restrict__ out2) {
   const int c = blockIdx.x * 256 + threadIdx.x;
+  if (amax != nullptr && c == 0) {          // (every partial block has finished: this is a later launch of the same stream)
+    const unsigned bits = __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float sc = 1.f;
+    if (bits != 0 && bits < 0x7f800000u) sc = exp2f(10.f - floorf(log2f(__uint_as_float(bits))));
+    out2[0] = sc;
+    out2[1] = 1.f / sc;
+    __hip_atomic_store(amax, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (c >= cols) return;
   double t = 0.0;
   for (int k = 0; k < splits; ++k) t += part[(size_t)k * cols + c];
@@ -939,17 +964,28 @@ extern "C" size_t mvd_col_sum_workspace_doubles(int rows, int cols) {
   return (size_t)splits * cols;
 }
 
-extern "C" int mvd_col_sum(const float* x, int rows, int cols, int ldx, float* out, double* ws, size_t ws_doubles, mvd_stream_t stream) {
-  MVD_CHECK_ARG(x && out && ws && rows > 0 && cols > 0 && ldx >= cols, "mvd_col_sum: bad arguments");
+static int col_sum_launch(const float* x, int rows, int cols, int ldx, float* out, double* ws, size_t ws_doubles, unsigned* amax, float* out2,
+                          hipStream_t stream) {
   int splits = rows / 256;
   if (splits < 1) splits = 1;
   if (splits > 64) splits = 64;
   MVD_CHECK_ARG(ws_doubles >= (size_t)splits * cols, "mvd_col_sum: workspace too small (%zu < %zu doubles)", ws_doubles,
                 (size_t)splits * cols);
-  hipLaunchKernelGGL(col_sum_partial_kernel, dim3((cols + 31) / 32, splits), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ldx, ws);
-  hipLaunchKernelGGL(col_sum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, splits, cols, out);
+  hipLaunchKernelGGL(col_sum_partial_kernel, dim3((cols + 31) / 32, splits), dim3(256), 0, stream, x, rows, cols, ldx, ws, amax);
+  hipLaunchKernelGGL(col_sum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, ws, splits, cols, out, amax, out2);
   MVD_CHECK_LAUNCH("mvd_col_sum");
   return 0;
+}
+
+extern "C" int mvd_col_sum(const float* x, int rows, int cols, int ldx, float* out, double* ws, size_t ws_doubles, mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && out && ws && rows > 0 && cols > 0 && ldx >= cols, "mvd_col_sum: bad arguments");
+  return col_sum_launch(x, rows, cols, ldx, out, ws, ws_doubles, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mvd_col_sum_pow2(const float* x, int rows, int cols, int ldx, float* out, double* ws, size_t ws_doubles, float* out2,
+                                unsigned* scratch1, mvd_stream_t stream) {
+  MVD_CHECK_ARG(x && out && ws && out2 && scratch1 && rows > 0 && cols > 0 && ldx >= cols, "mvd_col_sum_pow2: bad arguments");
+  return col_sum_launch(x, rows, cols, ldx, out, ws, ws_doubles, scratch1, out2, (hipStream_t)stream);
 }
 
 extern "C" int mvd_groupnorm_backward(const float* x, const float* dy, const float* gamma, const float* beta, int B, int HW, int C,

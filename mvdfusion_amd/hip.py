@@ -107,6 +107,7 @@ SIGNATURES = {
     "mvd_im2col3x3_t_planes": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "mvd_col_sum_workspace_doubles": (_sz, [_i, _i]),
     "mvd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "mvd_col_sum_pow2": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "mvd_gridattn_tokens_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "mvd_layernorm_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "mvd_geglu_backward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

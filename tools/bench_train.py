@@ -81,7 +81,8 @@ def main():
         st.sort_stats("cumulative").print_stats(60)
         st.sort_stats("tottime").print_stats(45)
         open(a.cprofile, "w").write(f"# {a.steps} steady steps of tools/bench_train.py --views {a.views} --depth-samples {a.depth_samples}\n" + buf.getvalue())
-    dt = sum(times[1:]) / a.steps
+    import statistics
+    dt = statistics.median(times[1:])          # (median: a step that meets a new shape tunes it, a host hiccup is 50 ms)
     # algorithmic work of one step (SURVEY.md section 8(d), 2 FLOP per MAC): forward = V UNet passes (cfg 1: no null twin) + GridAttn; the
     # backward is a dgrad and a wgrad per contraction (2 x forward) and re-runs every block's forward once (activation checkpointing at block
     # granularity, like the reference's use_checkpoint=True) => 4 x forward
@@ -89,7 +90,7 @@ def main():
     T = V * V * S * S * D
     f_fwd = V * f_unet + T * (3516416 + 3072 * V) + V * S * S * D * 393216 + (V + 1) * S * S * 2560
     flops = 4.0 * f_fwd
-    print(json.dumps({"metric": "training-steps/sec (fwd + bwd + AdamW, one scene)", "value": 1.0 / dt, "unit": "steps/s", "s_per_step": dt, "first_step_s": times[0],
+    print(json.dumps({"metric": "training-steps/sec (fwd + bwd + AdamW, one scene)", "value": 1.0 / dt, "unit": "steps/s", "s_per_step": dt, "step_s": [round(t, 4) for t in times[1:]], "first_step_s": times[0],
                       "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / dt / 2.5e15,
                                    "traffic": None, "algorithmic_tflop_per_step": flops / 1e12,
                                    "note": "whole step (fwd + recompute + dgrad + wgrad) against the dense 16-bit MFMA peak; the step is "
@@ -98,7 +99,7 @@ def main():
                       "finetune_unet": not a.frozen_unet,
                       "losses": losses, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
                       "note": "backward = recompute-per-block + dgrad/wgrad on the split-operand MFMA GEMM (big shapes autotuned on first sight), "
-                              "fp32 VALU attention backward; one batched max|w| read per step; no graph capture, fresh allocations"}))
+                              "fp32-MFMA self-attention backward; one batched max|w| read per step; no graph capture, fresh allocations; s_per_step = median of the timed steps"}))
 
 
 if __name__ == "__main__":
