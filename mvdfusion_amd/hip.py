@@ -180,7 +180,17 @@ def check(rc):
         raise RuntimeError(f"mvd_hip error {rc}: {lib().mvd_last_error().decode()}")
 
 
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream      # one C call (torch.cuda.current_stream() builds a Stream object through five Python
+    _cur_device = torch._C._cuda_getDevice                 # frames: 17 000 calls = ~10 ms of host time per training step)
+except AttributeError:
+    _raw_stream = None
+
+
 def stream():
+    """torch's current stream of the current device as the library's mvd_stream_t."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(_cur_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -378,11 +388,36 @@ def params_signature(module):
     EMA swaps via ``.data``, ``torch._foreach_*`` on ``.data``) bump no version and keep the pointer: they are invisible here by
     construction, and ``ViewFusion.invalidate_packed()`` is MANDATORY after them (ViewFusion.load_state_dict / _apply call it
     themselves).  The packed MFMA operand images are derived from the fp32 parameters; their owners compare this before reuse."""
-    return hash(tuple((p.data_ptr(), p._version) for p in module.parameters()) + tuple(b.data_ptr() for b in module.buffers()))
+    # (the walk over the module tree -- named_modules / named_parameters, ~600 k Python calls for the full model -- is done ONCE: the slots
+    #  (owner's _parameters / _buffers dict, name) are cached on the module and read through on every call, so a Parameter OBJECT replaced
+    #  under an existing name is still seen; adding / removing submodules after the first call needs invalidate_packed(), like .data writes)
+    slots = module.__dict__.get("_mvd_sig_slots")
+    if slots is None:
+        ps, bs, seen = [], [], set()
+        for m in module.modules():
+            for n, p in m._parameters.items():
+                if p is not None and id(p) not in seen:
+                    seen.add(id(p))
+                    ps.append((m._parameters, n))
+            for n, b in m._buffers.items():
+                if b is not None and id(b) not in seen:
+                    seen.add(id(b))
+                    bs.append((m._buffers, n))
+        slots = module.__dict__["_mvd_sig_slots"] = (ps, bs)
+    ps, bs = slots
+    sig = []
+    for d_, n in ps:
+        p = d_.get(n)
+        sig.append((p.data_ptr(), p._version) if p is not None else None)
+    for d_, n in bs:
+        b = d_.get(n)
+        sig.append(b.data_ptr() if b is not None else None)
+    return hash(tuple(sig))
 
 
 def drop_packed_caches(module):
     """Forget every lazily packed weight image under `module` (they are re-packed from the live parameters on next use)."""
+    module.__dict__.pop("_mvd_sig_slots", None)          # (params_signature's cached slots: re-walk the module tree next time)
     for m in module.modules():
         for name in _CACHE_ATTRS:
             if name in m.__dict__:
