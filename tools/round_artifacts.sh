@@ -29,7 +29,7 @@ rm -rf $out
 # the rank share of the emulated 8-way view-parallel job: per-kernel table of ITS steps (the shard steps are the last ones of the run)
 cd /tmp
 rocprofv3 --kernel-trace -d $out -o bench --output-format csv -- python $R/bench.py --views 8 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --shard-emulate 0/8 > $O/prof_shard.log 2>&1
-python $R/tools/trace_summary.py $out $O/step_trace_v8_shard0of8.json > $O/step_trace_v8_shard0of8.txt
+TRACE_LAST_GROUP=1 python $R/tools/trace_summary.py $out $O/step_trace_v8_shard0of8.json > $O/step_trace_v8_shard0of8.txt
 rm -rf $out
 # weight prefetch on / off, alternating, same box
 cd $R

@@ -25,6 +25,8 @@ def main():
     # the steady (graph-replayed) steps all have the same launch count: the MOST COMMON one (the very last segment may carry tear-down copies)
     import collections
     n_last = collections.Counter(s[1] - s[0] for s in segs).most_common(1)[0][0]
+    if os.environ.get("TRACE_LAST_GROUP") and len(segs) > 2:       # a run with two workloads (bench.py --shard-emulate: the shard's steps come last)
+        n_last = segs[-2][1] - segs[-2][0]
     steady = [s for s in segs if s[1] - s[0] == n_last][-20:]
     if os.environ.get("TRACE_LAST_STEPS"):          # eager workloads (tools/bench_train.py): the launch count may differ by step
         steady = segs[-int(os.environ["TRACE_LAST_STEPS"]):]
