@@ -268,3 +268,30 @@ def test_activation_forward_planes_and_backward(hip, act, rows, cols):
     assert none is None and torch.equal(only_planes, sp)
     dx = bw.act_backward(dy.cuda(), x.detach().cuda(), code)
     assert rel_err(dx, x.grad) < 3e-6
+
+
+@pytest.mark.parametrize("N,K", [(320, 640), (1280, 320), (48, 200), (5, 96)])
+def test_pack_linear_transposed_source_is_bit_identical(hip, N, K):
+    """mvd_pack_linear_weight_t (round 6: the dgrad weight W^T packed straight from the parameter) writes the SAME image as packing an
+    explicit transposed copy -- same elements, same power-of-two scale, same micro-tile layout, zero padding included."""
+    w = (torch.randn(N, K, generator=g(70)) * 0.05).cuda()
+    a = hip.pack_linear(w.t().contiguous(), like=w)          # image of W^T (K rows, N columns) from a transposed copy
+    b = hip.pack_linear_t(w, like=w)                         # ... straight from W
+    assert (a.N, a.K, a.n_real, a.acc_scale) == (b.N, b.K, b.n_real, b.acc_scale)
+    assert torch.equal(a.data, b.data)
+
+
+@pytest.mark.parametrize("rows,cols", [(4096, 320), (37, 50), (1024, 5), (8192, 1280)])
+def test_col_sum_pow2_equals_the_two_passes(hip, rows, cols):
+    """mvd_col_sum_pow2 (round 6): bias gradient and power-of-two operand scale of a dY from one pass == mvd_col_sum and mvd_pow2_scale,
+    bit for bit (the same fp64 partials in the same order; the same maximum)."""
+    from mvdfusion_amd import backward as bw
+    dy = (torch.randn(rows, cols, generator=g(71)) * 3e-6).cuda()
+    db, sc, isc = bw._colsum_pow2_scale(dy, rows, cols)
+    sc2, isc2 = bw._pow2_scale(dy)
+    assert torch.equal(db, bw.col_sum(dy, rows, cols))
+    assert float(sc) == float(sc2) and float(isc) == float(isc2) and 1024.0 <= float(dy.abs().max()) * float(sc) < 2048.0
+    assert rel_err(db.cpu(), dy.double().sum(0).float().cpu()) < 1e-5
+    # the scratch word is left zero: a second call gives the same answer
+    db3, sc3, _ = bw._colsum_pow2_scale(dy * 0.5, rows, cols)
+    assert float(sc3) == 2.0 * float(sc)
